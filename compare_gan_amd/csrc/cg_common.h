@@ -1,0 +1,90 @@
+// Shared device/host helpers for libcgamd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "cgamd.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- error bookkeeping -------------------------------------------------------------------
+void cg_set_error(const char* fmt, ...);
+#define CG_FAIL(code, ...)          \
+  do {                              \
+    cg_set_error(__VA_ARGS__);      \
+    return (code);                  \
+  } while (0)
+#define CG_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess)                                                 \
+      CG_FAIL(CG_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__));      \
+  } while (0)
+
+// ---- bf16 conversion (round-to-nearest-even, same as torch / TF) ---------------------------
+__host__ __device__ __forceinline__ float bf2f(bf16_t v) {
+  union { uint32_t u; float f; } c;
+  c.u = ((uint32_t)v) << 16;
+  return c.f;
+}
+__host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+struct __attribute__((aligned(16))) bf16x8_raw {
+  bf16_t v[8];
+};
+
+// ---- division by a runtime constant --------------------------------------------------------
+struct FastDiv {
+  uint32_t d, mul, shr;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - d)) / d + 1);
+  return f;
+}
+// valid for 0 <= n < 2^31
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return (__umulhi(n, f.mul) + n) >> f.shr;
+}
+
+// ---- reductions ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float* sm4) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm4[w] = v;
+  __syncthreads();
+  return sm4[0] + sm4[1] + sm4[2] + sm4[3];
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,554 @@
+// Element-wise, pooling and small reduction kernels of the G/D graphs (HBM-bound: 16-byte
+// vector accesses, grid-stride loops capped at 2048 blocks).  Contracts: include/cgamd.h.
+#include "cg_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(int64_t work_items) {
+  int64_t b = (work_items + kBlock - 1) / kBlock;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+union V8 {
+  uint4 q;
+  bf16_t h[8];
+};
+
+// out[i] = f(a[i], b[i]) over bf16 arrays (b optional), 8 elements per lane when aligned.
+template <typename F>
+__global__ void ew2_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                           bf16_t* __restrict__ out, int64_t n, F f) {
+  const bool aligned = ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0;
+  const int64_t nv = aligned ? n / 8 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    V8 va, vb, vo;
+    va.q = reinterpret_cast<const uint4*>(a)[i];
+    if (b) vb.q = reinterpret_cast<const uint4*>(b)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vo.h[e] = f2bf(f(bf2f(va.h[e]), b ? bf2f(vb.h[e]) : 0.f));
+    reinterpret_cast<uint4*>(out)[i] = vo.q;
+  }
+  for (int64_t i = nv * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = f2bf(f(bf2f(a[i]), b ? bf2f(b[i]) : 0.f));
+}
+
+struct LreluF {
+  float slope;
+  __device__ float operator()(float x, float) const { return x > 0.f ? x : slope * x; }
+};
+struct LreluBwdF {
+  float slope;
+  __device__ float operator()(float x, float dy) const { return x > 0.f ? dy : slope * dy; }
+};
+struct AxpbyF {
+  float alpha, beta;
+  __device__ float operator()(float a, float b) const { return alpha * a + beta * b; }
+};
+
+// ---- pooling -------------------------------------------------------------------------------
+// one thread handles 8 channels of one output pixel (C % 8 == 0) or 1 channel otherwise.
+template <bool VEC, bool MAXP>
+__global__ void pool2_kernel(const bf16_t* __restrict__ x, int N, int H, int W, int C,
+                             bf16_t* __restrict__ y) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int CV = VEC ? C / 8 : C;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int ow = (int)(p % Wo);
+    p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int64_t base = (((int64_t)n * H + oh * 2) * W + ow * 2) * C;
+    if (VEC) {
+      V8 v[4], o;
+      const bf16_t* xp = x + base + cv * 8;
+      v[0].q = *reinterpret_cast<const uint4*>(xp);
+      v[1].q = *reinterpret_cast<const uint4*>(xp + C);
+      v[2].q = *reinterpret_cast<const uint4*>(xp + (int64_t)W * C);
+      v[3].q = *reinterpret_cast<const uint4*>(xp + (int64_t)W * C + C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = bf2f(v[0].h[e]), b = bf2f(v[1].h[e]), c = bf2f(v[2].h[e]),
+                    d = bf2f(v[3].h[e]);
+        o.h[e] = MAXP ? f2bf(fmaxf(fmaxf(a, b), fmaxf(c, d))) : f2bf(0.25f * (a + b + c + d));
+      }
+      *reinterpret_cast<uint4*>(y + (((int64_t)n * Ho + oh) * Wo + ow) * C + cv * 8) = o.q;
+    } else {
+      const bf16_t* xp = x + base + cv;
+      const float a = bf2f(xp[0]), b = bf2f(xp[C]), c = bf2f(xp[(int64_t)W * C]),
+                  d = bf2f(xp[(int64_t)W * C + C]);
+      y[(((int64_t)n * Ho + oh) * Wo + ow) * C + cv] =
+          MAXP ? f2bf(fmaxf(fmaxf(a, b), fmaxf(c, d))) : f2bf(0.25f * (a + b + c + d));
+    }
+  }
+}
+
+// gradient: avg: dx = dy/4 broadcast.  max: route dy to the FIRST maximal tap (row-major order).
+template <bool MAXP>
+__global__ void pool2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                 int N, int H, int W, int C, bf16_t* __restrict__ dx) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int ow = (int)(p % Wo);
+    p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int64_t base = (((int64_t)n * H + oh * 2) * W + ow * 2) * C + c;
+    const int64_t o1 = C, o2 = (int64_t)W * C, o3 = (int64_t)W * C + C;
+    const float g = bf2f(dy[i]);
+    if (MAXP) {
+      const float a = bf2f(x[base]), b = bf2f(x[base + o1]), cc = bf2f(x[base + o2]),
+                  d = bf2f(x[base + o3]);
+      const float m = fmaxf(fmaxf(a, b), fmaxf(cc, d));
+      int sel = 3;
+      if (a == m) sel = 0;
+      else if (b == m) sel = 1;
+      else if (cc == m) sel = 2;
+      const bf16_t z = 0, gv = dy[i];
+      dx[base] = sel == 0 ? gv : z;
+      dx[base + o1] = sel == 1 ? gv : z;
+      dx[base + o2] = sel == 2 ? gv : z;
+      dx[base + o3] = sel == 3 ? gv : z;
+    } else {
+      const bf16_t q = f2bf(0.25f * g);
+      dx[base] = q;
+      dx[base + o1] = q;
+      dx[base + o2] = q;
+      dx[base + o3] = q;
+    }
+  }
+}
+
+// ---- spatial reduce over HW per (n, c) -----------------------------------------------------
+// block = 256 threads handles one n and 64 channels; 4 waves split HW; LDS combine.
+__global__ void spatial_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
+                                      int HW, int C, float scale, bf16_t* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C) {
+    const bf16_t* xp = x + (int64_t)n * HW * C + c;
+    const bf16_t* gp = gate ? gate + (int64_t)n * HW * C + c : nullptr;
+    for (int p = w; p < HW; p += 4) {
+      float v = bf2f(xp[(int64_t)p * C]);
+      if (gp && !(bf2f(gp[(int64_t)p * C]) > 0.f)) v = 0.f;
+      s += v;
+    }
+  }
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    out[(int64_t)n * C + c] = f2bf(scale * (part[0][l] + part[1][l] + part[2][l] + part[3][l]));
+  }
+}
+
+__global__ void spatial_reduce_bwd_kernel(const bf16_t* __restrict__ gate,
+                                          const bf16_t* __restrict__ dout, int HW, int C,
+                                          float scale, int64_t total,
+                                          bf16_t* __restrict__ dx) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const int64_t n = i / ((int64_t)HW * C);
+    float g = scale * bf2f(dout[n * C + c]);
+    if (gate && !(bf2f(gate[i]) > 0.f)) g = 0.f;
+    dx[i] = f2bf(g);
+  }
+}
+
+// ---- heads ---------------------------------------------------------------------------------
+__global__ void head_kernel(const float* __restrict__ x, int kind, float* __restrict__ y,
+                            int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    y[i] = kind == 0 ? 1.f / (1.f + expf(-v)) : 0.5f * tanhf(v) + 0.5f;
+  }
+}
+__global__ void head_bwd_kernel(const float* __restrict__ y, int kind, const void* dy,
+                                int dy_is_f32, bf16_t* __restrict__ dx, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float yy = y[i];
+    const float g = dy_is_f32 ? reinterpret_cast<const float*>(dy)[i]
+                              : bf2f(reinterpret_cast<const bf16_t*>(dy)[i]);
+    // sigmoid' = y(1-y);  (0.5 tanh + 0.5)' = 0.5 (1 - tanh^2) = 2 y (1 - y)
+    const float d = kind == 0 ? yy * (1.f - yy) : 2.f * yy * (1.f - yy);
+    dx[i] = f2bf(g * d);
+  }
+}
+
+__global__ void cast_f2b_kernel(const float* __restrict__ x, float a, float b,
+                                bf16_t* __restrict__ y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = f2bf(x[i] * a + b);
+}
+__global__ void cast_b2f_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = bf2f(x[i]);
+}
+
+// ---- column sums: [rows, C] bf16 -> fp32 [C] -------------------------------------------------
+// grid (ceil(C/64), splits): each block sums a row slab for 64 columns; partials -> ws; reduce.
+__global__ void colsum_part_kernel(const bf16_t* __restrict__ x, int64_t rows, int C,
+                                   int64_t rows_per_split, float* __restrict__ part) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = min(rows, r0 + rows_per_split);
+  float s = 0.f;
+  if (c < C)
+    for (int64_t r = r0 + w; r < r1; r += 4) s += bf2f(x[r * C + c]);
+  sm[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    part[(int64_t)blockIdx.y * C + c] = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int splits, int C,
+                                    float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * C + c];
+  out[c] = s;
+}
+inline int colsum_splits(int64_t rows, int C) {
+  const int ct = cdiv(C, 64);
+  int s = cdiv(1024, ct);
+  const int64_t maxs = rows / 64 > 0 ? rows / 64 : 1;
+  if (s > maxs) s = (int)maxs;
+  if (s < 1) s = 1;
+  return s;
+}
+
+// ---- row dot ---------------------------------------------------------------------------------
+__global__ void rowdot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, int C,
+                              float* __restrict__ out) {
+  __shared__ float sm4[4];
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    s += bf2f(a[(int64_t)r * C + c]) * bf2f(b[(int64_t)r * C + c]);
+  s = block_sum_256(s, sm4);
+  if (threadIdx.x == 0) out[r] = s;
+}
+__global__ void rowdot_bwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                  const float* __restrict__ dout, int C, int64_t total,
+                                  bf16_t* __restrict__ da, bf16_t* __restrict__ db) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float g = dout[i / C];
+    if (da) da[i] = f2bf(g * bf2f(b[i]));
+    if (db) db[i] = f2bf(g * bf2f(a[i]));
+  }
+}
+
+__global__ void one_hot_kernel(const int32_t* __restrict__ labels, int K, int64_t total,
+                               bf16_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int b = (int)(i / K), k = (int)(i - (int64_t)b * K);
+    out[i] = labels[b] == k ? (bf16_t)0x3f80 : (bf16_t)0;
+  }
+}
+
+// ---- general pooling (Inception graph) -----------------------------------------------------
+__global__ void pool2d_kernel(const bf16_t* __restrict__ x, int N, int H, int W, int C, int k,
+                              int s, int p, int kind, int Ho, int Wo, bf16_t* __restrict__ y) {
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    int64_t q = i / C;
+    const int ow = (int)(q % Wo);
+    q /= Wo;
+    const int oh = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    float acc = kind == 0 ? -3.4e38f : 0.f;
+    int cnt = 0;
+    for (int r = 0; r < k; ++r) {
+      const int ih = oh * s - p + r;
+      if (ih < 0 || ih >= H) continue;
+      for (int t = 0; t < k; ++t) {
+        const int iw = ow * s - p + t;
+        if (iw < 0 || iw >= W) continue;
+        const float v = bf2f(x[(((int64_t)n * H + ih) * W + iw) * C + c]);
+        acc = kind == 0 ? fmaxf(acc, v) : acc + v;
+        ++cnt;
+      }
+    }
+    y[i] = f2bf(kind == 0 ? acc : acc / (float)(cnt > 0 ? cnt : 1));
+  }
+}
+
+// TF1 legacy bilinear resize (align_corners=False, half_pixel_centers=False):
+//   src = dst * (in / out);  lo = floor(src), hi = min(lo+1, in-1), frac = src - lo.
+__global__ void inception_preprocess_kernel(const float* __restrict__ x, int N, int H, int W,
+                                            int C, int Ho, int Wo, bf16_t* __restrict__ y) {
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    int64_t q = i / C;
+    const int ow = (int)(q % Wo);
+    q /= Wo;
+    const int oh = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    const float fy = oh * sh, fx = ow * sw;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float wy = fy - y0, wx = fx - x0;
+    const float* xp = x + (int64_t)n * H * W * C + c;
+    const float tl = xp[((int64_t)y0 * W + x0) * C], tr = xp[((int64_t)y0 * W + x1) * C];
+    const float bl = xp[((int64_t)y1 * W + x0) * C], br = xp[((int64_t)y1 * W + x1) * C];
+    const float top = tl + (tr - tl) * wx, bot = bl + (br - bl) * wx;
+    const float v = top + (bot - top) * wy;
+    y[i] = f2bf((v - 128.f) / 128.f);
+  }
+}
+
+}  // namespace
+
+#define CG_NONNEG(n, who) \
+  if ((n) < 0) CG_FAIL(CG_ERR_BAD_ARG, who ": negative size")
+
+extern "C" int cg_lrelu(const void* x, float slope, void* y, int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_lrelu");
+  if (n == 0) return CG_OK;
+  if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "cg_lrelu: null pointer");
+  ew2_kernel<<<grid_for(n / 8 + 1), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, LreluF{slope});
+  CG_CHECK_LAUNCH("cg_lrelu");
+  return CG_OK;
+}
+extern "C" int cg_lrelu_bwd(const void* x, const void* dy, float slope, void* dx, int64_t n,
+                            cgStream stream) {
+  CG_NONNEG(n, "cg_lrelu_bwd");
+  if (n == 0) return CG_OK;
+  if (!x || !dy || !dx) CG_FAIL(CG_ERR_BAD_ARG, "cg_lrelu_bwd: null pointer");
+  ew2_kernel<<<grid_for(n / 8 + 1), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, LreluBwdF{slope});
+  CG_CHECK_LAUNCH("cg_lrelu_bwd");
+  return CG_OK;
+}
+extern "C" int cg_axpby(const void* a, float alpha, const void* b, float beta, void* out,
+                        int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_axpby");
+  if (n == 0) return CG_OK;
+  if (!a || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_axpby: null pointer");
+  ew2_kernel<<<grid_for(n / 8 + 1), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, AxpbyF{alpha, b ? beta : 0.f});
+  CG_CHECK_LAUNCH("cg_axpby");
+  return CG_OK;
+}
+
+static int check_pool(const void* x, int N, int H, int W, int C, const void* y, const char* who) {
+  if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "%s: null pointer", who);
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1))
+    CG_FAIL(CG_ERR_BAD_ARG, "%s: bad shape [%d,%d,%d,%d] (H, W must be even)", who, N, H, W, C);
+  return CG_OK;
+}
+template <bool MAXP>
+static int pool2_launch(const void* x, int N, int H, int W, int C, void* y, hipStream_t st) {
+  const bool vec = (C % 8) == 0;
+  const int64_t work = (int64_t)N * (H / 2) * (W / 2) * (vec ? C / 8 : C);
+  if (vec)
+    pool2_kernel<true, MAXP><<<grid_for(work), kBlock, 0, st>>>((const bf16_t*)x, N, H, W, C,
+                                                                 (bf16_t*)y);
+  else
+    pool2_kernel<false, MAXP><<<grid_for(work), kBlock, 0, st>>>((const bf16_t*)x, N, H, W, C,
+                                                                  (bf16_t*)y);
+  return CG_OK;
+}
+extern "C" int cg_avgpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream) {
+  int rc = check_pool(x, N, H, W, C, y, "cg_avgpool2");
+  if (rc) return rc;
+  pool2_launch<false>(x, N, H, W, C, y, (hipStream_t)stream);
+  CG_CHECK_LAUNCH("cg_avgpool2");
+  return CG_OK;
+}
+extern "C" int cg_maxpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream) {
+  int rc = check_pool(x, N, H, W, C, y, "cg_maxpool2");
+  if (rc) return rc;
+  pool2_launch<true>(x, N, H, W, C, y, (hipStream_t)stream);
+  CG_CHECK_LAUNCH("cg_maxpool2");
+  return CG_OK;
+}
+extern "C" int cg_avgpool2_bwd(const void* dy, int N, int H, int W, int C, void* dx,
+                               cgStream stream) {
+  int rc = check_pool(dy, N, H, W, C, dx, "cg_avgpool2_bwd");
+  if (rc) return rc;
+  const int64_t work = (int64_t)N * (H / 2) * (W / 2) * C;
+  pool2_bwd_kernel<false><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
+      nullptr, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
+  CG_CHECK_LAUNCH("cg_avgpool2_bwd");
+  return CG_OK;
+}
+extern "C" int cg_maxpool2_bwd(const void* x, const void* dy, int N, int H, int W, int C,
+                               void* dx, cgStream stream) {
+  int rc = check_pool(x, N, H, W, C, dx, "cg_maxpool2_bwd");
+  if (rc) return rc;
+  if (!dy) CG_FAIL(CG_ERR_BAD_ARG, "cg_maxpool2_bwd: null dy");
+  const int64_t work = (int64_t)N * (H / 2) * (W / 2) * C;
+  pool2_bwd_kernel<true><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
+  CG_CHECK_LAUNCH("cg_maxpool2_bwd");
+  return CG_OK;
+}
+
+extern "C" int cg_spatial_reduce(const void* x, const void* gate, int N, int HW, int C,
+                                 float scale, void* out, cgStream stream) {
+  if (!x || !out || N <= 0 || HW <= 0 || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_spatial_reduce: bad argument");
+  dim3 grid(cdiv(C, 64), N);
+  spatial_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)gate, HW, C, scale, (bf16_t*)out);
+  CG_CHECK_LAUNCH("cg_spatial_reduce");
+  return CG_OK;
+}
+extern "C" int cg_spatial_reduce_bwd(const void* gate, const void* dout, int N, int HW, int C,
+                                     float scale, void* dx, cgStream stream) {
+  if (!dout || !dx || N <= 0 || HW <= 0 || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_spatial_reduce_bwd: bad argument");
+  const int64_t total = (int64_t)N * HW * C;
+  spatial_reduce_bwd_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)gate, (const bf16_t*)dout, HW, C, scale, total, (bf16_t*)dx);
+  CG_CHECK_LAUNCH("cg_spatial_reduce_bwd");
+  return CG_OK;
+}
+
+extern "C" int cg_head(const float* x, int kind, float* y, int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_head");
+  if (n == 0) return CG_OK;
+  if (!x || !y || (kind != 0 && kind != 1)) CG_FAIL(CG_ERR_BAD_ARG, "cg_head: bad argument");
+  head_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(x, kind, y, n);
+  CG_CHECK_LAUNCH("cg_head");
+  return CG_OK;
+}
+extern "C" int cg_head_bwd(const float* y, int kind, const void* dy, int dy_is_f32, void* dx,
+                           int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_head_bwd");
+  if (n == 0) return CG_OK;
+  if (!y || !dy || !dx || (kind != 0 && kind != 1))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_head_bwd: bad argument");
+  head_bwd_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(y, kind, dy, dy_is_f32,
+                                                                  (bf16_t*)dx, n);
+  CG_CHECK_LAUNCH("cg_head_bwd");
+  return CG_OK;
+}
+
+extern "C" int cg_cast_f32_to_bf16(const float* x, void* y, int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_cast_f32_to_bf16");
+  if (n == 0) return CG_OK;
+  if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "cg_cast_f32_to_bf16: null pointer");
+  cast_f2b_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(x, 1.f, 0.f, (bf16_t*)y, n);
+  CG_CHECK_LAUNCH("cg_cast_f32_to_bf16");
+  return CG_OK;
+}
+extern "C" int cg_affine_f32_to_bf16(const float* x, float a, float b, void* y, int64_t n,
+                                     cgStream stream) {
+  CG_NONNEG(n, "cg_affine_f32_to_bf16");
+  if (n == 0) return CG_OK;
+  if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "cg_affine_f32_to_bf16: null pointer");
+  cast_f2b_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(x, a, b, (bf16_t*)y, n);
+  CG_CHECK_LAUNCH("cg_affine_f32_to_bf16");
+  return CG_OK;
+}
+extern "C" int cg_cast_bf16_to_f32(const void* x, float* y, int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_cast_bf16_to_f32");
+  if (n == 0) return CG_OK;
+  if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "cg_cast_bf16_to_f32: null pointer");
+  cast_b2f_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>((const bf16_t*)x, y, n);
+  CG_CHECK_LAUNCH("cg_cast_bf16_to_f32");
+  return CG_OK;
+}
+
+extern "C" size_t cg_colsum_workspace_bytes(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return align_up((size_t)colsum_splits(rows, C) * C * sizeof(float), 256);
+}
+extern "C" int cg_colsum(const void* x, int64_t rows, int C, float* out, void* ws,
+                         size_t ws_bytes, cgStream stream) {
+  if (!x || !out || rows <= 0 || C <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_colsum: bad argument");
+  if (!ws || ws_bytes < cg_colsum_workspace_bytes(rows, C))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_colsum: workspace too small");
+  const int splits = colsum_splits(rows, C);
+  const int64_t rps = (rows + splits - 1) / splits;
+  dim3 grid(cdiv(C, 64), splits);
+  hipStream_t st = (hipStream_t)stream;
+  colsum_part_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, C, rps, (float*)ws);
+  CG_CHECK_LAUNCH("cg_colsum(part)");
+  colsum_final_kernel<<<cdiv(C, 256), 256, 0, st>>>((const float*)ws, splits, C, out);
+  CG_CHECK_LAUNCH("cg_colsum(final)");
+  return CG_OK;
+}
+
+extern "C" int cg_rowdot(const void* a, const void* b, int B, int C, float* out,
+                         cgStream stream) {
+  if (!a || !b || !out || B <= 0 || C <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_rowdot: bad argument");
+  rowdot_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, C, out);
+  CG_CHECK_LAUNCH("cg_rowdot");
+  return CG_OK;
+}
+extern "C" int cg_rowdot_bwd(const void* a, const void* b, const float* dout, int B, int C,
+                             void* da, void* db, cgStream stream) {
+  if (!a || !b || !dout || B <= 0 || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_rowdot_bwd: bad argument");
+  const int64_t total = (int64_t)B * C;
+  rowdot_bwd_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)a, (const bf16_t*)b, dout, C, total, (bf16_t*)da, (bf16_t*)db);
+  CG_CHECK_LAUNCH("cg_rowdot_bwd");
+  return CG_OK;
+}
+
+extern "C" int cg_one_hot(const int32_t* labels, int B, int K, void* out, cgStream stream) {
+  if (!labels || !out || B <= 0 || K <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_one_hot: bad argument");
+  const int64_t total = (int64_t)B * K;
+  one_hot_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(labels, K, total,
+                                                                      (bf16_t*)out);
+  CG_CHECK_LAUNCH("cg_one_hot");
+  return CG_OK;
+}
+
+extern "C" int cg_pool2d(const void* x, int N, int H, int W, int C, int k, int s, int p, int kind,
+                         int Ho, int Wo, void* y, cgStream stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || p < 0 || Ho <= 0 ||
+      Wo <= 0 || (kind != 0 && kind != 1))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_pool2d: bad argument");
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  pool2d_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, N, H, W, C, k, s, p, kind, Ho, Wo, (bf16_t*)y);
+  CG_CHECK_LAUNCH("cg_pool2d");
+  return CG_OK;
+}
+
+extern "C" int cg_inception_preprocess(const float* x, int N, int H, int W, int C, int Ho, int Wo,
+                                       void* y, cgStream stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_inception_preprocess: bad argument");
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  inception_preprocess_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
+      x, N, H, W, C, Ho, Wo, (bf16_t*)y);
+  CG_CHECK_LAUNCH("cg_inception_preprocess");
+  return CG_OK;
+}

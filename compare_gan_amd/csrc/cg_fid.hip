@@ -1,0 +1,375 @@
+// FID / Inception-score statistics in fp64 (metrics/fid_score.py:44-75,
+// metrics/inception_score.py:39-48; arithmetic restated from tensorflow_gan):
+// centred covariance GEMM, general fp64 GEMM, parallel one-sided Jacobi eigensolver for the
+// symmetric square roots, and the classifier score.  v1 kernels are LDS-tiled vector-ALU fp64.
+#include "cg_common.h"
+
+namespace {
+
+// ---- column means in fp64 ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colmean_part_kernel(const float* __restrict__ x, int64_t n,
+                                                           int d, int64_t rows_per_split,
+                                                           double* __restrict__ part) {
+  __shared__ double sm[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split, r1 = min(n, r0 + rows_per_split);
+  double s = 0.0;
+  if (c < d)
+    for (int64_t r = r0 + w; r < r1; r += 4) s += (double)x[r * d + c];
+  sm[w][l] = s;
+  __syncthreads();
+  if (w == 0 && c < d) part[(int64_t)blockIdx.y * d + c] = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
+}
+__global__ void colmean_final_kernel(const double* __restrict__ part, int splits, int d,
+                                     double inv_n, double* __restrict__ mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  double s = 0.0;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * d + c];
+  mean[c] = s * inv_n;
+}
+
+// ---- tiled fp64 GEMM: C[m,n] = scale * sum_k A(i,k) B(k,j) ------------------------------------
+// MODE 0: A,B fp64 with optional transposes.  MODE 1: covariance: A = B = (x - mean)^T from fp32 x.
+constexpr int GT = 64, GK = 16;
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(const void* __restrict__ ap,
+                                                       const void* __restrict__ bp,
+                                                       const double* __restrict__ mean,
+                                                       double* __restrict__ c, int M, int N,
+                                                       int64_t K, int ta, int tb, double scale) {
+  __shared__ double As[GK][GT + 1];
+  __shared__ double Bs[GK][GT + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int64_t k0 = 0; k0 < K; k0 += GK) {
+    // load A tile [GK][GT] (k-major) and B tile [GK][GT]
+    for (int e = threadIdx.x; e < GK * GT; e += 256) {
+      double av = 0.0, bv = 0.0;
+      if (MODE == 1) {
+        const int kk = e / GT, ii = e - kk * GT;  // consecutive threads -> consecutive columns
+        const int64_t k = k0 + kk;
+        const float* x = (const float*)ap;
+        if (k < K && i0 + ii < M) av = (double)x[k * M + i0 + ii] - mean[i0 + ii];
+        if (k < K && j0 + ii < N) bv = (double)x[k * N + j0 + ii] - mean[j0 + ii];
+        As[kk][ii] = av;
+        Bs[kk][ii] = bv;
+      } else {
+        const double* A = (const double*)ap;
+        const double* B = (const double*)bp;
+        {
+          int kk, ii;
+          if (ta) { kk = e / GT; ii = e - kk * GT; } else { ii = e / GK; kk = e - ii * GK; }
+          const int64_t k = k0 + kk;
+          if (k < K && i0 + ii < M) av = ta ? A[k * M + i0 + ii] : A[(int64_t)(i0 + ii) * K + k];
+          As[kk][ii] = av;
+        }
+        {
+          int kk, jj;
+          if (tb) { jj = e / GK; kk = e - jj * GK; } else { kk = e / GT; jj = e - kk * GT; }
+          const int64_t k = k0 + kk;
+          if (k < K && j0 + jj < N) bv = tb ? B[(int64_t)(j0 + jj) * K + k] : B[k * N + j0 + jj];
+          Bs[kk][jj] = bv;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = As[kk][ty * 4 + u];
+        b[u] = Bs[kk][tx * 4 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+      if (i < M && j < N) c[(int64_t)i * N + j] = acc[u][v] * scale;
+    }
+}
+
+// ---- one-sided Jacobi (Hestenes) on the ROWS of G (= A, symmetric) and V (= I) ---------------
+// Round r of a sweep pairs rows by the circle method; one block per pair.
+__global__ void jacobi_init_kernel(double* __restrict__ v, int d, int* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)d * d) v[i] = (i / d == i % d) ? 1.0 : 0.0;
+  if (i == 0) {
+    flags[0] = 0;  // converged
+    flags[1] = 0;  // rotations in current sweep
+  }
+}
+__global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ g,
+                                                           double* __restrict__ v, int d, int np,
+                                                           int round, double tol,
+                                                           int* __restrict__ flags) {
+  if (flags[0]) return;
+  __shared__ double sm[3][4];
+  __shared__ double s_c, s_s;
+  __shared__ int s_rot;
+  const int i = blockIdx.x;
+  const int m = np - 1;  // np even (padded)
+  int p, q;
+  if (i == 0) {
+    p = np - 1;
+    q = round % m;
+  } else {
+    p = (round + i) % m;
+    q = (round - i + m) % m;
+  }
+  if (p >= d || q >= d) return;  // dummy player
+  if (p > q) { const int t = p; p = q; q = t; }
+  double* gp = g + (int64_t)p * d;
+  double* gq = g + (int64_t)q * d;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const double x = gp[k], y = gq[k];
+    a += x * x;
+    b += y * y;
+    c += x * y;
+  }
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  c = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][threadIdx.x >> 6] = a;
+    sm[1][threadIdx.x >> 6] = b;
+    sm[2][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double al = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    const double be = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    const double ga = sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3];
+    int rot = 0;
+    double cs = 1.0, sn = 0.0;
+    if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300) {
+      const double zeta = (be - al) / (2.0 * ga);
+      const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      cs = 1.0 / sqrt(1.0 + t * t);
+      sn = cs * t;
+      rot = 1;
+    }
+    s_c = cs;
+    s_s = sn;
+    s_rot = rot;
+    if (rot) atomicAdd(&flags[1], 1);
+  }
+  __syncthreads();
+  if (!s_rot) return;
+  const double cs = s_c, sn = s_s;
+  double* vp = v + (int64_t)p * d;
+  double* vq = v + (int64_t)q * d;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const double x = gp[k], y = gq[k];
+    gp[k] = cs * x - sn * y;
+    gq[k] = sn * x + cs * y;
+    const double vx = vp[k], vy = vq[k];
+    vp[k] = cs * vx - sn * vy;
+    vq[k] = sn * vx + cs * vy;
+  }
+}
+__global__ void jacobi_sweep_end_kernel(int* flags) {
+  if (flags[0]) return;
+  if (flags[1] == 0) flags[0] = 1;
+  flags[1] = 0;
+}
+// eigenvalue_i = g_i . v_i  (g_i = A v_i = lambda_i v_i, |v_i| = 1)
+__global__ __launch_bounds__(256) void jacobi_eigvals_kernel(const double* __restrict__ g,
+                                                             const double* __restrict__ v, int d,
+                                                             double* __restrict__ w) {
+  __shared__ double sm[4];
+  const int i = blockIdx.x;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < d; k += 256) s += g[(int64_t)i * d + k] * v[(int64_t)i * d + k];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) w[i] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// ---- inception score ----------------------------------------------------------------------------
+// pass 1: q partial sums of softmax rows; pass 2: KL sums.
+__global__ __launch_bounds__(256) void is_pass_kernel(const float* __restrict__ logits, int64_t n,
+                                                      int k, int64_t rows_per_block, int pass,
+                                                      const double* __restrict__ logq,
+                                                      double* __restrict__ part) {
+  // one wave per row at a time; 4 waves per block
+  extern __shared__ double sq[];  // [4][k] for pass 1
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  if (pass == 1)
+    for (int c = l; c < k; c += 64) sq[w * k + c] = 0.0;
+  double klsum = 0.0;
+  for (int64_t r = r0 + w; r < r1; r += 4) {
+    const float* row = logits + r * k;
+    double mx = -1e300;
+    for (int c = l; c < k; c += 64) mx = fmax(mx, (double)row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    double se = 0.0;
+    for (int c = l; c < k; c += 64) se += exp((double)row[c] - mx);
+    se = wave_sum_d(se);
+    const double lse = mx + log(se);
+    if (pass == 1) {
+      for (int c = l; c < k; c += 64) sq[w * k + c] += exp((double)row[c] - lse);
+    } else {
+      double kl = 0.0;
+      for (int c = l; c < k; c += 64) {
+        const double lp = (double)row[c] - lse;
+        kl += exp(lp) * (lp - logq[c]);
+      }
+      klsum += wave_sum_d(kl);
+    }
+  }
+  __syncthreads();
+  if (pass == 1) {
+    for (int c = threadIdx.x; c < k; c += 256)
+      part[(int64_t)blockIdx.x * k + c] = sq[c] + sq[k + c] + sq[2 * k + c] + sq[3 * k + c];
+  } else {
+    __shared__ double skl[4];
+    if (l == 0) skl[w] = klsum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = skl[0] + skl[1] + skl[2] + skl[3];
+  }
+}
+__global__ void is_logq_kernel(const double* __restrict__ part, int blocks, int k, double inv_n,
+                               double* __restrict__ logq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += part[(int64_t)b * k + c];
+  logq[c] = log(s * inv_n);
+}
+__global__ void is_final_kernel(const double* __restrict__ part, int blocks, double inv_n,
+                                double* __restrict__ score) {
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += part[b];
+  *score = exp(s * inv_n);
+}
+
+inline int mean_splits(int64_t n, int d) {
+  const int ct = cdiv(d, 64);
+  int s = cdiv(1024, ct);
+  const int64_t maxs = n / 16 > 0 ? n / 16 : 1;
+  if (s > maxs) s = (int)maxs;
+  if (s < 1) s = 1;
+  return s;
+}
+inline int is_blocks(int64_t n) {
+  int64_t b = (n + 15) / 16;
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" size_t cg_mean_cov_workspace_bytes(int64_t n, int d) {
+  if (n <= 0 || d <= 0) return 0;
+  return align_up((size_t)mean_splits(n, d) * d * sizeof(double), 256);
+}
+
+extern "C" int cg_mean_cov_f64(const float* x, int64_t n, int d, double* mean, double* cov,
+                               void* ws, size_t ws_bytes, cgStream stream) {
+  if (!x || !mean || !cov || n <= 1 || d <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_mean_cov_f64: bad argument (need n >= 2)");
+  if (!ws || ws_bytes < cg_mean_cov_workspace_bytes(n, d))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_mean_cov_f64: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = mean_splits(n, d);
+  const int64_t rps = (n + splits - 1) / splits;
+  dim3 g1(cdiv(d, 64), splits);
+  colmean_part_kernel<<<g1, 256, 0, st>>>(x, n, d, rps, (double*)ws);
+  CG_CHECK_LAUNCH("cg_mean_cov_f64(mean part)");
+  colmean_final_kernel<<<cdiv(d, 256), 256, 0, st>>>((const double*)ws, splits, d, 1.0 / (double)n,
+                                                     mean);
+  CG_CHECK_LAUNCH("cg_mean_cov_f64(mean)");
+  dim3 g2(cdiv(d, GT), cdiv(d, GT));
+  gemm_f64_kernel<1><<<g2, 256, 0, st>>>(x, x, mean, cov, d, d, n, 1, 0, 1.0 / (double)(n - 1));
+  CG_CHECK_LAUNCH("cg_mean_cov_f64(cov)");
+  return CG_OK;
+}
+
+extern "C" int cg_gemm_f64(const double* a, const double* b, double* c, int m, int n, int k,
+                           int ta, int tb, cgStream stream) {
+  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gemm_f64: bad argument");
+  dim3 grid(cdiv(n, GT), cdiv(m, GT));
+  gemm_f64_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, nullptr, c, m, n, k, ta, tb, 1.0);
+  CG_CHECK_LAUNCH("cg_gemm_f64");
+  return CG_OK;
+}
+
+extern "C" size_t cg_syevj_workspace_bytes(int d) { return d > 0 ? 256 : 0; }
+
+extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol,
+                            void* ws, size_t ws_bytes, cgStream stream) {
+  if (!a || !w || !v || d <= 0 || max_sweeps <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_syevj_f64: bad argument");
+  if (!ws || ws_bytes < cg_syevj_workspace_bytes(d))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_syevj_f64: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int* flags = (int*)ws;
+  jacobi_init_kernel<<<cdiv((int64_t)d * d, 256), 256, 0, st>>>(v, d, flags);
+  CG_CHECK_LAUNCH("cg_syevj_f64(init)");
+  const int np = (d + 1) & ~1;
+  if (d > 1) {
+    for (int s = 0; s < max_sweeps; ++s) {
+      for (int r = 0; r < np - 1; ++r) {
+        jacobi_round_kernel<<<np / 2, 256, 0, st>>>(a, v, d, np, r, tol, flags);
+      }
+      jacobi_sweep_end_kernel<<<1, 1, 0, st>>>(flags);
+    }
+    CG_CHECK_LAUNCH("cg_syevj_f64(sweeps)");
+  }
+  jacobi_eigvals_kernel<<<d, 256, 0, st>>>(a, v, d, w);
+  CG_CHECK_LAUNCH("cg_syevj_f64(eigvals)");
+  return CG_OK;
+}
+
+extern "C" size_t cg_inception_score_workspace_bytes(int64_t n, int k) {
+  if (n <= 0 || k <= 0) return 0;
+  return align_up(((size_t)is_blocks(n) * k + (size_t)k + (size_t)is_blocks(n)) * sizeof(double),
+                  256);
+}
+
+extern "C" int cg_inception_score_f64(const float* logits, int64_t n, int k, double* score,
+                                      void* ws, size_t ws_bytes, cgStream stream) {
+  if (!logits || !score || n <= 0 || k <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_inception_score_f64: bad argument");
+  if (!ws || ws_bytes < cg_inception_score_workspace_bytes(n, k))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_inception_score_f64: workspace too small");
+  if ((size_t)4 * k * sizeof(double) > 60000)
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_inception_score_f64: k=%d too large", k);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = is_blocks(n);
+  const int64_t rpb = (n + nb - 1) / nb;
+  double* part = (double*)ws;
+  double* logq = part + (size_t)nb * k;
+  double* klp = logq + k;
+  is_pass_kernel<<<nb, 256, 4 * k * sizeof(double), st>>>(logits, n, k, rpb, 1, nullptr, part);
+  CG_CHECK_LAUNCH("cg_inception_score_f64(pass1)");
+  is_logq_kernel<<<cdiv(k, 256), 256, 0, st>>>(part, nb, k, 1.0 / (double)n, logq);
+  CG_CHECK_LAUNCH("cg_inception_score_f64(logq)");
+  is_pass_kernel<<<nb, 256, 4 * k * sizeof(double), st>>>(logits, n, k, rpb, 2, logq, klp);
+  CG_CHECK_LAUNCH("cg_inception_score_f64(pass2)");
+  is_final_kernel<<<1, 1, 0, st>>>(klp, nb, 1.0 / (double)n, score);
+  CG_CHECK_LAUNCH("cg_inception_score_f64(final)");
+  return CG_OK;
+}

@@ -1,0 +1,720 @@
+// Generalised NHWC convolution on MFMA (gfx950): forward / data-gradient / transposed conv /
+// linear all map onto ONE im2col-free implicit-GEMM gather kernel (cg_gconv) and one
+// weight-gradient kernel (cg_gwgrad).  See include/cgamd.h for the contract and the reference
+// call sites (architectures/arch_ops.py:538-592, architectures/resnet_ops.py:35-56,112-134).
+//
+// Tiling (v1): 256 threads = 4 waves; block tile BM x BN output, BK = 64 reduction slice staged
+// through LDS (register-staged double buffer, one barrier per slice); each wave owns a
+// (BM/WM) x (BN/WN) sub-tile built from v_mfma_f32_32x32x16_bf16.  LDS rows are padded by 16 B
+// (144 B stride) which makes every ds_read_b128 fragment read bank-conflict free.
+#include "cg_common.h"
+
+namespace {
+
+struct GConvArgs {
+  const bf16_t* in;
+  const bf16_t* bt;
+  void* out;
+  const float* bias;
+  const bf16_t* gate_in;
+  const bf16_t* gate_out;
+  const bf16_t* residual;
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, ulog, pt, pl;
+  int M;    // N*Ho*Wo
+  int K;    // kh*kw*Ci
+  int Kp;   // K rounded up to 8 (row stride of bt)
+  int HinU, WinU;
+  float slope_in, slope_out;
+  int out_f32;
+  FastDiv dWo, dHo, dCi, dKw;
+};
+
+constexpr int LDS_PAD = 8;  // bf16 elements (16 B)
+
+__device__ __forceinline__ uint4 gate_apply(uint4 x, uint4 g, float slope) {
+  union { uint4 q; bf16_t h[8]; } xv, gv, ov;
+  xv.q = x;
+  gv.q = g;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float gf = bf2f(gv.h[e]);
+    const float xf = bf2f(xv.h[e]);
+    ov.h[e] = gf > 0.f ? xv.h[e] : f2bf(xf * slope);
+  }
+  return ov.q;
+}
+
+// Loads 8 consecutive k (one tap, 8 channels) of im2col row described by (nbase, bh, bw).
+template <bool VEC>
+__device__ __forceinline__ uint4 load_a_chunk(const GConvArgs& a, bool row_ok, int nbase, int bh,
+                                              int bw, int k) {
+  uint4 z = make_uint4(0, 0, 0, 0);
+  if (!row_ok) return z;
+  if (VEC) {
+    if (k >= a.K) return z;
+    const uint32_t tap = fdiv((uint32_t)k, a.dCi);
+    const int c = k - (int)tap * a.Ci;
+    const int r = (int)fdiv(tap, a.dKw);
+    const int s = (int)tap - r * a.kw;
+    const int ihv = bh + r, iwv = bw + s;
+    if (ihv < 0 || iwv < 0 || ihv >= a.HinU || iwv >= a.WinU) return z;
+    const int um = (1 << a.ulog) - 1;
+    if ((ihv & um) | (iwv & um)) return z;
+    const int64_t off = ((int64_t)(nbase + (ihv >> a.ulog)) * a.Win + (iwv >> a.ulog)) * a.Ci + c;
+    uint4 x = *reinterpret_cast<const uint4*>(a.in + off);
+    if (a.gate_in) {
+      uint4 g = (a.gate_in == a.in) ? x : *reinterpret_cast<const uint4*>(a.gate_in + off);
+      x = gate_apply(x, g, a.slope_in);
+    }
+    return x;
+  } else {
+    union { uint4 q; bf16_t h[8]; } ov;
+    ov.q = z;
+    const int um = (1 << a.ulog) - 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ke = k + e;
+      if (ke >= a.K) continue;
+      const uint32_t tap = fdiv((uint32_t)ke, a.dCi);
+      const int c = ke - (int)tap * a.Ci;
+      const int r = (int)fdiv(tap, a.dKw);
+      const int s = (int)tap - r * a.kw;
+      const int ihv = bh + r, iwv = bw + s;
+      if (ihv < 0 || iwv < 0 || ihv >= a.HinU || iwv >= a.WinU) continue;
+      if ((ihv & um) | (iwv & um)) continue;
+      const int64_t off =
+          ((int64_t)(nbase + (ihv >> a.ulog)) * a.Win + (iwv >> a.ulog)) * a.Ci + c;
+      bf16_t x = a.in[off];
+      if (a.gate_in) {
+        const float g = bf2f(a.gate_in[off]);
+        if (!(g > 0.f)) x = f2bf(bf2f(x) * a.slope_in);
+      }
+      ov.h[e] = x;
+    }
+    return ov.q;
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
+  constexpr int LD = BK + LDS_PAD;
+  constexpr int CPR = BK / 8;               // 16-byte chunks per tile row
+  constexpr int LA = BM * CPR / 256;        // A chunks per thread
+  constexpr int LB = (BN * CPR + 255) / 256;  // B chunks per thread
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BM * CPR % 256 == 0, "A tile must divide over the block");
+
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * LD];
+  auto As = [&](int buf) { return smem + buf * (BM + BN) * LD; };
+  auto Bs = [&](int buf) { return smem + buf * (BM + BN) * LD + BM * LD; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-thread im2col row descriptors (fixed across the K loop) ----
+  const int seg = tid % CPR;
+  int a_nbase[LA], a_bh[LA], a_bw[LA];
+  bool a_ok[LA];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int row = tid / CPR + i * (256 / CPR);
+    const int m = m0 + row;
+    a_ok[i] = m < a.M;
+    const uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
+    const uint32_t t1 = fdiv(mm, a.dWo);
+    const int ow = (int)(mm - t1 * a.Wo);
+    const uint32_t n = fdiv(t1, a.dHo);
+    const int oh = (int)(t1 - n * a.Ho);
+    a_nbase[i] = (int)n * a.Hin;
+    a_bh[i] = oh * a.S - a.pt;
+    a_bw[i] = ow * a.S - a.pl;
+  }
+  int b_row[LB];
+  bool b_ok[LB];
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int cidx = tid + i * 256;
+    const int row = cidx / CPR;
+    b_row[i] = row;
+    b_ok[i] = (row < BN) && (n0 + row < a.Co);
+  }
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  uint4 ra[LA], rb[LB];
+
+  auto gload = [&](int it) {
+    const int k = it * BK + seg * 8;
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+      ra[i] = load_a_chunk<VEC>(a, a_ok[i], a_nbase[i], a_bh[i], a_bw[i], k);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (b_ok[i] && k < a.Kp)
+        rb[i] = *reinterpret_cast<const uint4*>(a.bt + (int64_t)(n0 + b_row[i]) * a.Kp + k);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int row = tid / CPR + i * (256 / CPR);
+      *reinterpret_cast<uint4*>(As(buf) + row * LD + seg * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      if (b_row[i] < BN) *reinterpret_cast<uint4*>(Bs(buf) + b_row[i] * LD + seg * 8) = rb[i];
+  };
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  const int arow0 = wm * (BM / WM) + (lane & 31);
+  const int brow0 = wn * (BN / WN) + (lane & 31);
+  const int koff = (lane >> 5) * 8;
+
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) gload(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8_t*>(As(buf) + (arow0 + i * 32) * LD + kk * 16 + koff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs(buf) + (brow0 + j * 32) * LD + kk * 16 + koff);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, output gate, residual, store ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (co >= a.Co) continue;
+      const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = wm * (BM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        const int m = m0 + row;
+        if (m >= a.M) continue;
+        const int64_t o = (int64_t)m * a.Co + co;
+        float val = acc[i][j][v] + bias;
+        if (a.gate_out) {
+          const float g = bf2f(a.gate_out[o]);
+          if (!(g > 0.f)) val *= a.slope_out;
+        }
+        if (a.residual) val += bf2f(a.residual[o]);
+        if (a.out_f32)
+          reinterpret_cast<float*>(a.out)[o] = val;
+        else
+          reinterpret_cast<bf16_t*>(a.out)[o] = f2bf(val);
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// Weight gradient.
+// -------------------------------------------------------------------------------------------
+struct GWgradArgs {
+  const bf16_t* in;
+  const bf16_t* gate_in;
+  const bf16_t* dy;
+  const bf16_t* gate_dy;
+  float* out;       // dw (splits == 1) or workspace partials [splits][K*Co]
+  float* bias_out;  // NULL, dbias (splits == 1) or workspace partials [splits][Co]
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, ulog, pt, pl;
+  int M, K, HinU, WinU;
+  int rows_per_split;  // multiple of 32
+  int accumulate;      // only honoured when writing dw directly
+  float slope_in, slope_dy;
+  FastDiv dWo, dHo, dCi, dKw;
+};
+
+template <int TK, int TN, bool VX, bool VY>
+__global__ __launch_bounds__(256) void gwgrad_kernel(GWgradArgs a) {
+  constexpr int BMR = 32;
+  constexpr int LDX = TK + LDS_PAD;
+  constexpr int LDY = TN + LDS_PAD;
+  constexpr int XC = TK / 8, YC = TN / 8;  // chunks per row
+  constexpr int LX = (BMR * XC + 255) / 256;
+  constexpr int LY = (BMR * YC + 255) / 256;
+  constexpr int WK = TK >= 64 ? 2 : 1;  // wave grid
+  constexpr int WN = 4 / WK;
+  constexpr int FK = TK / WK / 32;  // 32x32 tiles per wave along k
+  constexpr int FN = TN / WN / 32;
+  static_assert(FK >= 1 && FN >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BMR * (LDX + LDY)];
+  auto Xs = [&](int buf) { return smem + buf * BMR * (LDX + LDY); };
+  auto Ys = [&](int buf) { return smem + buf * BMR * (LDX + LDY) + BMR * LDX; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / WN, wn = wave % WN;
+  const int k0 = blockIdx.x * TK;
+  const int c0 = blockIdx.y * TN;
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+  const int nit = (mend - mbeg + BMR - 1) / BMR;
+  const int um = (1 << a.ulog) - 1;
+
+  // per-thread fixed k decode for the X tile loads
+  int x_row[LX], x_c[LX], x_r[LX], x_s[LX];
+  bool x_kok[LX];
+  constexpr bool vec = VX;
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    const int cidx = tid + i * 256;
+    x_row[i] = cidx / XC;
+    const int k = k0 + (cidx % XC) * 8;
+    x_kok[i] = (x_row[i] < BMR) && (k < a.K);
+    const uint32_t tap = fdiv((uint32_t)(x_kok[i] ? k : 0), a.dCi);
+    x_c[i] = k - (int)tap * a.Ci;
+    x_r[i] = (int)fdiv(tap, a.dKw);
+    x_s[i] = (int)tap - x_r[i] * a.kw;
+  }
+  int y_row[LY], y_col[LY];
+  bool y_ok[LY];
+#pragma unroll
+  for (int i = 0; i < LY; ++i) {
+    const int cidx = tid + i * 256;
+    y_row[i] = cidx / YC;
+    y_col[i] = c0 + (cidx % YC) * 8;
+    y_ok[i] = (y_row[i] < BMR) && (y_col[i] < a.Co);
+  }
+  constexpr bool yvec = VY;
+
+  f32x16_t acc[FK][FN];
+#pragma unroll
+  for (int i = 0; i < FK; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  float bias_acc = 0.f;
+
+  uint4 rx[LX], ry[LY];
+  auto gload = [&](int it) {
+    const int mb = mbeg + it * BMR;
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      uint4 ovq = make_uint4(0, 0, 0, 0);
+      const int m = mb + x_row[i];
+      if (x_kok[i] && m < mend) {
+        const uint32_t t1 = fdiv((uint32_t)m, a.dWo);
+        const int ow = m - (int)t1 * a.Wo;
+        const uint32_t n = fdiv(t1, a.dHo);
+        const int oh = (int)t1 - (int)n * a.Ho;
+        const int bh = oh * a.S - a.pt, bw = ow * a.S - a.pl;
+        if constexpr (vec) {
+          const int ihv = bh + x_r[i], iwv = bw + x_s[i];
+          if (ihv >= 0 && iwv >= 0 && ihv < a.HinU && iwv < a.WinU && !((ihv & um) | (iwv & um))) {
+            const int64_t off =
+                ((int64_t)((int)n * a.Hin + (ihv >> a.ulog)) * a.Win + (iwv >> a.ulog)) * a.Ci +
+                x_c[i];
+            ovq = *reinterpret_cast<const uint4*>(a.in + off);
+            if (a.gate_in) {
+              uint4 g = (a.gate_in == a.in) ? ovq
+                                             : *reinterpret_cast<const uint4*>(a.gate_in + off);
+              ovq = gate_apply(ovq, g, a.slope_in);
+            }
+          }
+        } else {
+          s16x8_t hv = {0, 0, 0, 0, 0, 0, 0, 0};
+          const int kb = k0 + ((tid + i * 256) % XC) * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ke = kb + e;
+            if (ke >= a.K) continue;
+            const uint32_t tap = fdiv((uint32_t)ke, a.dCi);
+            const int c = ke - (int)tap * a.Ci;
+            const int r = (int)fdiv(tap, a.dKw);
+            const int s = (int)tap - r * a.kw;
+            const int ihv = bh + r, iwv = bw + s;
+            if (ihv < 0 || iwv < 0 || ihv >= a.HinU || iwv >= a.WinU) continue;
+            if ((ihv & um) | (iwv & um)) continue;
+            const int64_t off =
+                ((int64_t)((int)n * a.Hin + (ihv >> a.ulog)) * a.Win + (iwv >> a.ulog)) * a.Ci + c;
+            bf16_t x = a.in[off];
+            if (a.gate_in) {
+              const float g = bf2f(a.gate_in[off]);
+              if (!(g > 0.f)) x = f2bf(bf2f(x) * a.slope_in);
+            }
+            hv[e] = (short)x;
+          }
+          ovq = __builtin_bit_cast(uint4, hv);
+        }
+      }
+      rx[i] = ovq;
+    }
+#pragma unroll
+    for (int i = 0; i < LY; ++i) {
+      uint4 ovq = make_uint4(0, 0, 0, 0);
+      const int m = mb + y_row[i];
+      if (y_ok[i] && m < mend) {
+        const int64_t off = (int64_t)m * a.Co + y_col[i];
+        if constexpr (yvec) {
+          ovq = *reinterpret_cast<const uint4*>(a.dy + off);
+          if (a.gate_dy) {
+            uint4 g = *reinterpret_cast<const uint4*>(a.gate_dy + off);
+            ovq = gate_apply(ovq, g, a.slope_dy);
+          }
+        } else {
+          s16x8_t hv = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (y_col[i] + e >= a.Co) continue;
+            bf16_t x = a.dy[off + e];
+            if (a.gate_dy) {
+              const float g = bf2f(a.gate_dy[off + e]);
+              if (!(g > 0.f)) x = f2bf(bf2f(x) * a.slope_dy);
+            }
+            hv[e] = (short)x;
+          }
+          ovq = __builtin_bit_cast(uint4, hv);
+        }
+      }
+      ry[i] = ovq;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LX; ++i)
+      if (x_row[i] < BMR)
+        *reinterpret_cast<uint4*>(Xs(buf) + x_row[i] * LDX + ((tid + i * 256) % XC) * 8) = rx[i];
+#pragma unroll
+    for (int i = 0; i < LY; ++i)
+      if (y_row[i] < BMR)
+        *reinterpret_cast<uint4*>(Ys(buf) + y_row[i] * LDY + ((tid + i * 256) % YC) * 8) = ry[i];
+  };
+
+  if (nit > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+
+  const int xcol0 = wk * (TK / WK) + (lane & 31);
+  const int ycol0 = wn * (TN / WN) + (lane & 31);
+  const int mofs = (lane >> 5) * 8;
+  const bool do_bias = (a.bias_out != nullptr) && (blockIdx.x == 0);
+
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) gload(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BMR / 16; ++kk) {
+      bf16x8_t xf[FK], yf[FN];
+      const int mm = kk * 16 + mofs;
+#pragma unroll
+      for (int i = 0; i < FK; ++i) {
+        s16x8_t u;
+        const bf16_t* xp = Xs(buf) + mm * LDX + xcol0 + i * 32;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = (short)xp[e * LDX];
+        xf[i] = __builtin_bit_cast(bf16x8_t, u);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        s16x8_t u;
+        const bf16_t* yp = Ys(buf) + mm * LDY + ycol0 + j * 32;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = (short)yp[e * LDY];
+        yf[j] = __builtin_bit_cast(bf16x8_t, u);
+      }
+#pragma unroll
+      for (int i = 0; i < FK; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bias && tid < TN) {
+#pragma unroll 8
+      for (int r = 0; r < BMR; ++r) bias_acc += bf2f(Ys(buf)[r * LDY + tid]);
+    }
+    if (it + 1 < nit) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  const bool direct = (gridDim.z == 1);
+  float* outp = a.out + (direct ? 0 : (int64_t)blockIdx.z * a.K * a.Co);
+#pragma unroll
+  for (int i = 0; i < FK; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int co = c0 + wn * (TN / WN) + j * 32 + (lane & 31);
+      if (co >= a.Co) continue;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = k0 + wk * (TK / WK) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (k >= a.K) continue;
+        const int64_t o = (int64_t)k * a.Co + co;
+        if (direct && a.accumulate)
+          outp[o] += acc[i][j][v];
+        else
+          outp[o] = acc[i][j][v];
+      }
+    }
+  }
+  if (do_bias && tid < TN && c0 + tid < a.Co) {
+    float* bp = a.bias_out + (direct ? 0 : (int64_t)blockIdx.z * a.Co);
+    if (direct && a.accumulate)
+      bp[c0 + tid] += bias_acc;
+    else
+      bp[c0 + tid] = bias_acc;
+  }
+}
+
+__global__ void split_reduce_kernel(const float* __restrict__ part, int splits, int64_t n,
+                                    float* __restrict__ out, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// -------------------------------------------------------------------------------------------
+// Weight preparation (fp32 HWIO -> bf16 operand images).
+// -------------------------------------------------------------------------------------------
+__global__ void prep_fwd_kernel(const float* __restrict__ w, int K, int Kp, int Co,
+                                const float* __restrict__ scale, bf16_t* __restrict__ bt) {
+  // transpose [K][Co] -> [Co][Kp] through a 32x33 LDS tile
+  __shared__ float tile[32][33];
+  const float sc = scale ? *scale : 1.f;
+  const int kb = blockIdx.x * 32, cb = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int k = kb + r, c = cb + tx;
+    tile[r][tx] = (k < K && c < Co) ? w[(int64_t)k * Co + c] * sc : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = cb + r, k = kb + tx;
+    if (c < Co && k < Kp) bt[(int64_t)c * Kp + k] = f2bf(tile[tx][r]);
+  }
+}
+
+__global__ void prep_bwd_kernel(const float* __restrict__ w, int T, int Ci, int Co, int Kbp,
+                                const float* __restrict__ scale, bf16_t* __restrict__ bt) {
+  // out[ci][ (T-1-t)*Co + co ] = w[t][ci][co]; pad columns [T*Co, Kbp) are zero.
+  const float sc = scale ? *scale : 1.f;
+  const int64_t total = (int64_t)Ci * Kbp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / Kbp);
+    const int kk = (int)(i - (int64_t)ci * Kbp);
+    float v = 0.f;
+    if (kk < T * Co) {
+      const int tt = kk / Co, co = kk - tt * Co;
+      const int t = T - 1 - tt;
+      v = w[((int64_t)t * Ci + ci) * Co + co] * sc;
+    }
+    bt[i] = f2bf(v);
+  }
+}
+
+int ilog2_exact(int x) {
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return ((1 << l) == x) ? l : -1;
+}
+
+int check_geom(const cgConvGeom* g, const char* who) {
+  if (!g) CG_FAIL(CG_ERR_BAD_ARG, "%s: null geometry", who);
+  if (g->N <= 0 || g->Hin <= 0 || g->Win <= 0 || g->Ci <= 0 || g->Ho <= 0 || g->Wo <= 0 ||
+      g->Co <= 0 || g->kh <= 0 || g->kw <= 0 || g->S <= 0 || g->U <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "%s: non-positive dimension", who);
+  if (ilog2_exact(g->U) < 0) CG_FAIL(CG_ERR_UNSUPPORTED, "%s: U=%d is not a power of two", who, g->U);
+  if ((int64_t)g->N * g->Ho * g->Wo >= (1ll << 31) ||
+      (int64_t)g->N * g->Hin * g->Win >= (1ll << 31) || (int64_t)g->kh * g->kw * g->Ci >= (1ll << 30))
+    CG_FAIL(CG_ERR_UNSUPPORTED, "%s: index space exceeds 2^31", who);
+  return CG_OK;
+}
+
+}  // namespace
+
+extern "C" int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,
+                              void* bt_fwd, void* bt_bwd, cgStream stream) {
+  if (!w || kh <= 0 || kw <= 0 || Ci <= 0 || Co <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_weight_prep: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = kh * kw;
+  if (bt_fwd) {
+    const int K = T * Ci, Kp = (K + 7) & ~7;
+    dim3 grid(cdiv(Kp, 32), cdiv(Co, 32));
+    prep_fwd_kernel<<<grid, 256, 0, st>>>(w, K, Kp, Co, scale, (bf16_t*)bt_fwd);
+    CG_CHECK_LAUNCH("cg_weight_prep(fwd)");
+  }
+  if (bt_bwd) {
+    const int Kb = T * Co, Kbp = (Kb + 7) & ~7;
+    const int64_t total = (int64_t)Ci * Kbp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    prep_bwd_kernel<<<blocks, 256, 0, st>>>(w, T, Ci, Co, Kbp, scale, (bf16_t*)bt_bwd);
+    CG_CHECK_LAUNCH("cg_weight_prep(bwd)");
+  }
+  return CG_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_gconv(const GConvArgs& a, bool vec, hipStream_t st) {
+  dim3 grid(cdiv(a.M, BM), cdiv(a.Co, BN));
+  if (vec)
+    gconv_kernel<BM, BN, 64, WM, WN, true><<<grid, 256, 0, st>>>(a);
+  else
+    gconv_kernel<BM, BN, 64, WM, WN, false><<<grid, 256, 0, st>>>(a);
+}
+
+extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                        int out_is_f32, const float* bias, const void* gate_in, float slope_in,
+                        const void* gate_out, float slope_out, const void* residual,
+                        cgStream stream) {
+  int rc = check_geom(g, "cg_gconv");
+  if (rc) return rc;
+  if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
+  GConvArgs a;
+  a.in = (const bf16_t*)in;
+  a.bt = (const bf16_t*)bt;
+  a.out = out;
+  a.bias = bias;
+  a.gate_in = (const bf16_t*)gate_in;
+  a.gate_out = (const bf16_t*)gate_out;
+  a.residual = (const bf16_t*)residual;
+  a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
+  a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;
+  a.S = g->S; a.ulog = ilog2_exact(g->U); a.pt = g->pt; a.pl = g->pl;
+  a.M = g->N * g->Ho * g->Wo;
+  a.K = g->kh * g->kw * g->Ci;
+  a.Kp = (a.K + 7) & ~7;
+  a.HinU = g->Hin * g->U; a.WinU = g->Win * g->U;
+  a.slope_in = slope_in; a.slope_out = slope_out;
+  a.out_f32 = out_is_f32;
+  a.dWo = make_fastdiv(g->Wo); a.dHo = make_fastdiv(g->Ho);
+  a.dCi = make_fastdiv(g->Ci); a.dKw = make_fastdiv(g->kw);
+  const bool vec = (g->Ci % 8) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (g->Co > 64)
+    launch_gconv<128, 128, 2, 2>(a, vec, st);
+  else if (g->Co > 32)
+    launch_gconv<128, 64, 2, 2>(a, vec, st);
+  else
+    launch_gconv<128, 32, 4, 1>(a, vec, st);
+  CG_CHECK_LAUNCH("cg_gconv");
+  return CG_OK;
+}
+
+static void wgrad_plan(const cgConvGeom* g, int* tk, int* tn, int* splits, int* rows_per_split) {
+  const int K = g->kh * g->kw * g->Ci;
+  const int M = g->N * g->Ho * g->Wo;
+  *tk = K > 64 ? 128 : 64;
+  *tn = g->Co > 64 ? 128 : 64;
+  const int tiles = cdiv(K, *tk) * cdiv(g->Co, *tn);
+  int s = cdiv(1024, tiles);
+  const int max_by_rows = M / 128 > 0 ? M / 128 : 1;  // at least 4 slices of 32 rows per split
+  if (s > max_by_rows) s = max_by_rows;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  int rps = cdiv(M, s);
+  rps = (rps + 31) / 32 * 32;
+  s = cdiv(M, rps);
+  *splits = s;
+  *rows_per_split = rps;
+}
+
+extern "C" size_t cg_gwgrad_workspace_bytes(const cgConvGeom* g) {
+  if (!g) return 0;
+  int tk, tn, splits, rps;
+  wgrad_plan(g, &tk, &tn, &splits, &rps);
+  if (splits == 1) return 256;
+  const size_t K = (size_t)g->kh * g->kw * g->Ci;
+  return align_up((size_t)splits * (K * g->Co + g->Co) * sizeof(float), 256);
+}
+
+extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in,
+                         const void* dy, const void* gate_dy, float slope_dy, float* dw,
+                         int accumulate, float* dbias, void* ws, size_t ws_bytes,
+                         cgStream stream) {
+  int rc = check_geom(g, "cg_gwgrad");
+  if (rc) return rc;
+  if (!in || !dy || !dw) CG_FAIL(CG_ERR_BAD_ARG, "cg_gwgrad: null tensor");
+  int tk, tn, splits, rps;
+  wgrad_plan(g, &tk, &tn, &splits, &rps);
+  const int K = g->kh * g->kw * g->Ci;
+  if (splits > 1 && (!ws || ws_bytes < cg_gwgrad_workspace_bytes(g)))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_gwgrad: workspace too small (%zu < %zu)", ws_bytes,
+            cg_gwgrad_workspace_bytes(g));
+  GWgradArgs a;
+  a.in = (const bf16_t*)in; a.gate_in = (const bf16_t*)gate_in;
+  a.dy = (const bf16_t*)dy; a.gate_dy = (const bf16_t*)gate_dy;
+  a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
+  a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;
+  a.S = g->S; a.ulog = ilog2_exact(g->U); a.pt = g->pt; a.pl = g->pl;
+  a.M = g->N * g->Ho * g->Wo; a.K = K;
+  a.HinU = g->Hin * g->U; a.WinU = g->Win * g->U;
+  a.rows_per_split = rps;
+  a.accumulate = accumulate;
+  a.slope_in = slope_in; a.slope_dy = slope_dy;
+  a.dWo = make_fastdiv(g->Wo); a.dHo = make_fastdiv(g->Ho);
+  a.dCi = make_fastdiv(g->Ci); a.dKw = make_fastdiv(g->kw);
+  float* wsf = (float*)ws;
+  if (splits == 1) {
+    a.out = dw;
+    a.bias_out = dbias;
+  } else {
+    a.out = wsf;
+    a.bias_out = dbias ? wsf + (size_t)splits * K * g->Co : nullptr;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(K, tk), cdiv(g->Co, tn), splits);
+  const bool vx = (g->Ci % 8) == 0, vy = (g->Co % 8) == 0;
+#define CG_WG(TK_, TN_)                                                        \
+  do {                                                                         \
+    if (vx && vy) gwgrad_kernel<TK_, TN_, true, true><<<grid, 256, 0, st>>>(a);        \
+    else if (vx) gwgrad_kernel<TK_, TN_, true, false><<<grid, 256, 0, st>>>(a);        \
+    else if (vy) gwgrad_kernel<TK_, TN_, false, true><<<grid, 256, 0, st>>>(a);        \
+    else gwgrad_kernel<TK_, TN_, false, false><<<grid, 256, 0, st>>>(a);               \
+  } while (0)
+  if (tk == 128 && tn == 128) CG_WG(128, 128);
+  else if (tk == 128 && tn == 64) CG_WG(128, 64);
+  else if (tk == 64 && tn == 128) CG_WG(64, 128);
+  else CG_WG(64, 64);
+#undef CG_WG
+  CG_CHECK_LAUNCH("cg_gwgrad");
+  if (splits > 1) {
+    const int64_t n = (int64_t)K * g->Co;
+    split_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(wsf, splits, n, dw, accumulate);
+    CG_CHECK_LAUNCH("cg_gwgrad(reduce)");
+    if (dbias) {
+      split_reduce_kernel<<<cdiv(g->Co, 256), 256, 0, st>>>(wsf + (size_t)splits * K * g->Co,
+                                                             splits, g->Co, dbias, accumulate);
+      CG_CHECK_LAUNCH("cg_gwgrad(reduce bias)");
+    }
+  }
+  return CG_OK;
+}

@@ -1,0 +1,393 @@
+// Losses (gans/loss_lib.py:53-148), WGAN-GP reductions (gans/penalty_lib.py:59-82), the fused
+// multi-tensor TF-Adam(+EMA) update (modular_gan.py:480-508), gradient bucket
+// gather/scatter for the RCCL all-reduce, step counters and the stateless Philox RNG
+// (tpu/tpu_random.py semantics).  Contracts: include/cgamd.h.
+#include "cg_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// GAN losses: single block, B <= a few thousand.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_neg_abs(float x) { return log1pf(expf(-fabsf(x))); }
+// sigmoid_cross_entropy_with_logits(x, z) = max(x,0) - x z + log(1 + exp(-|x|))
+__device__ __forceinline__ float sce(float x, float z) {
+  return fmaxf(x, 0.f) - x * z + softplus_neg_abs(x);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gan_loss_kernel(int kind, const float* __restrict__ logits,
+                                                       int B, float* __restrict__ losses,
+                                                       float* __restrict__ dd,
+                                                       float* __restrict__ dg) {
+  __shared__ float sm4[4];
+  const float invB = 1.f / (float)B;
+  float lr = 0.f, lf = 0.f, lg = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float xr = logits[i], xf = logits[B + i];
+    float gr = 0.f, gf = 0.f, gg = 0.f;
+    if (kind == 0) {  // non_saturating
+      lr += sce(xr, 1.f);
+      lf += sce(xf, 0.f);
+      lg += sce(xf, 1.f);
+      gr = sigmoidf_(xr) - 1.f;
+      gf = sigmoidf_(xf);
+      gg = sigmoidf_(xf) - 1.f;
+    } else if (kind == 1) {  // wasserstein
+      lr += -xr;
+      lf += xf;
+      lg += -xf;
+      gr = -1.f;
+      gf = 1.f;
+      gg = -1.f;
+    } else if (kind == 2) {  // least_squares (on probabilities)
+      const float pr = sigmoidf_(xr), pf = sigmoidf_(xf);
+      lr += (pr - 1.f) * (pr - 1.f);
+      lf += pf * pf;
+      lg += 0.5f * (pf - 1.f) * (pf - 1.f);
+      gr = (pr - 1.f) * pr * (1.f - pr);  // 0.5 * 2 (p-1) p (1-p)
+      gf = pf * pf * (1.f - pf);
+      gg = (pf - 1.f) * pf * (1.f - pf);
+    } else {  // hinge
+      lr += fmaxf(1.f - xr, 0.f);
+      lf += fmaxf(1.f + xf, 0.f);
+      lg += -xf;
+      gr = (1.f - xr) > 0.f ? -1.f : 0.f;
+      gf = (1.f + xf) > 0.f ? 1.f : 0.f;
+      gg = -1.f;
+    }
+    if (dd) {
+      dd[i] = gr * invB;
+      dd[B + i] = gf * invB;
+    }
+    if (dg) {
+      dg[i] = 0.f;
+      dg[B + i] = gg * invB;
+    }
+  }
+  lr = block_sum_256(lr, sm4);
+  lf = block_sum_256(lf, sm4);
+  lg = block_sum_256(lg, sm4);
+  if (threadIdx.x == 0) {
+    lr *= invB;
+    lf *= invB;
+    lg *= invB;
+    const float d = kind == 2 ? 0.5f * (lr + lf) : lr + lf;
+    losses[0] = d;
+    losses[1] = lr;
+    losses[2] = lf;
+    losses[3] = lg;
+  }
+}
+
+__global__ void interpolate_kernel(const float* __restrict__ x, const float* __restrict__ xf,
+                                   const float* __restrict__ alpha, int64_t per, int64_t total,
+                                   bf16_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float a = alpha[i / per];
+    out[i] = f2bf(x[i] + a * (xf[i] - x[i]));
+  }
+}
+
+// one block per sample: slopes[b] = sqrt(1e-4 + sum g^2)
+__global__ __launch_bounds__(256) void gp_slopes_kernel(const float* __restrict__ g, int64_t per,
+                                                        float* __restrict__ slopes) {
+  __shared__ float sm4[4];
+  const float* gp = g + (int64_t)blockIdx.x * per;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += blockDim.x) s += gp[i] * gp[i];
+  s = block_sum_256(s, sm4);
+  if (threadIdx.x == 0) slopes[blockIdx.x] = sqrtf(1e-4f + s);
+}
+__global__ __launch_bounds__(256) void gp_mean_kernel(const float* __restrict__ slopes, int B,
+                                                      float* __restrict__ penalty) {
+  __shared__ float sm4[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) s += (slopes[i] - 1.f) * (slopes[i] - 1.f);
+  s = block_sum_256(s, sm4);
+  if (threadIdx.x == 0) *penalty = s / (float)B;
+}
+__global__ void gp_bwd_kernel(const float* __restrict__ g, const float* __restrict__ slopes,
+                              const float* __restrict__ upstream, int B, int64_t per,
+                              int64_t total, bf16_t* __restrict__ dg) {
+  const float up = upstream ? *upstream : 1.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float s = slopes[i / per];
+    dg[i] = f2bf(up * (2.f / (float)B) * (s - 1.f) / s * g[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-tensor Adam + EMA.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_entry(const cgAdamEntry* __restrict__ t, int n,
+                                          int64_t chunk) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t[mid].chunk_begin <= chunk) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const cgAdamEntry* __restrict__ table,
+                                                         int n_entries, float lr, float beta1,
+                                                         float beta2, float eps, float grad_scale,
+                                                         const int64_t* __restrict__ step,
+                                                         float ema_decay, int64_t ema_start) {
+  __shared__ float s_lrt, s_omd;
+  __shared__ int s_e;
+  if (threadIdx.x == 0) {
+    const int64_t t0 = step ? *step : 0;
+    const double t = (double)(t0 + 1);
+    s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    const float d = (t0 >= ema_start) ? ema_decay : 0.f;
+    s_omd = 1.f - d;
+    s_e = find_entry(table, n_entries, blockIdx.x);
+  }
+  __syncthreads();
+  const cgAdamEntry e = table[s_e];
+  const float lrt = s_lrt, omd = s_omd;
+  const int64_t base = ((int64_t)blockIdx.x - e.chunk_begin) * CG_ADAM_CHUNK;
+  const int64_t end = min(e.n, base + CG_ADAM_CHUNK);
+  for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+    const float g = e.grad[i] * grad_scale;
+    const float m = beta1 * e.m[i] + (1.f - beta1) * g;
+    const float v = beta2 * e.v[i] + (1.f - beta2) * g * g;
+    const float p = e.param[i] - lrt * m / (sqrtf(v) + eps);
+    e.m[i] = m;
+    e.v[i] = v;
+    e.param[i] = p;
+    if (e.ema) {
+      const float s = e.ema[i];
+      e.ema[i] = s - omd * (s - p);
+    }
+  }
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void multi_copy_kernel(const cgAdamEntry* __restrict__ table,
+                                                         const int64_t* __restrict__ offs,
+                                                         int n_entries, float* flat) {
+  __shared__ int s_e;
+  if (threadIdx.x == 0) s_e = find_entry(table, n_entries, blockIdx.x);
+  __syncthreads();
+  const cgAdamEntry e = table[s_e];
+  const int64_t base = ((int64_t)blockIdx.x - e.chunk_begin) * CG_ADAM_CHUNK;
+  const int64_t end = min(e.n, base + CG_ADAM_CHUNK);
+  float* f = flat + offs[s_e];
+  float* g = const_cast<float*>(e.grad);
+  for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+    if (GATHER) f[i] = g[i];
+    else g[i] = f[i];
+  }
+}
+
+__global__ void counter_add_kernel(int64_t* c, int64_t inc) { *c += inc; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10.
+// ---------------------------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ U4 philox(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    U4 n;
+    n.x = hi1 ^ c.y ^ k0;
+    n.y = lo1;
+    n.z = hi0 ^ c.w ^ k1;
+    n.w = lo0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ void make_key(uint64_t seed, uint32_t op_id, uint32_t* k0,
+                                         uint32_t* k1) {
+  *k0 = (uint32_t)seed ^ (op_id * 0x9E3779B1u);
+  *k1 = (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu;
+}
+
+__global__ void random_kernel(int kind, float lo, float hi, uint64_t seed, uint32_t op_id,
+                              uint32_t stream_id, const int64_t* __restrict__ step_ptr,
+                              float* __restrict__ out, int64_t n) {
+  uint32_t k0, k1;
+  make_key(seed, op_id, &k0, &k1);
+  const uint64_t step = step_ptr ? (uint64_t)*step_ptr : 0ull;
+  const int64_t nq = (n + 3) / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+    U4 c;
+    c.x = (uint32_t)q;
+    c.y = (uint32_t)((uint64_t)q >> 32) ^ (stream_id << 8);
+    c.z = (uint32_t)step;
+    c.w = (uint32_t)(step >> 32);
+    const U4 r = philox(c, k0, k1);
+    float v[4];
+    if (kind == 0) {
+      const float sc = hi - lo;
+      v[0] = lo + sc * ((float)(r.x >> 8) * 5.9604644775390625e-8f);
+      v[1] = lo + sc * ((float)(r.y >> 8) * 5.9604644775390625e-8f);
+      v[2] = lo + sc * ((float)(r.z >> 8) * 5.9604644775390625e-8f);
+      v[3] = lo + sc * ((float)(r.w >> 8) * 5.9604644775390625e-8f);
+    } else {
+      const float u1 = ((float)(r.x >> 8) + 1.f) * 5.9604644775390625e-8f;
+      const float u2 = (float)(r.y >> 8) * 5.9604644775390625e-8f;
+      const float u3 = ((float)(r.z >> 8) + 1.f) * 5.9604644775390625e-8f;
+      const float u4 = (float)(r.w >> 8) * 5.9604644775390625e-8f;
+      const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
+      const float ta = 6.283185307179586f * u2, tb = 6.283185307179586f * u4;
+      v[0] = lo + hi * ra * cosf(ta);
+      v[1] = lo + hi * ra * sinf(ta);
+      v[2] = lo + hi * rb * cosf(tb);
+      v[3] = lo + hi * rb * sinf(tb);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (q * 4 + e < n) out[q * 4 + e] = v[e];
+  }
+}
+
+__global__ void random_labels_kernel(int K, uint64_t seed, uint32_t op_id, uint32_t stream_id,
+                                     const int64_t* __restrict__ step_ptr,
+                                     int32_t* __restrict__ out, int64_t n) {
+  uint32_t k0, k1;
+  make_key(seed, op_id, &k0, &k1);
+  const uint64_t step = step_ptr ? (uint64_t)*step_ptr : 0ull;
+  const int64_t nq = (n + 3) / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+    U4 c;
+    c.x = (uint32_t)q;
+    c.y = (uint32_t)((uint64_t)q >> 32) ^ (stream_id << 8);
+    c.z = (uint32_t)step;
+    c.w = (uint32_t)(step >> 32);
+    const U4 r = philox(c, k0, k1);
+    const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (q * 4 + e < n) out[q * 4 + e] = (int32_t)(((uint64_t)rv[e] * (uint64_t)K) >> 32);
+  }
+}
+
+inline int grid_cap(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int cg_gan_loss(int kind, const float* logits, int B, float* losses, float* dlogits_d,
+                           float* dlogits_g, cgStream stream) {
+  if (!logits || !losses || B <= 0 || kind < 0 || kind > 3)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gan_loss: bad argument");
+  gan_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(kind, logits, B, losses, dlogits_d,
+                                                      dlogits_g);
+  CG_CHECK_LAUNCH("cg_gan_loss");
+  return CG_OK;
+}
+
+extern "C" int cg_interpolate(const float* x, const float* x_fake, const float* alpha, int B,
+                              int64_t per, void* out, cgStream stream) {
+  if (!x || !x_fake || !alpha || !out || B <= 0 || per <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_interpolate: bad argument");
+  const int64_t total = (int64_t)B * per;
+  interpolate_kernel<<<grid_cap(total), 256, 0, (hipStream_t)stream>>>(x, x_fake, alpha, per,
+                                                                       total, (bf16_t*)out);
+  CG_CHECK_LAUNCH("cg_interpolate");
+  return CG_OK;
+}
+
+extern "C" int cg_gradient_penalty(const float* g, int B, int64_t per, float* slopes,
+                                   float* penalty, cgStream stream) {
+  if (!g || !slopes || !penalty || B <= 0 || per <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gradient_penalty: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  gp_slopes_kernel<<<B, 256, 0, st>>>(g, per, slopes);
+  CG_CHECK_LAUNCH("cg_gradient_penalty(slopes)");
+  gp_mean_kernel<<<1, 256, 0, st>>>(slopes, B, penalty);
+  CG_CHECK_LAUNCH("cg_gradient_penalty(mean)");
+  return CG_OK;
+}
+
+extern "C" int cg_gradient_penalty_bwd(const float* g, const float* slopes, const float* upstream,
+                                       int B, int64_t per, void* dg, cgStream stream) {
+  if (!g || !slopes || !dg || B <= 0 || per <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gradient_penalty_bwd: bad argument");
+  const int64_t total = (int64_t)B * per;
+  gp_bwd_kernel<<<grid_cap(total), 256, 0, (hipStream_t)stream>>>(g, slopes, upstream, B, per,
+                                                                  total, (bf16_t*)dg);
+  CG_CHECK_LAUNCH("cg_gradient_penalty_bwd");
+  return CG_OK;
+}
+
+extern "C" int cg_adam_multi(const cgAdamEntry* table, int n_entries, int64_t total_chunks,
+                             float lr, float beta1, float beta2, float eps, float grad_scale,
+                             const int64_t* step, float ema_decay, int64_t ema_start_step,
+                             cgStream stream) {
+  if (!table || n_entries <= 0 || total_chunks <= 0 || total_chunks >= (1ll << 31))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_adam_multi: bad argument");
+  adam_multi_kernel<<<(int)total_chunks, 256, 0, (hipStream_t)stream>>>(
+      table, n_entries, lr, beta1, beta2, eps, grad_scale, step, ema_decay, ema_start_step);
+  CG_CHECK_LAUNCH("cg_adam_multi");
+  return CG_OK;
+}
+
+extern "C" int cg_counter_add(int64_t* counter, int64_t inc, cgStream stream) {
+  if (!counter) CG_FAIL(CG_ERR_BAD_ARG, "cg_counter_add: null counter");
+  counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter, inc);
+  CG_CHECK_LAUNCH("cg_counter_add");
+  return CG_OK;
+}
+
+extern "C" int cg_multi_gather(const cgAdamEntry* table, const int64_t* flat_offsets,
+                               int n_entries, int64_t total_chunks, float* flat,
+                               cgStream stream) {
+  if (!table || !flat_offsets || !flat || n_entries <= 0 || total_chunks <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_multi_gather: bad argument");
+  multi_copy_kernel<true><<<(int)total_chunks, 256, 0, (hipStream_t)stream>>>(
+      table, flat_offsets, n_entries, flat);
+  CG_CHECK_LAUNCH("cg_multi_gather");
+  return CG_OK;
+}
+extern "C" int cg_multi_scatter(const cgAdamEntry* table, const int64_t* flat_offsets,
+                                int n_entries, int64_t total_chunks, const float* flat,
+                                cgStream stream) {
+  if (!table || !flat_offsets || !flat || n_entries <= 0 || total_chunks <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_multi_scatter: bad argument");
+  multi_copy_kernel<false><<<(int)total_chunks, 256, 0, (hipStream_t)stream>>>(
+      table, flat_offsets, n_entries, const_cast<float*>(flat));
+  CG_CHECK_LAUNCH("cg_multi_scatter");
+  return CG_OK;
+}
+
+extern "C" int cg_random(int kind, float lo, float hi, uint64_t seed, uint32_t op_id,
+                         uint32_t stream_id, const int64_t* step_ptr, float* out, int64_t n,
+                         cgStream stream) {
+  if (!out || n < 0 || (kind != 0 && kind != 1)) CG_FAIL(CG_ERR_BAD_ARG, "cg_random: bad argument");
+  if (n == 0) return CG_OK;
+  random_kernel<<<grid_cap((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      kind, lo, hi, seed, op_id, stream_id, step_ptr, out, n);
+  CG_CHECK_LAUNCH("cg_random");
+  return CG_OK;
+}
+extern "C" int cg_random_labels(int K, uint64_t seed, uint32_t op_id, uint32_t stream_id,
+                                const int64_t* step_ptr, int32_t* out, int64_t n,
+                                cgStream stream) {
+  if (!out || n < 0 || K <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_random_labels: bad argument");
+  if (n == 0) return CG_OK;
+  random_labels_kernel<<<grid_cap((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      K, seed, op_id, stream_id, step_ptr, out, n);
+  CG_CHECK_LAUNCH("cg_random_labels");
+  return CG_OK;
+}

@@ -1,0 +1,128 @@
+"""Loads libcgamd.so and declares the C-ABI (include/cgamd.h) for ctypes.
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import fails
+loudly -- the product path only ever runs the hand-written HIP kernels.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcgamd.so")
+
+c_int, c_i64, c_f32, c_f64 = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+c_u64, c_u32, c_sz, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p
+
+
+class ConvGeom(ctypes.Structure):
+    """Mirror of cgConvGeom."""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "Hin", "Win", "Ci", "Ho", "Wo", "Co", "kh", "kw", "S", "U", "pt", "pl")]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class AdamEntry(ctypes.Structure):
+    """Mirror of cgAdamEntry."""
+    _fields_ = [("param", vp), ("grad", vp), ("m", vp), ("v", vp), ("ema", vp),
+                ("n", c_i64), ("chunk_begin", c_i64)]
+
+
+ADAM_CHUNK = 16384
+GP = ctypes.POINTER(ConvGeom)
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    "cg_abi_version": (c_int, []),
+    "cg_last_error": (ctypes.c_char_p, []),
+    "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
+    "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
+    "cg_gwgrad_workspace_bytes": (c_sz, [GP]),
+    "cg_gwgrad": (c_int, [GP, vp, vp, c_f32, vp, vp, c_f32, vp, c_int, vp, vp, c_sz, vp]),
+    "cg_spectral_norm_workspace_bytes": (c_sz, [c_int, c_int]),
+    "cg_spectral_norm": (c_int, [vp, c_int, c_int, c_int, c_f32, vp, vp, vp, vp, vp, vp, c_sz, vp]),
+    "cg_sn_backward_workspace_bytes": (c_sz, [c_int, c_int]),
+    "cg_sn_backward": (c_int, [vp, vp, c_int, c_int, vp, vp, vp, vp, vp, c_sz, vp]),
+    "cg_scale_f32": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
+    "cg_bn_stats_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, c_sz, vp]),
+    "cg_bn_apply": (c_int, [vp, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, c_int, c_int, vp, vp]),
+    "cg_bn_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "cg_bn_backward": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_f32, vp, c_int, c_int,
+                               c_int, vp, vp, vp, vp, c_sz, vp]),
+    "cg_bn_update_moving": (c_int, [vp, vp, vp, vp, c_int, c_f32, vp]),
+    "cg_lrelu": (c_int, [vp, c_f32, vp, c_i64, vp]),
+    "cg_lrelu_bwd": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
+    "cg_axpby": (c_int, [vp, c_f32, vp, c_f32, vp, c_i64, vp]),
+    "cg_avgpool2": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_avgpool2_bwd": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_maxpool2": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_maxpool2_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_spatial_reduce": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),
+    "cg_spatial_reduce_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),
+    "cg_head": (c_int, [vp, c_int, vp, c_i64, vp]),
+    "cg_head_bwd": (c_int, [vp, c_int, vp, c_int, vp, c_i64, vp]),
+    "cg_cast_f32_to_bf16": (c_int, [vp, vp, c_i64, vp]),
+    "cg_cast_bf16_to_f32": (c_int, [vp, vp, c_i64, vp]),
+    "cg_affine_f32_to_bf16": (c_int, [vp, c_f32, c_f32, vp, c_i64, vp]),
+    "cg_colsum_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "cg_colsum": (c_int, [vp, c_i64, c_int, vp, vp, c_sz, vp]),
+    "cg_rowdot": (c_int, [vp, vp, c_int, c_int, vp, vp]),
+    "cg_rowdot_bwd": (c_int, [vp, vp, vp, c_int, c_int, vp, vp, vp]),
+    "cg_one_hot": (c_int, [vp, c_int, c_int, vp, vp]),
+    "cg_attention_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp]),
+    "cg_attention_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "cg_attention_bwd": (c_int, [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp,
+                                 vp, vp, vp, c_sz, vp]),
+    "cg_gan_loss": (c_int, [c_int, vp, c_int, vp, vp, vp, vp]),
+    "cg_interpolate": (c_int, [vp, vp, vp, c_int, c_i64, vp, vp]),
+    "cg_gradient_penalty": (c_int, [vp, c_int, c_i64, vp, vp, vp]),
+    "cg_gradient_penalty_bwd": (c_int, [vp, vp, vp, c_int, c_i64, vp, vp]),
+    "cg_adam_multi": (c_int, [vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, vp, c_f32,
+                              c_i64, vp]),
+    "cg_counter_add": (c_int, [vp, c_i64, vp]),
+    "cg_multi_gather": (c_int, [vp, vp, c_int, c_i64, vp, vp]),
+    "cg_multi_scatter": (c_int, [vp, vp, c_int, c_i64, vp, vp]),
+    "cg_random": (c_int, [c_int, c_f32, c_f32, c_u64, c_u32, c_u32, vp, vp, c_i64, vp]),
+    "cg_random_labels": (c_int, [c_int, c_u64, c_u32, c_u32, vp, vp, c_i64, vp]),
+    "cg_mean_cov_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "cg_mean_cov_f64": (c_int, [vp, c_i64, c_int, vp, vp, vp, c_sz, vp]),
+    "cg_gemm_f64": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    "cg_syevj_workspace_bytes": (c_sz, [c_int]),
+    "cg_syevj_f64": (c_int, [vp, c_int, vp, vp, c_int, c_f64, vp, c_sz, vp]),
+    "cg_inception_score_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "cg_inception_score_f64": (c_int, [vp, c_i64, c_int, vp, vp, c_sz, vp]),
+    "cg_inception_preprocess": (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_pool2d": (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, vp, vp]),
+}
+
+_lib = None
+
+
+class CgamdError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library (loads + type-declares on first use)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CgamdError(
+            "libcgamd.so not found at %s: run `python -m compare_gan_amd.csrc.build` "
+            "(there is no CPU / eager fallback for the HIP kernels)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cg_last_error()
+        raise CgamdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,598 @@
+"""Thin tensor-level wrappers over the C-ABI (include/cgamd.h): argument validation, output and
+workspace allocation on the current torch HIP stream.  No arithmetic happens in Python/torch here;
+torch only owns the device memory and the stream."""
+import ctypes
+
+import torch
+
+from compare_gan_amd.hip import _lib
+from compare_gan_amd.hip._lib import ConvGeom, check
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+F64 = torch.float64
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return
+        raise ValueError("%s must not be None" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (no CPU fallback exists)" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry helpers
+# ------------------------------------------------------------------------------------------------
+def make_geom(N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S=1, U=1, pt=0, pl=0):
+    return ConvGeom(N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, U, pt, pl)
+
+
+def geom_conv_same(N, H, W, Ci, Co, kh, kw, stride=1, up=1):
+    """tf.nn.conv2d(padding='SAME') on the zero-inserted input."""
+    Hv, Wv = H * up, W * up
+    Ho, Wo = -(-Hv // stride), -(-Wv // stride)
+    ph = max((Ho - 1) * stride + kh - Hv, 0)
+    pw = max((Wo - 1) * stride + kw - Wv, 0)
+    return make_geom(N, H, W, Ci, Ho, Wo, Co, kh, kw, stride, up, ph // 2, pw // 2)
+
+
+def geom_adjoint(g):
+    """Geometry of the data-gradient / transposed convolution of `g` (input = g's output)."""
+    return make_geom(g.N, g.Ho, g.Wo, g.Co, g.Hin, g.Win, g.Ci, g.kh, g.kw, g.U, g.S,
+                     g.kh - 1 - g.pt, g.kw - 1 - g.pl)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution family
+# ------------------------------------------------------------------------------------------------
+def weight_prep(w, scale=None, want_fwd=True, want_bwd=False):
+    """w fp32 [kh,kw,Ci,Co] -> (bt_fwd [Co, Kp] bf16, bt_bwd [Ci, Kbp] bf16)."""
+    _req(w, F32, "w")
+    _req(scale, F32, "scale", True)
+    kh, kw, Ci, Co = w.shape
+    bt_f = bt_b = None
+    if want_fwd:
+        Kp = (kh * kw * Ci + 7) // 8 * 8
+        bt_f = torch.empty((Co, Kp), dtype=BF16, device=w.device)
+    if want_bwd:
+        Kbp = (kh * kw * Co + 7) // 8 * 8
+        bt_b = torch.empty((Ci, Kbp), dtype=BF16, device=w.device)
+    check(lib().cg_weight_prep(_p(w), kh, kw, Ci, Co, _p(scale), _p(bt_f), _p(bt_b), _stream()),
+          "cg_weight_prep")
+    return bt_f, bt_b
+
+
+def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slope_out=0.0,
+          residual=None, out_f32=False):
+    _req(x, BF16, "x")
+    _req(bt, BF16, "bt")
+    _req(bias, F32, "bias", True)
+    _req(gate_in, BF16, "gate_in", True)
+    _req(gate_out, BF16, "gate_out", True)
+    _req(residual, BF16, "residual", True)
+    if x.numel() != geom.N * geom.Hin * geom.Win * geom.Ci:
+        raise ValueError("x has %d elements, geometry expects %s" % (x.numel(), geom.key()))
+    Kp = (geom.kh * geom.kw * geom.Ci + 7) // 8 * 8
+    if tuple(bt.shape) != (geom.Co, Kp):
+        raise ValueError("bt shape %s != (%d, %d)" % (tuple(bt.shape), geom.Co, Kp))
+    oshape = (geom.N, geom.Ho, geom.Wo, geom.Co)
+    for t, nm in ((gate_out, "gate_out"), (residual, "residual")):
+        if t is not None and t.numel() != geom.N * geom.Ho * geom.Wo * geom.Co:
+            raise ValueError("%s has the wrong number of elements" % nm)
+    if gate_in is not None and gate_in.numel() != x.numel():
+        raise ValueError("gate_in has the wrong number of elements")
+    if bias is not None and bias.numel() != geom.Co:
+        raise ValueError("bias has the wrong number of elements")
+    out = torch.empty(oshape, dtype=F32 if out_f32 else BF16, device=x.device)
+    check(lib().cg_gconv(ctypes.byref(geom), _p(x), _p(bt), _p(out), int(out_f32), _p(bias),
+                         _p(gate_in), float(slope_in), _p(gate_out), float(slope_out),
+                         _p(residual), _stream()), "cg_gconv")
+    return out
+
+
+def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, want_dbias=False,
+           out=None, accumulate=False):
+    """dw fp32 [kh,kw,Ci,Co] (+ dbias [Co]) of the gather convolution `geom`."""
+    _req(x, BF16, "x")
+    _req(dy, BF16, "dy")
+    _req(gate_in, BF16, "gate_in", True)
+    _req(gate_dy, BF16, "gate_dy", True)
+    if x.numel() != geom.N * geom.Hin * geom.Win * geom.Ci:
+        raise ValueError("x has the wrong number of elements for %s" % (geom.key(),))
+    if dy.numel() != geom.N * geom.Ho * geom.Wo * geom.Co:
+        raise ValueError("dy has the wrong number of elements for %s" % (geom.key(),))
+    dw = out if out is not None else torch.empty((geom.kh, geom.kw, geom.Ci, geom.Co), dtype=F32,
+                                                  device=x.device)
+    _req(dw, F32, "dw")
+    dbias = torch.empty((geom.Co,), dtype=F32, device=x.device) if want_dbias else None
+    nbytes = lib().cg_gwgrad_workspace_bytes(ctypes.byref(geom))
+    ws = _ws(nbytes, x)
+    check(lib().cg_gwgrad(ctypes.byref(geom), _p(x), _p(gate_in), float(slope_in), _p(dy),
+                          _p(gate_dy), float(slope_dy), _p(dw), int(accumulate), _p(dbias),
+                          _p(ws), ws.numel(), _stream()), "cg_gwgrad")
+    return dw, dbias
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral norm
+# ------------------------------------------------------------------------------------------------
+def spectral_norm(w2d, u, mode, eps=1e-12):
+    """One power iteration; updates u IN PLACE.  Returns (v, sigma, inv_sigma)."""
+    _req(w2d, F32, "w")
+    _req(u, F32, "u")
+    K, Co = w2d.shape
+    if u.numel() != (K if mode == 0 else Co):
+        raise ValueError("u has %d elements for mode %d of a [%d,%d] matrix" % (u.numel(), mode, K, Co))
+    v = torch.empty((Co if mode == 0 else K,), dtype=F32, device=w2d.device)
+    sig = torch.empty((2,), dtype=F32, device=w2d.device)
+    ws = _ws(lib().cg_spectral_norm_workspace_bytes(K, Co), w2d)
+    check(lib().cg_spectral_norm(_p(w2d), K, Co, mode, float(eps), _p(u), _p(u), _p(v),
+                                 ctypes.c_void_p(sig.data_ptr()),
+                                 ctypes.c_void_p(sig.data_ptr() + 4), _p(ws), ws.numel(),
+                                 _stream()), "cg_spectral_norm")
+    return v, sig[0:1], sig[1:2]
+
+
+def sn_backward(dwbar2d, w2d, a_k, b_co, sigma):
+    _req(dwbar2d, F32, "dwbar")
+    _req(w2d, F32, "w")
+    K, Co = w2d.shape
+    dw = torch.empty_like(w2d)
+    ws = _ws(lib().cg_sn_backward_workspace_bytes(K, Co), w2d)
+    check(lib().cg_sn_backward(_p(dwbar2d), _p(w2d), K, Co, _p(a_k), _p(b_co), _p(sigma), _p(dw),
+                               _p(ws), ws.numel(), _stream()), "cg_sn_backward")
+    return dw
+
+
+def scale_f32(x, scale_dev=None, scale_host=1.0):
+    _req(x, F32, "x")
+    out = torch.empty_like(x)
+    check(lib().cg_scale_f32(_p(x), _p(scale_dev), float(scale_host), _p(out), x.numel(),
+                             _stream()), "cg_scale_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------------------
+def bn_stats(x3):
+    """x3 [N, HW, C] bf16 -> mean, var fp32 [C]."""
+    _req(x3, BF16, "x")
+    N, HW, C = x3.shape
+    mean = torch.empty((C,), dtype=F32, device=x3.device)
+    var = torch.empty((C,), dtype=F32, device=x3.device)
+    ws = _ws(lib().cg_bn_stats_workspace_bytes(N * HW, C), x3)
+    check(lib().cg_bn_stats(_p(x3), N * HW, C, _p(mean), _p(var), _p(ws), ws.numel(), _stream()),
+          "cg_bn_stats")
+    return mean, var
+
+
+def bn_apply(x3, mean, var, eps, gamma=None, beta=None, per_sample=False, relu=False):
+    _req(x3, BF16, "x")
+    N, HW, C = x3.shape
+    for t, nm in ((mean, "mean"), (var, "var")):
+        _req(t, F32, nm)
+    _req(gamma, F32, "gamma", True)
+    _req(beta, F32, "beta", True)
+    y = torch.empty_like(x3)
+    check(lib().cg_bn_apply(_p(x3), N, HW, C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta),
+                            int(per_sample), int(relu), _p(y), _stream()), "cg_bn_apply")
+    return y
+
+
+def bn_backward(x3, y3, dy3, mean, var, eps, gamma=None, per_sample=False, relu=False,
+                batch_stats=True, want_dgamma=True, want_dbeta=True):
+    _req(x3, BF16, "x")
+    _req(dy3, BF16, "dy")
+    _req(y3, BF16, "y", not relu)
+    N, HW, C = x3.shape
+    dx = torch.empty_like(x3)
+    pshape = (N, C) if per_sample else (C,)
+    dgamma = torch.empty(pshape, dtype=F32, device=x3.device) if want_dgamma else None
+    dbeta = torch.empty(pshape, dtype=F32, device=x3.device) if want_dbeta else None
+    ws = _ws(lib().cg_bn_backward_workspace_bytes(N, HW, C), x3)
+    check(lib().cg_bn_backward(_p(x3), _p(y3), _p(dy3), N, HW, C, _p(mean), _p(var), float(eps),
+                               _p(gamma), int(per_sample), int(relu), int(batch_stats), _p(dx),
+                               _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream()),
+          "cg_bn_backward")
+    return dx, dgamma, dbeta
+
+
+def bn_update_moving(moving_mean, moving_var, mean, var, decay):
+    check(lib().cg_bn_update_moving(_p(moving_mean), _p(moving_var), _p(mean), _p(var),
+                                    mean.numel(), float(decay), _stream()), "cg_bn_update_moving")
+
+
+# ------------------------------------------------------------------------------------------------
+# element-wise / pooling
+# ------------------------------------------------------------------------------------------------
+def lrelu(x, slope):
+    _req(x, BF16, "x")
+    y = torch.empty_like(x)
+    check(lib().cg_lrelu(_p(x), float(slope), _p(y), x.numel(), _stream()), "cg_lrelu")
+    return y
+
+
+def lrelu_bwd(x, dy, slope):
+    _req(x, BF16, "x")
+    _req(dy, BF16, "dy")
+    dx = torch.empty_like(x)
+    check(lib().cg_lrelu_bwd(_p(x), _p(dy), float(slope), _p(dx), x.numel(), _stream()),
+          "cg_lrelu_bwd")
+    return dx
+
+
+def axpby(a, alpha, b=None, beta=0.0):
+    _req(a, BF16, "a")
+    _req(b, BF16, "b", True)
+    out = torch.empty_like(a)
+    check(lib().cg_axpby(_p(a), float(alpha), _p(b), float(beta), _p(out), a.numel(), _stream()),
+          "cg_axpby")
+    return out
+
+
+def _pool(fn, name, x):
+    _req(x, BF16, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    check(fn(_p(x), N, H, W, C, _p(y), _stream()), name)
+    return y
+
+
+def avgpool2(x):
+    return _pool(lib().cg_avgpool2, "cg_avgpool2", x)
+
+
+def maxpool2(x):
+    return _pool(lib().cg_maxpool2, "cg_maxpool2", x)
+
+
+def avgpool2_bwd(dy):
+    """dy [N,H/2,W/2,C] -> dx [N,H,W,C]."""
+    _req(dy, BF16, "dy")
+    N, Ho, Wo, C = dy.shape
+    dx = torch.empty((N, Ho * 2, Wo * 2, C), dtype=BF16, device=dy.device)
+    check(lib().cg_avgpool2_bwd(_p(dy), N, Ho * 2, Wo * 2, C, _p(dx), _stream()),
+          "cg_avgpool2_bwd")
+    return dx
+
+
+def maxpool2_bwd(x, dy):
+    _req(x, BF16, "x")
+    _req(dy, BF16, "dy")
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib().cg_maxpool2_bwd(_p(x), _p(dy), N, H, W, C, _p(dx), _stream()), "cg_maxpool2_bwd")
+    return dx
+
+
+def spatial_reduce(x, gate, scale):
+    """x [N,H,W,C] (or [N,HW,C]) -> [N,C]: scale * sum_hw x * (gate>0)."""
+    _req(x, BF16, "x")
+    _req(gate, BF16, "gate", True)
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    out = torch.empty((N, C), dtype=BF16, device=x.device)
+    check(lib().cg_spatial_reduce(_p(x), _p(gate), N, HW, C, float(scale), _p(out), _stream()),
+          "cg_spatial_reduce")
+    return out
+
+
+def spatial_reduce_bwd(gate, dout, shape, scale):
+    _req(dout, BF16, "dout")
+    _req(gate, BF16, "gate", True)
+    N, C = shape[0], shape[-1]
+    HW = 1
+    for s in shape[1:-1]:
+        HW *= s
+    dx = torch.empty(shape, dtype=BF16, device=dout.device)
+    check(lib().cg_spatial_reduce_bwd(_p(gate), _p(dout), N, HW, C, float(scale), _p(dx),
+                                      _stream()), "cg_spatial_reduce_bwd")
+    return dx
+
+
+def head(x, kind):
+    _req(x, F32, "x")
+    y = torch.empty_like(x)
+    check(lib().cg_head(_p(x), kind, _p(y), x.numel(), _stream()), "cg_head")
+    return y
+
+
+def head_bwd(y, kind, dy):
+    _req(y, F32, "y")
+    if dy.dtype not in (F32, BF16):
+        raise ValueError("dy must be fp32 or bf16")
+    dx = torch.empty(y.shape, dtype=BF16, device=y.device)
+    check(lib().cg_head_bwd(_p(y), kind, _p(dy.contiguous()), int(dy.dtype == F32), _p(dx),
+                            y.numel(), _stream()), "cg_head_bwd")
+    return dx
+
+
+def cast_f32_to_bf16(x, a=1.0, b=0.0, out=None):
+    _req(x, F32, "x")
+    y = out if out is not None else torch.empty(x.shape, dtype=BF16, device=x.device)
+    if a == 1.0 and b == 0.0:
+        check(lib().cg_cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "cg_cast_f32_to_bf16")
+    else:
+        check(lib().cg_affine_f32_to_bf16(_p(x), float(a), float(b), _p(y), x.numel(), _stream()),
+              "cg_affine_f32_to_bf16")
+    return y
+
+
+def cast_bf16_to_f32(x):
+    _req(x, BF16, "x")
+    y = torch.empty(x.shape, dtype=F32, device=x.device)
+    check(lib().cg_cast_bf16_to_f32(_p(x), _p(y), x.numel(), _stream()), "cg_cast_bf16_to_f32")
+    return y
+
+
+def colsum(x2):
+    _req(x2, BF16, "x")
+    rows, C = x2.shape
+    out = torch.empty((C,), dtype=F32, device=x2.device)
+    ws = _ws(lib().cg_colsum_workspace_bytes(rows, C), x2)
+    check(lib().cg_colsum(_p(x2), rows, C, _p(out), _p(ws), ws.numel(), _stream()), "cg_colsum")
+    return out
+
+
+def rowdot(a, b):
+    _req(a, BF16, "a")
+    _req(b, BF16, "b")
+    B, C = a.shape
+    out = torch.empty((B, 1), dtype=F32, device=a.device)
+    check(lib().cg_rowdot(_p(a), _p(b), B, C, _p(out), _stream()), "cg_rowdot")
+    return out
+
+
+def rowdot_bwd(a, b, dout, want_da=True, want_db=True):
+    _req(dout, F32, "dout")
+    B, C = a.shape
+    da = torch.empty_like(a) if want_da else None
+    db = torch.empty_like(b) if want_db else None
+    check(lib().cg_rowdot_bwd(_p(a), _p(b), _p(dout), B, C, _p(da), _p(db), _stream()),
+          "cg_rowdot_bwd")
+    return da, db
+
+
+def one_hot(labels, K):
+    if labels.dtype != torch.int32 or not labels.is_cuda:
+        raise ValueError("labels must be int32 on the GPU")
+    B = labels.numel()
+    out = torch.empty((B, K), dtype=BF16, device=labels.device)
+    check(lib().cg_one_hot(_p(labels.contiguous()), B, K, _p(out), _stream()), "cg_one_hot")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attention_fwd(theta, phi, g):
+    for t, nm in ((theta, "theta"), (phi, "phi"), (g, "g")):
+        _req(t, BF16, nm)
+    B, Lq, Dk = theta.shape
+    _, Lk, Dv = g.shape
+    out = torch.empty((B, Lq, Dv), dtype=BF16, device=theta.device)
+    lse = torch.empty((B, Lq), dtype=F32, device=theta.device)
+    check(lib().cg_attention_fwd(_p(theta), _p(phi), _p(g), B, Lq, Lk, Dk, Dv, _p(out), _p(lse),
+                                 _stream()), "cg_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(theta, phi, g, out, lse, dout):
+    _req(dout, BF16, "dout")
+    B, Lq, Dk = theta.shape
+    _, Lk, Dv = g.shape
+    dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+    ws = _ws(lib().cg_attention_bwd_workspace_bytes(B, Lq, Lk, Dk, Dv), theta)
+    check(lib().cg_attention_bwd(_p(theta), _p(phi), _p(g), _p(out), _p(lse), _p(dout), B, Lq, Lk,
+                                 Dk, Dv, _p(dtheta), _p(dphi), _p(dg), _p(ws), ws.numel(),
+                                 _stream()), "cg_attention_bwd")
+    return dtheta, dphi, dg
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / penalties
+# ------------------------------------------------------------------------------------------------
+LOSS_KINDS = {"non_saturating": 0, "wasserstein": 1, "least_squares": 2, "hinge": 3}
+
+
+def gan_loss(kind, logits):
+    """logits fp32 [2B(,1)] -> (losses[4], dlogits_d [2B], dlogits_g [2B])."""
+    _req(logits, F32, "logits")
+    B = logits.numel() // 2
+    losses = torch.empty((4,), dtype=F32, device=logits.device)
+    dd = torch.empty((2 * B,), dtype=F32, device=logits.device)
+    dg = torch.empty((2 * B,), dtype=F32, device=logits.device)
+    check(lib().cg_gan_loss(kind, _p(logits), B, _p(losses), _p(dd), _p(dg), _stream()),
+          "cg_gan_loss")
+    return losses, dd, dg
+
+
+def interpolate(x, x_fake, alpha):
+    _req(x, F32, "x")
+    _req(x_fake, F32, "x_fake")
+    _req(alpha, F32, "alpha")
+    B = x.shape[0]
+    per = x.numel() // B
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib().cg_interpolate(_p(x), _p(x_fake), _p(alpha), B, per, _p(out), _stream()),
+          "cg_interpolate")
+    return out
+
+
+def gradient_penalty(g):
+    _req(g, F32, "g")
+    B = g.shape[0]
+    per = g.numel() // B
+    slopes = torch.empty((B,), dtype=F32, device=g.device)
+    pen = torch.empty((1,), dtype=F32, device=g.device)
+    check(lib().cg_gradient_penalty(_p(g), B, per, _p(slopes), _p(pen), _stream()),
+          "cg_gradient_penalty")
+    return slopes, pen
+
+
+def gradient_penalty_bwd(g, slopes, upstream):
+    _req(upstream, F32, "upstream", True)
+    B = g.shape[0]
+    per = g.numel() // B
+    dg = torch.empty(g.shape, dtype=BF16, device=g.device)
+    check(lib().cg_gradient_penalty_bwd(_p(g), _p(slopes), _p(upstream), B, per, _p(dg),
+                                        _stream()), "cg_gradient_penalty_bwd")
+    return dg
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser / counters / rng
+# ------------------------------------------------------------------------------------------------
+class AdamTable(object):
+    """Device-resident cgAdamEntry table for a fixed list of (param, grad, m, v, ema) tensors."""
+
+    def __init__(self, params, grads, ms, vs, emas=None):
+        n = len(params)
+        entries = (_lib.AdamEntry * n)()
+        chunk = 0
+        offs = []
+        off = 0
+        for i in range(n):
+            for t in (params[i], grads[i], ms[i], vs[i]):
+                _req(t, F32, "adam tensor")
+            e = entries[i]
+            e.param, e.grad = params[i].data_ptr(), grads[i].data_ptr()
+            e.m, e.v = ms[i].data_ptr(), vs[i].data_ptr()
+            e.ema = emas[i].data_ptr() if emas is not None and emas[i] is not None else None
+            e.n = params[i].numel()
+            e.chunk_begin = chunk
+            chunk += (e.n + _lib.ADAM_CHUNK - 1) // _lib.ADAM_CHUNK
+            offs.append(off)
+            off += e.n
+        self.n = n
+        self.total_chunks = chunk
+        self.total_elems = off
+        dev = params[0].device
+        raw = bytes(entries)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.offsets = torch.tensor(offs, dtype=torch.int64).to(dev)
+        self._keep = (params, grads, ms, vs, emas)
+
+    def adam(self, lr, beta1, beta2, eps, grad_scale, step, ema_decay=0.0, ema_start=0):
+        check(lib().cg_adam_multi(_p(self.table), self.n, self.total_chunks, float(lr),
+                                  float(beta1), float(beta2), float(eps), float(grad_scale),
+                                  _p(step), float(ema_decay), int(ema_start), _stream()),
+              "cg_adam_multi")
+
+    def gather(self, flat):
+        _req(flat, F32, "flat")
+        check(lib().cg_multi_gather(_p(self.table), _p(self.offsets), self.n, self.total_chunks,
+                                    _p(flat), _stream()), "cg_multi_gather")
+
+    def scatter(self, flat):
+        _req(flat, F32, "flat")
+        check(lib().cg_multi_scatter(_p(self.table), _p(self.offsets), self.n, self.total_chunks,
+                                     _p(flat), _stream()), "cg_multi_scatter")
+
+
+def counter_add(counter, inc=1):
+    if counter.dtype != torch.int64:
+        raise ValueError("counter must be int64")
+    check(lib().cg_counter_add(_p(counter), int(inc), _stream()), "cg_counter_add")
+
+
+def random(kind, lo, hi, seed, op_id, stream_id, step, shape, device):
+    """kind 0 uniform[lo,hi), 1 normal(mean=lo, std=hi)."""
+    out = torch.empty(shape, dtype=F32, device=device)
+    check(lib().cg_random(kind, float(lo), float(hi), int(seed) & (2 ** 64 - 1), int(op_id),
+                          int(stream_id), _p(step), _p(out), out.numel(), _stream()), "cg_random")
+    return out
+
+
+def random_labels(K, seed, op_id, stream_id, step, n, device):
+    out = torch.empty((n,), dtype=torch.int32, device=device)
+    check(lib().cg_random_labels(int(K), int(seed) & (2 ** 64 - 1), int(op_id), int(stream_id),
+                                 _p(step), _p(out), n, _stream()), "cg_random_labels")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# FID / IS statistics
+# ------------------------------------------------------------------------------------------------
+def mean_cov_f64(x):
+    _req(x, F32, "x")
+    n, d = x.shape
+    mean = torch.empty((d,), dtype=F64, device=x.device)
+    cov = torch.empty((d, d), dtype=F64, device=x.device)
+    ws = _ws(lib().cg_mean_cov_workspace_bytes(n, d), x)
+    check(lib().cg_mean_cov_f64(_p(x), n, d, _p(mean), _p(cov), _p(ws), ws.numel(), _stream()),
+          "cg_mean_cov_f64")
+    return mean, cov
+
+
+def gemm_f64(a, b, ta=False, tb=False):
+    _req(a, F64, "a")
+    _req(b, F64, "b")
+    m, k = (a.shape[1], a.shape[0]) if ta else a.shape
+    n = b.shape[0] if tb else b.shape[1]
+    c = torch.empty((m, n), dtype=F64, device=a.device)
+    check(lib().cg_gemm_f64(_p(a), _p(b), _p(c), m, n, k, int(ta), int(tb), _stream()),
+          "cg_gemm_f64")
+    return c
+
+
+def syevj_f64(a, max_sweeps=30, tol=1e-15):
+    """Destroys `a`.  Returns (w [d], v [d,d] with eigenvectors as ROWS)."""
+    _req(a, F64, "a")
+    d = a.shape[0]
+    w = torch.empty((d,), dtype=F64, device=a.device)
+    v = torch.empty((d, d), dtype=F64, device=a.device)
+    ws = _ws(lib().cg_syevj_workspace_bytes(d), a)
+    check(lib().cg_syevj_f64(_p(a), d, _p(w), _p(v), int(max_sweeps), float(tol), _p(ws),
+                             ws.numel(), _stream()), "cg_syevj_f64")
+    return w, v
+
+
+def inception_score_f64(logits):
+    _req(logits, F32, "logits")
+    n, k = logits.shape
+    score = torch.empty((1,), dtype=F64, device=logits.device)
+    ws = _ws(lib().cg_inception_score_workspace_bytes(n, k), logits)
+    check(lib().cg_inception_score_f64(_p(logits), n, k, _p(score), _p(ws), ws.numel(),
+                                       _stream()), "cg_inception_score_f64")
+    return score
+
+
+def inception_preprocess(x, Ho=299, Wo=299):
+    _req(x, F32, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, Ho, Wo, C), dtype=BF16, device=x.device)
+    check(lib().cg_inception_preprocess(_p(x), N, H, W, C, Ho, Wo, _p(y), _stream()),
+          "cg_inception_preprocess")
+    return y
+
+
+def pool2d(x, k, s, p, kind, Ho, Wo):
+    _req(x, BF16, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, Ho, Wo, C), dtype=BF16, device=x.device)
+    check(lib().cg_pool2d(_p(x), N, H, W, C, k, s, p, kind, Ho, Wo, _p(y), _stream()), "cg_pool2d")
+    return y

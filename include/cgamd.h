@@ -1,0 +1,320 @@
+/*
+ * cgamd.h -- C-ABI of libcgamd.so: the MI355X (gfx950) kernels behind compare_gan's
+ * G/D forward-backward hot path and its FID/IS eval path.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers + sizes, no torch / C++ types in any signature.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*), re-entrant,
+ *     allocation-free and synchronisation-free (hipGraph-capturable); scratch memory is supplied
+ *     by the caller (`ws`, sized by the matching *_workspace_bytes query).
+ *   - return value: 0 = ok; negative = error (never throws, never aborts):
+ *       CG_ERR_BAD_ARG (-1) null pointer / non-positive dim / inconsistent geometry,
+ *       CG_ERR_UNSUPPORTED (-2) shape class the kernel family does not cover,
+ *       CG_ERR_LAUNCH (-3) hipGetLastError() after the launch,
+ *       CG_ERR_WORKSPACE (-4) workspace too small.
+ *   - activations are NHWC bf16 (raw uint16 storage); master weights are fp32 in the reference's
+ *     own layouts (conv HWIO [kh,kw,Ci,Co], linear [in,out]); accumulation is fp32; FID stats fp64.
+ *
+ * Each entry point cites the reference code (paths relative to the compare_gan tree) it replaces.
+ */
+#ifndef CGAMD_H_
+#define CGAMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG_OK 0
+#define CG_ERR_BAD_ARG (-1)
+#define CG_ERR_UNSUPPORTED (-2)
+#define CG_ERR_LAUNCH (-3)
+#define CG_ERR_WORKSPACE (-4)
+
+typedef void* cgStream; /* hipStream_t */
+
+/* Library/ABI version (bumped when a signature changes). */
+int cg_abi_version(void);
+/* Human-readable description of the last error on this thread ("" if none). */
+const char* cg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Generalised convolution geometry.
+ *
+ * One "gather convolution" primitive covers every dense contraction of the hot path:
+ *   out[n,oh,ow,co] = sum_{r,s,ci} IN_v[n, oh*S - pt + r, ow*S - pl + s, ci] * B[(r,s,ci), co]
+ * where IN_v is `in` with U-1 zeros inserted between pixels (virtual size Hin*U x Win*U) and
+ * zero padding outside.  U=1,S=stride is tf.nn.conv2d(SAME) (architectures/arch_ops.py:559-573);
+ * U=2,S=1 is resnet_ops.unpool + conv2d (architectures/resnet_ops.py:35-56,112-134);
+ * U=stride,S=1 with flipped/transposed weights is tf.nn.conv2d_transpose
+ * (arch_ops.py:579-592) and the data-gradient of a strided conv; kh=kw=1,H=W=1 is
+ * arch_ops.linear (arch_ops.py:538-556).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t N, Hin, Win, Ci; /* input  NHWC */
+  int32_t Ho, Wo, Co;      /* output NHWC */
+  int32_t kh, kw;          /* filter taps */
+  int32_t S;               /* output stride over the virtual input */
+  int32_t U;               /* zero-insertion factor of the input (1 = none) */
+  int32_t pt, pl;          /* top / left zero padding of the virtual input */
+} cgConvGeom;
+
+/* Weight preparation: fp32 HWIO master weight -> bf16 MFMA operand image(s).
+ *   w        [kh,kw,Ci,Co] fp32
+ *   scale    optional device scalar multiplied in (1/sigma of spectral norm,
+ *            arch_ops.py:531 `w / norm_value`), may be NULL
+ *   bt_fwd   optional [Co][kh*kw*Ci] bf16  (k = (r*kw+s)*Ci+ci contiguous)       -> cg_gconv fwd
+ *   bt_bwd   optional [Ci][kh*kw*Co] bf16  with taps flipped (r'=kh-1-r, s'=kw-1-s),
+ *            k' = (r'*kw+s')*Co+co contiguous                                    -> data-gradient /
+ *            conv2d_transpose form.
+ */
+int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,
+                   void* bt_fwd, void* bt_bwd, cgStream stream);
+
+/* out = d(gate_out) * ( gconv( d(gate_in) * in , bt ) + bias ) + residual
+ *   d(g) = g > 0 ? 1 : slope   (elementwise ReLU / leaky-ReLU derivative gates,
+ *   arch_ops.py:595-597 lrelu; resnet_ops.py:165,175 tf.nn.relu); gate_in==in gives act(in).
+ *   in        [N,Hin,Win,Ci] bf16
+ *   bt        [Co][kh*kw*Ci] bf16 (from cg_weight_prep)
+ *   out       [N,Ho,Wo,Co] bf16, or fp32 when out_is_f32 != 0
+ *   bias      [Co] fp32 or NULL;  gate_in like `in` (bf16) or NULL;  gate_out / residual like
+ *             `out` (bf16) or NULL.
+ */
+int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, int out_is_f32,
+             const float* bias, const void* gate_in, float slope_in, const void* gate_out,
+             float slope_out, const void* residual, cgStream stream);
+
+/* Weight gradient of the same primitive (tf.gradients of arch_ops.conv2d / deconv2d / linear
+ * w.r.t. the kernel):
+ *   dw[(r,s,ci),co] (+)= sum_{n,oh,ow} d(gate_in)*IN_v[n,oh*S-pt+r,ow*S-pl+s,ci] * d(gate_dy)*dy[n,oh,ow,co]
+ *   dw fp32 [kh,kw,Ci,Co]; accumulate != 0 adds into dw instead of overwriting.
+ *   dbias optional fp32 [Co] = column sums of the gated dy (NULL to skip).
+ *   ws: workspace of at least cg_gwgrad_workspace_bytes(geom) bytes.
+ */
+size_t cg_gwgrad_workspace_bytes(const cgConvGeom* geom);
+int cg_gwgrad(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
+              const void* dy, const void* gate_dy, float slope_dy, float* dw, int accumulate,
+              float* dbias, void* ws, size_t ws_bytes, cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectral normalisation (arch_ops.py:453-535): one power-iteration round, sigma, u update.
+ *   w [K,Co] fp32 (HWIO flattened); mode 0 = "left" (u is [K]), 1 = "right" (u is [Co]).
+ *   left : v = l2n(w^T u), u' = l2n(w v), sigma = u'^T w v
+ *   right: v = l2n(w u^T)  ([K]), u' = l2n(v^T w) ([Co]), sigma = v^T w u'^T
+ *   l2n(x) = x * rsqrt(max(sum x^2, eps)).
+ * Outputs: u_out (may alias u_in), v_out (the non-persisted vector), sigma (1 float),
+ *          inv_sigma (1 float).  ws >= cg_spectral_norm_workspace_bytes(K,Co).
+ * ------------------------------------------------------------------------------------------ */
+size_t cg_spectral_norm_workspace_bytes(int K, int Co);
+int cg_spectral_norm(const float* w, int K, int Co, int mode, float eps, const float* u_in,
+                     float* u_out, float* v_out, float* sigma, float* inv_sigma, void* ws,
+                     size_t ws_bytes, cgStream stream);
+/* Gradient through w_bar = w / sigma with u,v constants (arch_ops.py:519-531):
+ *   dw = (dwbar - <dwbar, w>/sigma * a b^T) / sigma   with (a,b) = (u',v) left, (v,u') right,
+ *   a is [K], b is [Co].  dw may alias dwbar.  ws >= cg_sn_backward_workspace_bytes(K,Co). */
+size_t cg_sn_backward_workspace_bytes(int K, int Co);
+int cg_sn_backward(const float* dwbar, const float* w, int K, int Co, const float* a_k,
+                   const float* b_co, const float* sigma, float* dw, void* ws, size_t ws_bytes,
+                   cgStream stream);
+
+/* out = x * (*scale_dev) * scale_host on fp32 (w_bar = w * (1/sigma), arch_ops.py:531; also loss
+ * gradient scaling).  scale_dev may be NULL (= 1). out may alias x. */
+int cg_scale_f32(const float* x, const float* scale_dev, float scale_host, float* out, int64_t n,
+                 cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch normalisation family (arch_ops.py:194-319 standardize_batch, :327-367 batch_norm,
+ * :423-445 conditional_batch_norm).  x is [N, HW, C] bf16 (2-D inputs use HW=1).
+ * ------------------------------------------------------------------------------------------ */
+/* mean[c] = sum x / n ; var[c] = sum x^2 / n - mean^2 (fp32, arch_ops.py:294-297).
+ * ws >= cg_bn_stats_workspace_bytes(N*HW, C). */
+size_t cg_bn_stats_workspace_bytes(int64_t rows, int C);
+int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var, void* ws,
+                size_t ws_bytes, cgStream stream);
+/* y = act( (x - mean) * rsqrt(var + eps) * gamma + beta ), act = relu if relu != 0.
+ * gamma/beta: fp32 [C] (per_sample == 0) or [N,C] (per_sample != 0, conditional BN), NULL = 1 / 0.
+ * y bf16 same shape as x. */
+int cg_bn_apply(const void* x, int N, int HW, int C, const float* mean, const float* var,
+                float eps, const float* gamma, const float* beta, int per_sample, int relu,
+                void* y, cgStream stream);
+/* Backward of cg_bn_apply in training mode (mean/var are functions of x):
+ *   dz = dy * (y > 0) if relu;  dbeta = sum dz;  dgamma = sum dz * xhat  (per [C] or per [N,C]);
+ *   dx = rstd * (g*dz - mean_n(g*dz) - xhat * mean_n(g*dz*xhat))   when batch_stats != 0
+ *   dx = rstd * g * dz                                              when batch_stats == 0 (eval).
+ * dgamma/dbeta may be NULL.  ws >= cg_bn_backward_workspace_bytes(N, HW, C). */
+size_t cg_bn_backward_workspace_bytes(int N, int HW, int C);
+int cg_bn_backward(const void* x, const void* y, const void* dy, int N, int HW, int C,
+                   const float* mean, const float* var, float eps, const float* gamma,
+                   int per_sample, int relu, int batch_stats, void* dx, float* dgamma,
+                   float* dbeta, void* ws, size_t ws_bytes, cgStream stream);
+/* Moving averages m <- m - (1-decay) * (m - batch)  (arch_ops.py:105-114), both vectors [C]. */
+int cg_bn_update_moving(float* moving_mean, float* moving_var, const float* mean,
+                        const float* var, int C, float decay, cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / pooling glue of the G and D graphs.
+ * ------------------------------------------------------------------------------------------ */
+/* y = x > 0 ? x : slope*x  (arch_ops.py:595-597; slope 0 = tf.nn.relu), bf16, n elements. */
+int cg_lrelu(const void* x, float slope, void* y, int64_t n, cgStream stream);
+/* dx = dy * (x > 0 ? 1 : slope) */
+int cg_lrelu_bwd(const void* x, const void* dy, float slope, void* dx, int64_t n, cgStream stream);
+/* out = a*alpha + b*beta (bf16), b may be NULL. */
+int cg_axpby(const void* a, float alpha, const void* b, float beta, void* out, int64_t n,
+             cgStream stream);
+/* 2x2 average pooling, stride 2 (resnet_ops.py:131-133), x [N,H,W,C] -> y [N,H/2,W/2,C]. */
+int cg_avgpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream);
+int cg_avgpool2_bwd(const void* dy, int N, int H, int W, int C, void* dx, cgStream stream);
+/* 2x2 max pooling stride 2 (arch_ops.py:741,750) and its gradient (routes to first max). */
+int cg_maxpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream);
+int cg_maxpool2_bwd(const void* x, const void* dy, int N, int H, int W, int C, void* dx,
+                    cgStream stream);
+/* Spatial reduction over HW per (n,c): out = scale * sum_hw x * (gate ? gate>0 : 1)
+ * (gate == x: resnet_cifar.py:154-156 relu+reduce_mean, resnet_biggan.py:404-405 relu+reduce_sum).
+ * x, gate [N,HW,C] bf16 -> out [N,C] bf16. */
+int cg_spatial_reduce(const void* x, const void* gate, int N, int HW, int C, float scale,
+                      void* out, cgStream stream);
+/* dx[n,hw,c] = scale * dout[n,c] * (gate ? gate>0 : 1) */
+int cg_spatial_reduce_bwd(const void* gate, const void* dout, int N, int HW, int C, float scale,
+                          void* dx, cgStream stream);
+/* Output heads (resnet_cifar.py:112 sigmoid; resnet_biggan.py:301 / sndcgan.py:74-78
+ * (tanh+1)/2; dcgan.py:81 0.5*tanh+0.5).  kind: 0 sigmoid, 1 (tanh+1)/2.
+ * x fp32 [n] -> y fp32 [n];  bwd: dx(bf16) = dy(fp32 or bf16) * head'(x). */
+int cg_head(const float* x, int kind, float* y, int64_t n, cgStream stream);
+int cg_head_bwd(const float* y, int kind, const void* dy, int dy_is_f32, void* dx_bf16, int64_t n,
+                cgStream stream);
+/* Casts. */
+int cg_cast_f32_to_bf16(const float* x, void* y, int64_t n, cgStream stream);
+int cg_cast_bf16_to_f32(const void* x, float* y, int64_t n, cgStream stream);
+/* y = x * a + b elementwise on fp32 -> bf16 (sndcgan.py:108 `x * 2.0 - 1.0`, plus cast). */
+int cg_affine_f32_to_bf16(const float* x, float a, float b, void* y, int64_t n, cgStream stream);
+/* Column sums of a [rows, C] bf16 matrix into fp32 [C] (bias gradients).
+ * ws >= cg_colsum_workspace_bytes(rows, C). */
+size_t cg_colsum_workspace_bytes(int64_t rows, int C);
+int cg_colsum(const void* x, int64_t rows, int C, float* out, void* ws, size_t ws_bytes,
+              cgStream stream);
+/* out[b] = sum_c a[b,c]*b[b,c]  (projection discriminator, resnet_biggan.py:423), bf16 in,
+ * fp32 out [B]; bwd: da = dout[b]*b, db = dout[b]*a. */
+int cg_rowdot(const void* a, const void* b, int B, int C, float* out, cgStream stream);
+int cg_rowdot_bwd(const void* a, const void* b, const float* dout, int B, int C, void* da,
+                  void* db, cgStream stream);
+/* one_hot(labels, K) as bf16 [B,K]  (modular_gan.py:359-363). */
+int cg_one_hot(const int32_t* labels, int B, int K, void* out, cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Self-attention core of arch_ops.non_local_block (arch_ops.py:744-753):
+ *   attn = softmax(theta phi^T) ; out = attn g,  per image.
+ *   theta [B,Lq,Dk], phi [B,Lk,Dk], g [B,Lk,Dv] bf16 -> out [B,Lq,Dv] bf16, lse [B,Lq] fp32.
+ * Backward recomputes the probabilities from lse (no [B,Lq,Lk] tensor is materialised).
+ * ------------------------------------------------------------------------------------------ */
+int cg_attention_fwd(const void* theta, const void* phi, const void* g, int B, int Lq, int Lk,
+                     int Dk, int Dv, void* out, float* lse, cgStream stream);
+size_t cg_attention_bwd_workspace_bytes(int B, int Lq, int Lk, int Dk, int Dv);
+int cg_attention_bwd(const void* theta, const void* phi, const void* g, const void* out,
+                     const float* lse, const void* dout, int B, int Lq, int Lk, int Dk, int Dv,
+                     void* dtheta, void* dphi, void* dg, void* ws, size_t ws_bytes,
+                     cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses (gans/loss_lib.py:53-148) and WGAN-GP (gans/penalty_lib.py:59-82).
+ * kind: 0 non_saturating, 1 wasserstein, 2 least_squares, 3 hinge.
+ * logits fp32 [2B] = real (first B) then fake (last B) (modular_gan.py:657-661).
+ * losses[4] = d_loss, d_loss_real, d_loss_fake, g_loss.
+ * dlogits_d [2B] = d d_loss / d logits;  dlogits_g [2B] = d g_loss / d logits (real half = 0).
+ * ------------------------------------------------------------------------------------------ */
+int cg_gan_loss(int kind, const float* logits, int B, float* losses, float* dlogits_d,
+                float* dlogits_g, cgStream stream);
+/* interpolates = x + alpha[b] * (x_fake - x)   (penalty_lib.py:72-73), fp32 in, bf16 out. */
+int cg_interpolate(const float* x, const float* x_fake, const float* alpha, int B, int64_t per,
+                   void* out_bf16, cgStream stream);
+/* slopes[b] = sqrt(1e-4 + sum g^2); penalty = mean((slopes-1)^2)  (penalty_lib.py:77-81).
+ * g fp32 [B, per]. */
+int cg_gradient_penalty(const float* g, int B, int64_t per, float* slopes, float* penalty,
+                        cgStream stream);
+/* dg = upstream * 2/B * (slopes[b]-1)/slopes[b] * g   -> bf16 */
+int cg_gradient_penalty_bwd(const float* g, const float* slopes, const float* upstream, int B,
+                            int64_t per, void* dg_bf16, cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser: tf.train.AdamOptimizer (TF1 epsilon placement) + tf.train.ExponentialMovingAverage
+ * (modular_gan.py:480-483,494-508) over a list of tensors in ONE launch.
+ *   lr_t = lr * sqrt(1-beta2^t) / (1-beta1^t);  m,v update;  p -= lr_t * m / (sqrt(v) + eps)
+ *   ema (optional): s <- s - (1-d)(s - p), d = ema_decay * [t_gen >= ema_start]
+ * table: device array of cgAdamEntry (one per tensor); step: device int64 counter holding the
+ * number of updates already applied (the kernel uses t = *step + 1); it is NOT modified here.
+ * grad_scale multiplies every gradient (1/world_size for summed data-parallel gradients).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* m;
+  float* v;
+  float* ema; /* NULL if this tensor has no shadow */
+  int64_t n;
+  int64_t chunk_begin; /* prefix sum of ceil(n / CG_ADAM_CHUNK) over previous entries */
+} cgAdamEntry;
+#define CG_ADAM_CHUNK 16384
+int cg_adam_multi(const cgAdamEntry* table, int n_entries, int64_t total_chunks, float lr,
+                  float beta1, float beta2, float eps, float grad_scale, const int64_t* step,
+                  float ema_decay, int64_t ema_start_step, cgStream stream);
+/* counter += inc (device int64 step counters: global_step, global_step_disc). */
+int cg_counter_add(int64_t* counter, int64_t inc, cgStream stream);
+/* Gather a list of fp32 tensors into / scatter out of one flat buffer (gradient buckets for the
+ * RCCL all-reduce).  table is the same cgAdamEntry array (uses .grad/.n/.chunk_begin), offsets in
+ * the flat buffer are chunk_begin * CG_ADAM_CHUNK-independent: flat_offsets[i] device int64. */
+int cg_multi_gather(const cgAdamEntry* table, const int64_t* flat_offsets, int n_entries,
+                    int64_t total_chunks, float* flat, cgStream stream);
+int cg_multi_scatter(const cgAdamEntry* table, const int64_t* flat_offsets, int n_entries,
+                     int64_t total_chunks, const float* flat, cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stateless counter-based RNG (tpu/tpu_random.py:54-154 semantics: reproducible, distinct per
+ * op / step / replica).  Philox4x32-10 keyed by (seed, op_id), counter = (*step_ptr, stream_id,
+ * element index).  step_ptr may be NULL (uses 0).
+ *   kind 0: uniform [lo,hi)   kind 1: normal(mean=lo, stddev=hi)   -> fp32 out[n]
+ * ------------------------------------------------------------------------------------------ */
+int cg_random(int kind, float lo, float hi, uint64_t seed, uint32_t op_id, uint32_t stream_id,
+              const int64_t* step_ptr, float* out, int64_t n, cgStream stream);
+/* Uniform int32 labels in [0,K) (modular_gan.py:386-391). */
+int cg_random_labels(int K, uint64_t seed, uint32_t op_id, uint32_t stream_id,
+                     const int64_t* step_ptr, int32_t* out, int64_t n, cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FID / Inception-score statistics (metrics/fid_score.py:44-75, metrics/inception_score.py:39-48;
+ * the arithmetic the reference delegates to tensorflow_gan, restated in SURVEY section 8c).
+ * ------------------------------------------------------------------------------------------ */
+/* mean[d] (fp64) and unbiased covariance cov[d,d] (fp64, divide by n-1) of x [n,d] fp32.
+ * ws >= cg_mean_cov_workspace_bytes(n, d). */
+size_t cg_mean_cov_workspace_bytes(int64_t n, int d);
+int cg_mean_cov_f64(const float* x, int64_t n, int d, double* mean, double* cov, void* ws,
+                    size_t ws_bytes, cgStream stream);
+/* C = op(A) * op(B), fp64 row-major, A [m,k] (or [k,m] if ta), B [k,n] (or [n,k] if tb). */
+int cg_gemm_f64(const double* a, const double* b, double* c, int m, int n, int k, int ta, int tb,
+                cgStream stream);
+/* Symmetric eigen-decomposition by parallel cyclic one-sided Jacobi: a [d,d] fp64 symmetric
+ * (destroyed), eigenvalues -> w [d] (unsorted), eigenvectors -> ROWS of v [d,d]
+ * (a = v^T diag(w) v).  max_sweeps bounds the work; rotation threshold tol (e.g. 1e-14).
+ * ws >= cg_syevj_workspace_bytes(d). */
+size_t cg_syevj_workspace_bytes(int d);
+int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,
+                 size_t ws_bytes, cgStream stream);
+/* Inception score pieces: logits [n,k] fp32 -> exp(mean_i KL(p_i || mean_j p_j)) in fp64. */
+size_t cg_inception_score_workspace_bytes(int64_t n, int k);
+int cg_inception_score_f64(const float* logits, int64_t n, int k, double* score, void* ws,
+                           size_t ws_bytes, cgStream stream);
+/* Bilinear resize, TF1 legacy `resize_bilinear` (align_corners=False, no half-pixel centres;
+ * eval_utils.py:165-175 via tfgan.eval.preprocess_image), then (x-128)/128.
+ * x [N,H,W,C] fp32 in [0,255] -> y [N,Ho,Wo,C] bf16. */
+int cg_inception_preprocess(const float* x, int N, int H, int W, int C, int Ho, int Wo, void* y,
+                            cgStream stream);
+/* General pooling for the Inception graph: kind 0 max, 1 avg (count includes only valid taps when
+ * pad > 0, TF 'SAME' avg-pool semantics), window k, stride s, symmetric padding p. bf16 NHWC. */
+int cg_pool2d(const void* x, int N, int H, int W, int C, int k, int s, int p, int kind, int Ho,
+              int Wo, void* y, cgStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGAMD_H_ */
