@@ -1,0 +1,488 @@
+"""Op-level parity: every C-ABI kernel family (through compare_gan_amd.hip.kernels -> libcgamd.so)
+against the CPU oracle on the same seeded inputs.
+
+Inputs are drawn in bf16 so that both sides see identical values; the oracle computes in fp64.
+Tolerances (stated per check): bf16 outputs within 2 bf16 ulps (2^-7 rel) + 2^-8 * rms(ref)
+absolute; fp32 outputs (fp32 accumulation of exact bf16 products) within 1e-4 rel + 1e-4 * rms.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import arch_ops as oops
+from oracle import fid as ofid
+from oracle import gan as ogan
+from oracle import rng as orng
+from tests.util import assert_close_bf16, assert_close_f32, rand_bf16
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def K():
+    from compare_gan_amd.hip import kernels
+    kernels.lib()
+    return kernels
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _ref_conv(x, w, stride, up, gate_slope=None):
+    """oracle forward of the gather conv: [lrelu] -> [unpool] -> conv2d SAME."""
+    if gate_slope is not None:
+        x = torch.where(x > 0, x, gate_slope * x)
+    if up == 2:
+        x = oops.unpool(x)
+    return oops.conv2d_same(x, w, stride)
+
+
+CONV_CASES = [
+    # name, N, H, W, Ci, Co, k, stride, up
+    ("gemm_1x1", 2, 8, 8, 64, 128, 1, 1, 1),
+    ("d_3x3_128", 4, 16, 16, 128, 128, 3, 1, 1),
+    ("rgb_in_3x3", 4, 16, 16, 3, 128, 3, 1, 1),
+    ("rgb_out_3x3", 2, 16, 16, 64, 3, 3, 1, 1),
+    ("up_3x3", 2, 4, 4, 256, 256, 3, 1, 2),
+    ("s2_4x4", 2, 16, 16, 64, 128, 4, 2, 1),
+    ("s2_5x5_asym", 2, 16, 16, 64, 128, 5, 2, 1),
+    ("odd_shapes", 3, 5, 7, 24, 40, 3, 1, 1),
+    ("wide_co", 1, 8, 8, 96, 192, 3, 1, 1),
+    ("up_1x1", 2, 8, 8, 64, 32, 1, 1, 2),
+    ("s2_5x5_rgb", 2, 32, 32, 3, 64, 5, 2, 1),
+    ("odd_stride2", 2, 9, 9, 16, 24, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_gconv_forward_adjoint_wgrad(K, dev, case):
+    name, N, H, W, Ci, Co, k, stride, up = case
+    g = _gen(sum(ord(c) for c in name))
+    x64, xb = rand_bf16((N, H, W, Ci), g)
+    w64, wb = rand_bf16((k, k, Ci, Co), g, 1.0 / math.sqrt(k * k * Ci))
+    bias = torch.randn(Co, generator=g, dtype=torch.float32)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, k, k, stride, up)
+    wd = wb.to(torch.float32).to(dev)
+    bt_f, bt_b = K.weight_prep(wd, want_fwd=True, want_bwd=True)
+    xd = xb.to(dev)
+
+    # forward + bias, bf16 and fp32 outputs
+    xr = x64.clone().requires_grad_(True)
+    wr = w64.clone().requires_grad_(True)
+    ref = _ref_conv(xr, wr, stride, up) + bias.to(torch.float64)
+    assert (geom.Ho, geom.Wo) == (ref.shape[1], ref.shape[2])
+    y = K.gconv(geom, xd, bt_f, bias=bias.to(dev))
+    assert_close_bf16(y, ref.detach(), name + " fwd bf16")
+    y32 = K.gconv(geom, xd, bt_f, bias=bias.to(dev), out_f32=True)
+    assert_close_f32(y32, ref.detach(), name + " fwd f32")
+
+    # gradients of sum(ref * dy) from torch autograd on the oracle
+    dy64, dyb = rand_bf16(tuple(ref.shape), g)
+    (ref * dy64).sum().backward()
+    dyd = dyb.to(dev)
+    dx = K.gconv(K.geom_adjoint(geom), dyd, bt_b, out_f32=True)
+    assert_close_f32(dx, xr.grad, name + " dgrad f32", rtol=2e-4, abs_rms=2e-4)
+    dw, db = K.gwgrad(geom, xd, dyd, want_dbias=True)
+    assert_close_f32(dw, wr.grad, name + " wgrad", rtol=2e-4, abs_rms=2e-4)
+    assert_close_f32(db, dy64.sum(dim=(0, 1, 2)), name + " dbias", rtol=2e-4, abs_rms=2e-4)
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.2])
+def test_gconv_gates_residual(K, dev, slope):
+    """out = d(gate_out) * (conv(lrelu(x)) + b) + residual and its wgrad with gated operands."""
+    g = _gen(7)
+    N, H, W, Ci, Co, k = 2, 8, 8, 64, 64, 3
+    x64, xb = rand_bf16((N, H, W, Ci), g)
+    w64, wb = rand_bf16((k, k, Ci, Co), g, 0.05)
+    go64, gob = rand_bf16((N, H, W, Co), g)
+    r64, rb = rand_bf16((N, H, W, Co), g)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, k, k, 1, 1)
+    bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev))
+    xd = xb.to(dev)
+    conv = _ref_conv(x64, w64, 1, 1, gate_slope=slope)
+    dgate = torch.where(go64 > 0, torch.ones_like(go64), torch.full_like(go64, slope))
+    ref = dgate * conv + r64
+    y = K.gconv(geom, xd, bt_f, gate_in=xd, slope_in=slope, gate_out=gob.to(dev), slope_out=slope,
+                residual=rb.to(dev), out_f32=True)
+    # lrelu(x) with slope != 0 is rounded to bf16 before the MFMA -> looser tolerance
+    assert_close_f32(y, ref, "gates fwd", rtol=1e-4 if slope == 0 else 5e-3,
+                     abs_rms=1e-4 if slope == 0 else 5e-3)
+    # wgrad with gate on x and gate on dy
+    dy64, dyb = rand_bf16((N, H, W, Co), g)
+    xr = torch.where(x64 > 0, x64, slope * x64)
+    wr = w64.clone().requires_grad_(True)
+    (oops.conv2d_same(xr, wr, 1) * (dgate * dy64)).sum().backward()
+    dw, _ = K.gwgrad(geom, xd, dyb.to(dev), gate_in=xd, slope_in=slope, gate_dy=gob.to(dev),
+                     slope_dy=slope)
+    assert_close_f32(dw, wr.grad, "gated wgrad", rtol=1e-4 if slope == 0 else 1e-2,
+                     abs_rms=1e-4 if slope == 0 else 1e-2)
+
+
+DECONV_CASES = [("dcgan_5x5", 2, 4, 4, 64, 32, 5, 2), ("sndcgan_4x4", 2, 8, 8, 32, 16, 4, 2),
+                ("sndcgan_3x3_s1", 2, 8, 8, 64, 3, 3, 1)]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
+def test_deconv(K, dev, case):
+    """conv2d_transpose(SAME) = adjoint geometry of the forward conv with kernel [kh,kw,Cout,Cin]."""
+    name, N, H, W, Cin, Cout, k, s = case
+    g = _gen(11)
+    x64, xb = rand_bf16((N, H, W, Cin), g)
+    w64, wb = rand_bf16((k, k, Cout, Cin), g, 0.1)
+    Hy, Wy = H * s, W * s
+    xr = x64.clone().requires_grad_(True)
+    wr = w64.clone().requires_grad_(True)
+    ref = oops.conv2d_transpose_same(xr, wr, (Hy, Wy), s)
+    fgeom = K.geom_conv_same(N, Hy, Wy, Cout, Cin, k, k, s, 1)  # F: y-space -> x-space
+    assert (fgeom.Ho, fgeom.Wo) == (H, W)
+    _, bt_b = K.weight_prep(wb.to(torch.float32).to(dev), want_fwd=False, want_bwd=True)
+    y = K.gconv(K.geom_adjoint(fgeom), xb.to(dev), bt_b, out_f32=True)
+    assert_close_f32(y, ref.detach(), name + " deconv fwd")
+    dy64, dyb = rand_bf16(tuple(ref.shape), g)
+    (ref * dy64).sum().backward()
+    # dx = F(dy) ; dw = wgrad_F(in = dy, "dy" = x)
+    bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev), want_fwd=True)
+    dx = K.gconv(fgeom, dyb.to(dev), bt_f, out_f32=True)
+    assert_close_f32(dx, xr.grad, name + " deconv dx", rtol=2e-4, abs_rms=2e-4)
+    dw, _ = K.gwgrad(fgeom, dyb.to(dev), xb.to(dev))
+    assert_close_f32(dw, wr.grad, name + " deconv dw", rtol=2e-4, abs_rms=2e-4)
+
+
+def test_linear_as_1x1(K, dev):
+    g = _gen(3)
+    B, Kin, Nout = 64, 128, 4096
+    x64, xb = rand_bf16((B, Kin), g)
+    w64, wb = rand_bf16((Kin, Nout), g, 0.05)
+    geom = K.make_geom(B, 1, 1, Kin, 1, 1, Nout, 1, 1)
+    bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev).reshape(1, 1, Kin, Nout))
+    y = K.gconv(geom, xb.to(dev), bt_f, out_f32=True)
+    assert_close_f32(y, x64 @ w64, "linear fwd")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(27, 128), (1152, 128), (128, 1), (148, 1536), (2304, 96)])
+def test_spectral_norm(K, dev, mode, shape):
+    g = _gen(5)
+    Kd, Co = shape
+    w = torch.randn(shape, generator=g, dtype=torch.float32) * 0.05
+    u0 = torch.randn((Kd, 1) if mode == 0 else (1, Co), generator=g, dtype=torch.float32)
+    vs = oops.VarStore(dtype=torch.float64)
+    vs.vars["w/u_var"] = u0.to(torch.float64).clone()
+    wr = w.to(torch.float64).clone().requires_grad_(True)
+    wbar = oops.spectral_norm(vs, wr, "w", 1e-12, "left" if mode == 0 else "right")
+    u_d = u0.reshape(-1).to(dev).clone()
+    v, sigma, inv_sigma = K.spectral_norm(w.to(dev), u_d, mode)
+    assert_close_f32(u_d, vs.vars["w/u_var"].reshape(-1), "u'", rtol=1e-4, abs_rms=1e-4)
+    sig_ref = (w.to(torch.float64) / wbar.detach()).mean()
+    assert abs(float(sigma) - float(sig_ref)) <= 2e-5 * abs(float(sig_ref)), (float(sigma), float(sig_ref))
+    wbar_d = K.scale_f32(w.to(dev), inv_sigma)
+    assert_close_f32(wbar_d, wbar.detach(), "w_bar", rtol=1e-4, abs_rms=1e-5)
+    # backward through w/sigma with u, v constant
+    dwbar = torch.randn(shape, generator=g, dtype=torch.float32)
+    (wbar * dwbar.to(torch.float64)).sum().backward()
+    a_k, b_co = (u_d, v) if mode == 0 else (v, u_d)
+    dw = K.sn_backward(dwbar.to(dev), w.to(dev), a_k, b_co, sigma)
+    assert_close_f32(dw, wr.grad, "sn backward", rtol=2e-4, abs_rms=2e-4)
+
+
+def test_batch_norm_golden(K, dev):
+    """The reference's own golden vector (architectures/arch_ops_test.py:32-61), eps = 1e-3."""
+    x = torch.tensor([[[[5, 7, 2]], [[5, 8, 8]]], [[[1, 2, 0]], [[4, 0, 4]]],
+                      [[[6, 2, 6]], [[5, 0, 5]]], [[[2, 4, 2]], [[6, 4, 1]]]], dtype=torch.float32)
+    expected = np.asarray(
+        [[[[0.4375205, 1.30336881, -0.58830315]], [[0.4375205, 1.66291881, 1.76490951]]],
+         [[[-1.89592218, -0.49438119, -1.37270737]], [[-0.14584017, -1.21348119, 0.19610107]]],
+         [[[1.02088118, -0.49438119, 0.98050523]], [[0.4375205, -1.21348119, 0.58830321]]],
+         [[[-1.31256151, 0.22471881, -0.58830315]], [[1.02088118, 0.22471881, -0.98050523]]]],
+        dtype=np.float32)
+    x3 = x.reshape(4, 2, 3).to(BF16).to(dev)  # small integers are exact in bf16
+    mean, var = K.bn_stats(x3)
+    y = K.bn_apply(x3, mean, var, 1e-3)
+    assert_close_bf16(y, torch.from_numpy(expected).to(torch.float64).reshape(4, 2, 3),
+                      "BN golden", ulps=2.0, abs_rms=2.0 ** -9)
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("shape", [(8, 16, 256), (32, 1, 1024), (4, 64, 24)])
+def test_batch_norm_fwd_bwd(K, dev, per_sample, shape):
+    g = _gen(9)
+    N, HW, C = shape
+    eps = 1e-5
+    x64, xb = rand_bf16(shape, g)
+    x64 = x64 * 1.5 + 0.3
+    xb = x64.to(torch.float32).to(BF16)
+    x64 = xb.to(torch.float64)
+    pshape = (N, C) if per_sample else (C,)
+    gamma = torch.randn(pshape, generator=g, dtype=torch.float32) * 0.5 + 1.0
+    beta = torch.randn(pshape, generator=g, dtype=torch.float32) * 0.2
+    xr = x64.clone().requires_grad_(True)
+    gr = gamma.to(torch.float64).requires_grad_(True)
+    br = beta.to(torch.float64).requires_grad_(True)
+    mean_r = xr.mean(dim=(0, 1))
+    var_r = (xr * xr).mean(dim=(0, 1)) - mean_r ** 2
+    xhat = (xr - mean_r) * torch.rsqrt(var_r + eps)
+    gg = gr.reshape(N, 1, C) if per_sample else gr
+    bb = br.reshape(N, 1, C) if per_sample else br
+    ref = torch.relu(xhat * gg + bb)
+    xd = xb.to(dev)
+    mean, var = K.bn_stats(xd)
+    assert_close_f32(mean, mean_r.detach(), "bn mean", rtol=1e-5, abs_rms=1e-5)
+    assert_close_f32(var, var_r.detach(), "bn var", rtol=1e-4, abs_rms=1e-4)
+    y = K.bn_apply(xd, mean, var, eps, gamma.to(dev), beta.to(dev), per_sample, relu=True)
+    assert_close_bf16(y, ref.detach(), "bn apply")
+    dy64, dyb = rand_bf16(shape, g)
+    (ref * dy64).sum().backward()
+    dx, dgam, dbet = K.bn_backward(xd, y, dyb.to(dev), mean, var, eps, gamma.to(dev), per_sample,
+                                   relu=True, batch_stats=True)
+    # y's relu mask is taken from the bf16-rounded y: identical sign pattern except exact zeros
+    assert_close_bf16(dx, xr.grad, "bn dx", ulps=4.0, abs_rms=2.0 ** -6)
+    assert_close_f32(dgam, gr.grad, "bn dgamma", rtol=2e-3, abs_rms=2e-3)
+    assert_close_f32(dbet, br.grad, "bn dbeta", rtol=2e-3, abs_rms=2e-3)
+
+
+def test_bn_moving_average(K, dev):
+    mm = torch.zeros(8, device=dev)
+    mv = torch.ones(8, device=dev)
+    mean = torch.arange(8, dtype=torch.float32, device=dev)
+    var = torch.full((8,), 3.0, device=dev)
+    K.bn_update_moving(mm, mv, mean, var, 0.9)
+    torch.testing.assert_close(mm.cpu(), 0.1 * torch.arange(8, dtype=torch.float32), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(mv.cpu(), torch.full((8,), 1.2), rtol=1e-6, atol=1e-7)
+
+
+def test_elementwise_and_pooling(K, dev):
+    g = _gen(13)
+    x64, xb = rand_bf16((2, 8, 8, 24), g)
+    d64, db = rand_bf16((2, 8, 8, 24), g)
+    xd = xb.to(dev)
+    assert_close_bf16(K.lrelu(xd, 0.2), oops.lrelu(x64, 0.2), "lrelu")
+    assert_close_bf16(K.lrelu_bwd(xd, db.to(dev), 0.1),
+                      torch.where(x64 > 0, d64, 0.1 * d64), "lrelu bwd")
+    assert_close_bf16(K.axpby(xd, 0.5, db.to(dev), 2.0), 0.5 * x64 + 2.0 * d64, "axpby")
+    assert_close_bf16(K.avgpool2(xd), oops.avg_pool2(x64), "avgpool")
+    assert_close_bf16(K.maxpool2(xd), oops.max_pool2(x64), "maxpool")
+    p64, pb = rand_bf16((2, 4, 4, 24), g)
+    xr = x64.clone().requires_grad_(True)
+    (oops.avg_pool2(xr) * p64).sum().backward()
+    assert_close_bf16(K.avgpool2_bwd(pb.to(dev)), xr.grad, "avgpool bwd")
+    xr = x64.clone().requires_grad_(True)
+    (oops.max_pool2(xr) * p64).sum().backward()
+    assert_close_bf16(K.maxpool2_bwd(xd, pb.to(dev)), xr.grad, "maxpool bwd")
+    # odd channel count takes the scalar path
+    y64, yb = rand_bf16((1, 4, 4, 3), g)
+    assert_close_bf16(K.avgpool2(yb.to(dev)), oops.avg_pool2(y64), "avgpool c=3")
+
+
+def test_spatial_reduce_heads_rowdot(K, dev):
+    g = _gen(17)
+    x64, xb = rand_bf16((4, 8, 8, 128), g)
+    xd = xb.to(dev)
+    ref = torch.relu(x64).mean(dim=(1, 2))
+    assert_close_bf16(K.spatial_reduce(xd, xd, 1.0 / 64), ref, "relu+mean")
+    assert_close_bf16(K.spatial_reduce(xd, None, 1.0), x64.sum(dim=(1, 2)), "sum", abs_rms=2.0 ** -7)
+    d64, db = rand_bf16((4, 128), g)
+    xr = x64.clone().requires_grad_(True)
+    (torch.relu(xr).mean(dim=(1, 2)) * d64).sum().backward()
+    assert_close_bf16(K.spatial_reduce_bwd(xd, db.to(dev), (4, 8, 8, 128), 1.0 / 64), xr.grad,
+                      "relu+mean bwd")
+    # heads
+    h = torch.randn((2, 4, 4, 3), generator=g, dtype=torch.float32)
+    for kind, fn in ((0, torch.sigmoid), (1, lambda t: (torch.tanh(t) + 1.0) / 2.0)):
+        hr = h.to(torch.float64).requires_grad_(True)
+        out = fn(hr)
+        yd = K.head(h.to(dev), kind)
+        assert_close_f32(yd, out.detach(), "head %d" % kind, rtol=1e-5, abs_rms=1e-6)
+        dyh = torch.randn(h.shape, generator=g, dtype=torch.float32)
+        (out * dyh.to(torch.float64)).sum().backward()
+        assert_close_bf16(K.head_bwd(yd, kind, dyh.to(dev)), hr.grad, "head bwd %d" % kind)
+    # rowdot / one-hot / casts / colsum
+    a64, ab = rand_bf16((16, 96), g)
+    b64, bb = rand_bf16((16, 96), g)
+    assert_close_f32(K.rowdot(ab.to(dev), bb.to(dev)), (a64 * b64).sum(1, keepdim=True), "rowdot")
+    do = torch.randn((16, 1), generator=g, dtype=torch.float32)
+    da, dbb = K.rowdot_bwd(ab.to(dev), bb.to(dev), do.to(dev))
+    assert_close_bf16(da, do.to(torch.float64) * b64, "rowdot da")
+    assert_close_bf16(dbb, do.to(torch.float64) * a64, "rowdot db")
+    labels = torch.tensor([1, 0, 9, 3], dtype=torch.int32)
+    oh = K.one_hot(labels.to(dev), 10).cpu().to(torch.float32)
+    assert torch.equal(oh, F.one_hot(labels.long(), 10).float())
+    f = torch.randn(1000, generator=g, dtype=torch.float32)
+    assert torch.equal(K.cast_f32_to_bf16(f.to(dev)).cpu(), f.to(BF16))
+    assert torch.equal(K.cast_bf16_to_f32(f.to(BF16).to(dev)).cpu(), f.to(BF16).to(torch.float32))
+    assert torch.equal(K.cast_f32_to_bf16(f.to(dev), 2.0, -1.0).cpu(), (f * 2.0 - 1.0).to(BF16))
+    c64, cb = rand_bf16((1000, 40), g)
+    assert_close_f32(K.colsum(cb.to(dev)), c64.sum(0), "colsum", rtol=1e-5, abs_rms=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["non_saturating", "wasserstein", "least_squares", "hinge"])
+def test_gan_losses(K, dev, kind):
+    g = _gen(19)
+    B = 48
+    logits = torch.randn((2 * B, 1), generator=g, dtype=torch.float32) * 2
+    lr = logits.to(torch.float64).requires_grad_(True)
+    real, fake = lr[:B], lr[B:]
+    d_loss, d_real, d_fake, g_loss = ogan.get_losses(kind, torch.sigmoid(real), torch.sigmoid(fake),
+                                                     real, fake)
+    losses, dd, dg = K.gan_loss(K.LOSS_KINDS[kind], logits.to(dev))
+    ref = torch.stack([d_loss, d_real, d_fake, g_loss]).detach()
+    assert_close_f32(losses, ref, kind + " losses", rtol=1e-5, abs_rms=1e-6)
+    gd, = torch.autograd.grad(d_loss, lr, retain_graph=True)
+    gg, = torch.autograd.grad(g_loss, lr)
+    assert_close_f32(dd, gd.reshape(-1), kind + " d grads", rtol=1e-5, abs_rms=1e-6)
+    assert_close_f32(dg, gg.reshape(-1), kind + " g grads", rtol=1e-5, abs_rms=1e-6)
+
+
+def test_gradient_penalty(K, dev):
+    g = _gen(23)
+    B, per = 8, 3 * 16 * 16
+    gr = (torch.randn((B, per), generator=g, dtype=torch.float32) * 0.05)
+    g64 = gr.to(torch.float64).requires_grad_(True)
+    slopes = torch.sqrt(0.0001 + (g64 ** 2).sum(1))
+    pen = ((slopes - 1.0) ** 2).mean()
+    sl, p = K.gradient_penalty(gr.to(dev))
+    assert_close_f32(sl, slopes.detach(), "slopes", rtol=1e-5, abs_rms=1e-6)
+    assert abs(float(p) - float(pen)) < 1e-5 * abs(float(pen))
+    (10.0 * pen).backward()
+    up = torch.tensor([10.0], device=dev)
+    assert_close_bf16(K.gradient_penalty_bwd(gr.to(dev), sl, up), g64.grad, "gp bwd")
+    x = torch.rand((B, 4, 4, 3), generator=g)
+    xf = torch.rand((B, 4, 4, 3), generator=g)
+    al = torch.rand((B,), generator=g)
+    ref = x.double() + al.double().reshape(B, 1, 1, 1) * (xf.double() - x.double())
+    assert_close_bf16(K.interpolate(x.to(dev), xf.to(dev), al.to(dev)), ref, "interpolate")
+
+
+def test_adam_ema_multi(K, dev):
+    g = _gen(29)
+    shapes = [(3, 3, 16, 32), (32,), (100000,), (7,)]
+    params = [torch.randn(s, generator=g, dtype=torch.float32) for s in shapes]
+    p64 = [p.to(torch.float64).clone() for p in params]
+    opt = ogan.TFAdam(p64, lr=2e-4, beta1=0.5, beta2=0.999)
+    shadow64 = [p.clone() for p in p64]
+    pd = [p.to(dev).clone() for p in params]
+    gd = [torch.zeros_like(p) for p in pd]
+    md = [torch.zeros_like(p) for p in pd]
+    vd = [torch.zeros_like(p) for p in pd]
+    ed = [p.clone() for p in pd]
+    table = K.AdamTable(pd, gd, md, vd, ed)
+    step = torch.zeros((), dtype=torch.int64, device=dev)
+    for it in range(3):
+        grads = [torch.randn(s, generator=g, dtype=torch.float32) for s in shapes]
+        for gdst, gsrc in zip(gd, grads):
+            gdst.copy_(gsrc)
+        decay = 0.9 if it >= 1 else 0.0
+        table.adam(2e-4, 0.5, 0.999, 1e-8, 1.0, step, ema_decay=0.9, ema_start=1)
+        K.counter_add(step, 1)
+        opt.step([gg.to(torch.float64) for gg in grads])
+        ogan.ema_update(shadow64, p64, decay)
+    assert int(step.item()) == 3
+    for i in range(len(shapes)):
+        assert_close_f32(pd[i], p64[i], "adam param %d" % i, rtol=1e-5, abs_rms=1e-6)
+        assert_close_f32(ed[i], shadow64[i], "ema %d" % i, rtol=1e-5, abs_rms=1e-6)
+    # gather / scatter of the gradient bucket
+    flat = torch.empty(table.total_elems, device=dev)
+    table.gather(flat)
+    ref = torch.cat([t.reshape(-1) for t in gd])
+    assert torch.equal(flat, ref)
+    flat.mul_(0.5)
+    table.scatter(flat)
+    assert torch.equal(torch.cat([t.reshape(-1) for t in gd]), ref * 0.5)
+
+
+def test_rng_matches_oracle_bitstream(K, dev):
+    step = torch.tensor(5, dtype=torch.int64, device=dev)
+    u = K.random(0, -1.0, 1.0, 547, 3, 1, step, (1001,), dev).cpu().numpy()
+    ref = orng.uniform(1001, -1.0, 1.0, 547, 3, 1, 5)
+    assert np.array_equal(u, ref)
+    n = K.random(1, 0.0, 1.0, 42, 7, 0, None, (64, 120), dev).cpu().numpy().reshape(-1)
+    refn = orng.normal(64 * 120, 0.0, 1.0, 42, 7, 0, 0)
+    np.testing.assert_allclose(n, refn, rtol=2e-5, atol=2e-6)
+    assert abs(n.mean()) < 0.05 and abs(n.std() - 1.0) < 0.05
+    lab = K.random_labels(1000, 9, 2, 3, step, 4097, dev).cpu().numpy()
+    assert np.array_equal(lab, orng.labels(4097, 1000, 9, 2, 3, 5))
+    # semantics of tpu_random_test.py: same (op, step) -> same; other step / replica -> different
+    u2 = K.random(0, -1.0, 1.0, 547, 3, 1, step, (1001,), dev).cpu().numpy()
+    assert np.array_equal(u, u2)
+    step2 = torch.tensor(6, dtype=torch.int64, device=dev)
+    assert not np.array_equal(u, K.random(0, -1.0, 1.0, 547, 3, 1, step2, (1001,), dev).cpu().numpy())
+    assert not np.array_equal(u, K.random(0, -1.0, 1.0, 547, 3, 2, step, (1001,), dev).cpu().numpy())
+
+
+@pytest.mark.parametrize("dims", [(2, 256, 64, 12, 48), (1, 1024, 256, 24, 96)])
+def test_attention(K, dev, dims):
+    B, Lq, Lk, Dk, Dv = dims
+    g = _gen(31)
+    t64, tb = rand_bf16((B, Lq, Dk), g, 0.5)
+    p64, pb = rand_bf16((B, Lk, Dk), g, 0.5)
+    g64, gb = rand_bf16((B, Lk, Dv), g)
+    tr, pr, gr = [t.clone().requires_grad_(True) for t in (t64, p64, g64)]
+    ref = torch.softmax(tr @ pr.transpose(1, 2), dim=-1) @ gr
+    out, lse = K.attention_fwd(tb.to(dev), pb.to(dev), gb.to(dev))
+    assert_close_bf16(out, ref.detach(), "attention fwd", ulps=3.0)
+    do64, dob = rand_bf16((B, Lq, Dv), g)
+    (ref * do64).sum().backward()
+    dt, dp, dg = K.attention_bwd(tb.to(dev), pb.to(dev), gb.to(dev), out, lse, dob.to(dev))
+    # ds = p * (dp - delta) cancels to ~1e-2 of its operands and delta is formed from the
+    # bf16-rounded `out` (as in every flash-style backward) -> 2^-5 * rms absolute slack
+    assert_close_bf16(dt, tr.grad, "dtheta", ulps=4.0, abs_rms=2.0 ** -5)
+    assert_close_bf16(dp, pr.grad, "dphi", ulps=4.0, abs_rms=2.0 ** -5)
+    assert_close_bf16(dg, gr.grad, "dg", ulps=4.0, abs_rms=2.0 ** -6)
+
+
+def test_fid_statistics(K, dev):
+    rng = np.random.RandomState(0)
+    x = rng.randn(500, 96).astype(np.float32) * rng.rand(96).astype(np.float32) + 1.0
+    mean, cov = K.mean_cov_f64(torch.from_numpy(x).to(dev))
+    m_ref, c_ref = ofid.mean_cov(x)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cov.cpu().numpy(), c_ref, rtol=1e-10, atol=1e-12)
+    a = rng.randn(70, 50)
+    b = rng.randn(50, 33)
+    c = K.gemm_f64(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(c, a @ b, rtol=1e-12, atol=1e-12)
+    c2 = K.gemm_f64(torch.from_numpy(a.T.copy()).to(dev), torch.from_numpy(b.T.copy()).to(dev),
+                    ta=True, tb=True).cpu().numpy()
+    np.testing.assert_allclose(c2, a @ b, rtol=1e-12, atol=1e-12)
+    # eigen-decomposition of a PSD matrix (rank-deficient like a covariance with n < d)
+    s = c_ref.copy()
+    w, v = K.syevj_f64(torch.from_numpy(s.copy()).to(dev))
+    w, v = w.cpu().numpy(), v.cpu().numpy()
+    np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(s), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(v.T @ np.diag(w) @ v, s, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(v @ v.T, np.eye(96), atol=1e-10)
+    logits = rng.randn(300, 1008).astype(np.float32) * 3
+    sc = K.inception_score_f64(torch.from_numpy(logits).to(dev))
+    assert abs(float(sc) - ofid.classifier_score_from_logits(logits)) < 1e-9 * float(sc)
+
+
+def test_inception_preprocess_and_pool(K, dev):
+    rng = np.random.RandomState(1)
+    img = (rng.rand(2, 32, 32, 3) * 255).astype(np.float32)
+    ref = ofid.inception_preprocess(img, 299)
+    y = K.inception_preprocess(torch.from_numpy(img).to(dev))
+    assert_close_bf16(y, torch.from_numpy(ref), "inception preprocess", ulps=2.0, abs_rms=2.0 ** -9)
+    g = _gen(37)
+    x64, xb = rand_bf16((2, 9, 9, 16), g)
+    ref_max = F.max_pool2d(x64.permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
+    assert_close_bf16(K.pool2d(xb.to(dev), 3, 2, 0, 0, 4, 4), ref_max, "maxpool 3x3/2 valid")
+    ref_avg = F.avg_pool2d(x64.permute(0, 3, 1, 2), 3, 1, 1, count_include_pad=False).permute(0, 2, 3, 1)
+    assert_close_bf16(K.pool2d(xb.to(dev), 3, 1, 1, 1, 9, 9), ref_avg, "avgpool 3x3/1 same")
+
+
+def test_error_codes(K, dev):
+    from compare_gan_amd.hip._lib import CgamdError
+    x = torch.zeros((1, 4, 4, 8), dtype=BF16, device=dev)
+    with pytest.raises(ValueError):
+        K.gconv(K.make_geom(1, 4, 4, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1), x.cpu(), x)
+    geom = K.make_geom(1, 4, 4, 8, 4, 4, 8, 3, 3, 1, 3, 1, 1)  # U=3 is not a power of two
+    bt = torch.zeros((8, 72), dtype=BF16, device=dev)
+    with pytest.raises(CgamdError):
+        K.gconv(geom, x, bt)
+    with pytest.raises(CgamdError):
+        K.avgpool2(torch.zeros((1, 3, 4, 8), dtype=BF16, device=dev))
