@@ -1,0 +1,534 @@
+"""Layer ops of the G/D graphs on the HIP kernels -- the product-side mirror of the reference's
+compare_gan/architectures/arch_ops.py (same function names, argument meaning, gin configurables
+and error behaviour; cited per function).
+
+Variables live in a `VariableStore` that plays the role of TF's variable scopes: created on first
+use, in call order, under the reference's names, then reused.  Every op runs a
+hand-written HIP kernel through compare_gan_amd.hip; a tensor on the "meta" device only builds the
+graph (variables, shapes) -- there is no CPU arithmetic path.
+
+Fusion device: `Act(x, slope)` is a *pending* leaky-ReLU.  Convolutions, linear layers and the
+spatial reductions consume it as an input gate of their kernel instead of materialising act(x).
+"""
+import contextlib
+import math
+
+import torch
+
+from compare_gan_amd import gin
+from compare_gan_amd.gans import consts
+from compare_gan_amd.hip import functional as Fn
+from compare_gan_amd.hip import kernels as K
+from compare_gan_amd.tpu import tpu_ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# variables
+# ------------------------------------------------------------------------------------------------
+class VariableStore(object):
+  """name -> fp32 device tensor; the checkpoint naming contract of SURVEY.md App. D."""
+
+  def __init__(self, device, seed=0):
+    self.device = torch.device(device)
+    self.seed = seed
+    self.vars = {}            # insertion-ordered
+    self.trainable = set()
+    self.initializers = {}    # name -> kind (for the initializer tests)
+    self._gen = torch.Generator().manual_seed(seed)
+    self._scope = []
+
+  # -- scopes --
+  @contextlib.contextmanager
+  def scope(self, name):
+    self._scope.append(name)
+    try:
+      yield
+    finally:
+      self._scope.pop()
+
+  def full_name(self, name):
+    return "/".join(self._scope + [name]) if name else "/".join(self._scope)
+
+  # -- access --
+  def get(self, name, shape, initializer, trainable=True, dtype=F32):
+    full = self.full_name(name)
+    if full not in self.vars:
+      kind, fn = initializer
+      if self.device.type == "meta":
+        t = torch.empty(tuple(shape), dtype=dtype, device="meta")
+      else:
+        t = fn(tuple(shape), self._gen).to(dtype).to(self.device)
+      if trainable:
+        t.requires_grad_(True)
+        self.trainable.add(full)
+      self.vars[full] = t
+      self.initializers[full] = kind
+    v = self.vars[full]
+    if tuple(v.shape) != tuple(shape):
+      raise ValueError("Variable %s has shape %s but %s was requested." % (
+          full, tuple(v.shape), tuple(shape)))
+    return v
+
+  def trainable_variables(self, scope_substr=None):
+    """abstract_arch.py:43-45: trainable variables whose name contains the module name."""
+    return [(n, v) for n, v in self.vars.items()
+            if n in self.trainable and (scope_substr is None or scope_substr in n)]
+
+  def global_variables(self):
+    return list(self.vars.items())
+
+  def state_dict(self):
+    return {n: v.detach() for n, v in self.vars.items()}
+
+  def load_state_dict(self, sd, strict=True):
+    with torch.no_grad():
+      for n, v in sd.items():
+        if n in self.vars:
+          self.vars[n].copy_(v.to(self.vars[n].dtype))
+        elif strict:
+          raise KeyError("unexpected variable %s" % n)
+
+
+_STORE = [None]
+
+
+@contextlib.contextmanager
+def use_store(store):
+  old = _STORE[0]
+  _STORE[0] = store
+  try:
+    yield store
+  finally:
+    _STORE[0] = old
+
+
+def current_store():
+  if _STORE[0] is None:
+    raise RuntimeError("No VariableStore is active (wrap the call in arch_ops.use_store(...)).")
+  return _STORE[0]
+
+
+def variable_scope(name):
+  return current_store().scope(name)
+
+
+def get_variable(name, shape, initializer, trainable=True, dtype=F32):
+  return current_store().get(name, shape, initializer, trainable, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# initialisers (arch_ops.py:46-63)
+# ------------------------------------------------------------------------------------------------
+def _normal(stddev):
+  return ("random_normal", lambda s, g: torch.randn(s, generator=g, dtype=torch.float32) * stddev)
+
+
+def _truncated(stddev):
+  def fn(s, g):
+    t = torch.randn(s, generator=g, dtype=torch.float32)
+    bad = t.abs() > 2
+    while bool(bad.any()):
+      t[bad] = torch.randn(int(bad.sum()), generator=g, dtype=torch.float32)
+      bad = t.abs() > 2
+    return t * stddev
+  return ("truncated_normal", fn)
+
+
+def _orthogonal():
+  def fn(s, g):
+    rows = 1
+    for d in s[:-1]:
+      rows *= d
+    cols = s[-1]
+    a = torch.randn((max(rows, cols), min(rows, cols)), generator=g, dtype=torch.float64)
+    q, r = torch.linalg.qr(a)
+    q = q * torch.sign(torch.diagonal(r))
+    if rows < cols:
+      q = q.t()
+    return q.reshape(s).to(torch.float32)
+  return ("orthogonal", fn)
+
+
+def glorot_normal():
+  def fn(s, g):
+    sd = math.sqrt(2.0 / (s[0] + s[1])) / 0.87962566103423978
+    return torch.randn(s, generator=g, dtype=torch.float32).clamp_(-2, 2) * sd
+  return ("glorot_normal", fn)
+
+
+def constant(value):
+  kind = "zeros" if value == 0 else ("ones" if value == 1 else "constant")
+  return (kind, lambda s, g: torch.full(s, float(value), dtype=torch.float32))
+
+
+@gin.configurable("weights")
+def weight_initializer(initializer=consts.NORMAL_INIT, stddev=0.02):
+  """Returns the (kind, fn) initializer for the given name (arch_ops.py:46-63)."""
+  if initializer == consts.NORMAL_INIT:
+    return _normal(stddev)
+  if initializer == consts.TRUNCATED_INIT:
+    return _truncated(stddev)
+  if initializer == consts.ORTHOGONAL_INIT:
+    return _orthogonal()
+  raise ValueError("Unknown weight initializer {}.".format(initializer))
+
+
+# ------------------------------------------------------------------------------------------------
+# pending activations
+# ------------------------------------------------------------------------------------------------
+class Act(object):
+  """x with a not-yet-applied leaky-ReLU of `slope` (0 = ReLU)."""
+
+  def __init__(self, x, slope):
+    self.x, self.slope = x, float(slope)
+
+  @property
+  def shape(self):
+    return self.x.shape
+
+  def materialize(self):
+    if self.x.is_meta:
+      return self.x
+    return Fn.LreluFn.apply(self.x, self.slope)
+
+
+def _split_act(inputs):
+  if isinstance(inputs, Act):
+    return inputs.x, inputs.slope
+  return inputs, None
+
+
+def relu(x):
+  """tf.nn.relu as a pending activation (resnet_ops.py:165,175)."""
+  return Act(x, 0.0)
+
+
+def lrelu(inputs, leak=0.2, name="lrelu"):
+  """Leaky-ReLU as a pending activation (arch_ops.py:595-597)."""
+  del name
+  return Act(inputs, leak)
+
+
+def as_tensor(x):
+  return x.materialize() if isinstance(x, Act) else x
+
+
+def _to_bf16(x):
+  """fp32 host-side inputs (z, one-hot y products) enter the bf16 domain through a cast kernel."""
+  if x.dtype == BF16:
+    return x
+  if x.is_meta:
+    return torch.empty(x.shape, dtype=BF16, device="meta")
+  return Fn.CastFn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral norm (arch_ops.py:453-535)
+# ------------------------------------------------------------------------------------------------
+@gin.configurable(blacklist=["inputs", "var_name", "build_only"])
+def spectral_norm(inputs, epsilon=1e-12, singular_value="left", var_name=None, build_only=False):
+  """Performs Spectral Normalization on a weight tensor; one power-iteration round per call, the
+  persisted vector "<weight>/u_var" is updated in place.  `var_name` is the weight's variable name
+  relative to the current scope (TF derives it from inputs.name, arch_ops.py:487-488)."""
+  if inputs.dim() < 2:
+    raise ValueError("Spectral norm can only be applied to multi-dimensional tensors")
+  k, co = inputs.numel() // inputs.shape[-1], inputs.shape[-1]
+  if singular_value == "auto":
+    singular_value = "left" if k <= co else "right"
+  if singular_value not in ("left", "right"):
+    raise ValueError("Unknown singular_value {}.".format(singular_value))
+  mode = 0 if singular_value == "left" else 1
+  u_shape = (k, 1) if mode == 0 else (1, co)
+  u_var = get_variable((var_name or "kernel") + "/u_var", u_shape, _normal(1.0), trainable=False)
+  if inputs.is_meta or build_only:
+    return inputs   # graph construction only: variables exist, no power iteration is run
+  return Fn.spectral_norm(inputs, u_var, mode, epsilon)
+
+
+# ------------------------------------------------------------------------------------------------
+# linear / conv2d / deconv2d (arch_ops.py:538-592)
+# ------------------------------------------------------------------------------------------------
+def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32):
+  spec = Fn.ConvSpec(spec_geom, transpose=transpose, slope_in=slope, out_f32=out_f32)
+  if x.is_meta:
+    return torch.empty(spec.out_shape, dtype=F32 if out_f32 else BF16, device="meta")
+  gate = x.detach() if slope is not None else None
+  return Fn.gconv(x, w, bias, residual, gate, None, spec, dx_f32)
+
+
+def linear(inputs, output_size, scope=None, stddev=0.02, bias_start=0.0, use_sn=False,
+           use_bias=True, out_f32=False, kernel_initializer=None):
+  """Linear layer without the non-linear activation applied (arch_ops.py:538-556).
+  inputs [B, K] (bf16, fp32 or a pending Act) -> [B, output_size] bf16 (fp32 if out_f32)."""
+  x, slope = _split_act(inputs)
+  if x.dim() != 2:
+    raise ValueError("linear expects rank-2 inputs, got rank %d" % x.dim())
+  x = _to_bf16(x)
+  b, k = x.shape
+  with variable_scope(scope or "linear"):
+    kernel = get_variable("kernel", [k, output_size],
+                          kernel_initializer or weight_initializer(stddev=stddev))
+    if use_sn:
+      kernel = spectral_norm(kernel, build_only=x.is_meta)
+    bias = get_variable("bias", [output_size], constant(bias_start)) if use_bias else None
+    geom = K.make_geom(b, 1, 1, k, 1, 1, output_size, 1, 1)
+    w4 = kernel.reshape(1, 1, k, output_size)
+    out = _conv_call(x.reshape(b, 1, 1, k), slope, w4, bias, geom, False, None, out_f32, False)
+    return out.reshape(b, output_size)
+
+
+def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", use_sn=False,
+           use_bias=True, upsample=False, residual=None, out_f32=False, dx_f32=False):
+  """2-D convolution, TF 'SAME' padding (arch_ops.py:559-573).
+
+  Extensions that keep the reference semantics but fuse its neighbours into the kernel:
+  `inputs` may be a pending Act (input gate), `upsample=True` convolves the zero-inserted input of
+  resnet_ops.unpool (resnet_ops.py:35-56,122-123) without materialising it, `residual` is added in
+  the epilogue (resnet_ops.py:181)."""
+  x, slope = _split_act(inputs)
+  if x.dim() != 4:
+    raise ValueError("conv2d expects NHWC inputs of rank 4, got rank %d" % x.dim())
+  if d_h != d_w:
+    raise ValueError("conv2d: only equal strides are supported (got %d, %d)" % (d_h, d_w))
+  n, h, w_, ci = x.shape
+  with variable_scope(name):
+    w = get_variable("kernel", [k_h, k_w, ci, output_dim], weight_initializer(stddev=stddev))
+    if use_sn:
+      w = spectral_norm(w, build_only=x.is_meta)
+    bias = get_variable("bias", [output_dim], constant(0.0)) if use_bias else None
+    geom = K.geom_conv_same(n, h, w_, ci, output_dim, k_h, k_w, d_h, 2 if upsample else 1)
+    # gradients w.r.t. image-like inputs (the network input) are kept in fp32: they feed the
+    # gradient penalty's norm (penalty_lib.py:77-78) and the generator's output head
+    return _conv_call(x, slope, w, bias, geom, False, residual, out_f32, dx_f32 or ci <= 4)
+
+
+def conv1x1(inputs, output_dim, **kwargs):
+  return conv2d(inputs, output_dim, k_h=1, k_w=1, d_h=1, d_w=1, **kwargs)
+
+
+def deconv2d(inputs, output_shape, k_h, k_w, d_h, d_w, stddev=0.02, name="deconv2d",
+             use_sn=False, out_f32=False):
+  """Transposed 2-D convolution, TF conv2d_transpose 'SAME' (arch_ops.py:579-592); kernel layout
+  [k_h, k_w, C_out, C_in]."""
+  x, slope = _split_act(inputs)
+  if d_h != d_w:
+    raise ValueError("deconv2d: only equal strides are supported")
+  n, h, w_, ci = x.shape
+  _, ho, wo, co = output_shape
+  with variable_scope(name):
+    w = get_variable("kernel", [k_h, k_w, co, ci], weight_initializer(stddev=stddev))
+    if use_sn:
+      w = spectral_norm(w, build_only=x.is_meta)
+    bias = get_variable("bias", [co], constant(0.0))
+    # forward conv F: [n,ho,wo,co] -> [n,h,w,ci]; the deconvolution is its adjoint
+    geom = K.geom_conv_same(n, ho, wo, co, ci, k_h, k_w, d_h, 1)
+    if (geom.Ho, geom.Wo) != (h, w_):
+      raise ValueError("deconv2d: output_shape %s is inconsistent with input %s at stride %d" % (
+          list(output_shape), list(x.shape), d_h))
+    return _conv_call(x, slope, w, bias, geom, True, None, out_f32, False)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm family (arch_ops.py:66-445)
+# ------------------------------------------------------------------------------------------------
+def _moments_for_inference(mean, variance, is_training, decay, use_moving_averages, num_channels):
+  """Returns (mean, var) to normalise with; creates / updates the inference statistics.
+
+  arch_ops.py:66-119 (moving averages, zero_debias=False) and :122-191 (accumulators)."""
+  c = [num_channels]
+  if use_moving_averages:
+    mm = get_variable("moving_mean", c, constant(0.0), trainable=False)
+    mv = get_variable("moving_variance", c, constant(1.0), trainable=False)
+    if is_training:
+      if mean is not None:
+        K.bn_update_moving(mm, mv, mean, variance, decay)
+      return None, None
+    return mm, mv
+  with variable_scope("accu"):
+    accu_mean = get_variable("accu_mean", c, constant(0.0), trainable=False)
+    accu_var = get_variable("accu_variance", c, constant(0.0), trainable=False)
+    accu_counter = get_variable("accu_counter", [], constant(1e-12), trainable=False)
+    update_accus = get_variable("update_accus", [], constant(0), trainable=False,
+                                dtype=torch.int32)
+  if is_training:
+    return None, None
+  return accu_mean, accu_var, accu_counter, update_accus
+
+
+@gin.configurable(whitelist=["decay", "epsilon", "use_cross_replica_mean", "use_moving_averages"])
+def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_format="NHWC",
+                      use_moving_averages=True, use_cross_replica_mean=None,
+                      gamma=None, beta=None, per_sample=False, relu=False):
+  """(x - mean) * rsqrt(var + eps) [* gamma + beta] [relu]  (arch_ops.py:194-319).
+
+  The optional affine / activation arguments fuse the reference's follow-up ops
+  (arch_ops.py:353-366,436-444; resnet_ops.py:165,175) into the same HIP kernel."""
+  if data_format not in {"NCHW", "NHWC"}:
+    raise ValueError("Invalid data_format {}. Allowed: NCHW, NHWC.".format(data_format))
+  if data_format != "NHWC":
+    raise ValueError("Only NHWC is supported by the HIP kernels.")
+  inputs = as_tensor(inputs)
+  if inputs.dim() not in (2, 4):
+    raise ValueError("Inputs has unsupported rank. Expected 2 or 4 but got %d" % inputs.dim())
+  if use_cross_replica_mean is None:
+    use_cross_replica_mean = tpu_ops.in_replica_context()   # arch_ops.py:258-263
+  num_channels = inputs.shape[-1]
+  sync_fn = tpu_ops.SyncMoments() if use_cross_replica_mean else None
+  if inputs.is_meta:
+    _moments_for_inference(None, None, is_training, decay, use_moving_averages, num_channels)
+    return inputs
+  inputs = _to_bf16(inputs)
+  if is_training:
+    out, mean, var = Fn.batch_norm_act(inputs, gamma, beta, None, None, epsilon, per_sample, relu,
+                                       sync_fn)
+    _moments_for_inference(mean, var, True, decay, use_moving_averages, num_channels)
+    return out
+  stats = _moments_for_inference(None, None, False, decay, use_moving_averages, num_channels)
+  if use_moving_averages:
+    mean, var = stats
+  else:
+    accu_mean, accu_var, accu_counter, update_accus = stats
+    if int(update_accus.item()) == 1:      # eval_gan_lib.py:65-92 fills the accumulators
+      n, c = inputs.shape[0], inputs.shape[-1]
+      bmean, bvar = K.bn_stats(inputs.contiguous().reshape(n, -1, c))
+      accu_mean.copy_(K.axpby_f32(accu_mean, 1.0, bmean, 1.0))
+      accu_var.copy_(K.axpby_f32(accu_var, 1.0, bvar, 1.0))
+      accu_counter.fill_(float(accu_counter.item()) + 1.0)
+    inv = 1.0 / float(accu_counter.item())  # arch_ops.py:191 accu / accu_counter
+    mean, var = K.axpby_f32(accu_mean, inv), K.axpby_f32(accu_var, inv)
+  out, _, _ = Fn.batch_norm_act(inputs, gamma, beta, mean.contiguous(), var.contiguous(), epsilon,
+                                per_sample, relu, None)
+  return out
+
+
+@gin.configurable(blacklist=["inputs"])
+def no_batch_norm(inputs):
+  return inputs
+
+
+@gin.configurable(blacklist=["inputs", "is_training", "center", "scale", "name", "relu"])
+def batch_norm(inputs, is_training, center=True, scale=True, name="batch_norm", relu=False):
+  """Vanilla batch normalization with trainable scale and offset (arch_ops.py:327-367)."""
+  with variable_scope(name):
+    c = inputs.shape[-1]
+    gamma = get_variable("gamma", [c], constant(1.0)) if scale else None
+    beta = get_variable("beta", [c], constant(0.0)) if center else None
+    return standardize_batch(inputs, is_training=is_training, gamma=gamma, beta=beta, relu=relu)
+
+
+@gin.configurable(whitelist=["num_hidden"])
+def self_modulated_batch_norm(inputs, z, is_training, use_sn, center=True, scale=True,
+                              name="batch_norm", num_hidden=32, relu=False):
+  """Self-modulated batch normalization (arch_ops.py:370-420)."""
+  if z is None:
+    raise ValueError("You must provide z for self modulation.")
+  with variable_scope(name):
+    c = inputs.shape[-1]
+    gamma = beta = None
+    with variable_scope("sbn"):
+      h = z
+      if num_hidden > 0:
+        h = relu_act(linear(h, num_hidden, scope="hidden", use_sn=use_sn))
+      if scale:
+        gamma = linear(h, c, scope="gamma", bias_start=1.0, use_sn=use_sn, out_f32=True)
+      if center:
+        beta = linear(h, c, scope="beta", use_sn=use_sn, out_f32=True)
+    return standardize_batch(inputs, is_training=is_training, gamma=gamma, beta=beta,
+                             per_sample=True, relu=relu)
+
+
+def relu_act(x):
+  return Act(x, 0.0)
+
+
+@gin.configurable(whitelist=["use_bias"])
+def conditional_batch_norm(inputs, y, is_training, use_sn, center=True, scale=True,
+                           name="batch_norm", use_bias=False, relu=False):
+  """Conditional batch normalization (arch_ops.py:423-445): gamma = linear(y), beta = linear(y)."""
+  if y is None:
+    raise ValueError("You must provide y for conditional batch normalization.")
+  if y.dim() != 2:
+    raise ValueError("Conditioning must have rank 2.")
+  with variable_scope(name):
+    c = inputs.shape[-1]
+    gamma = beta = None
+    with variable_scope("condition"):
+      if scale:
+        gamma = linear(y, c, scope="gamma", use_sn=use_sn, use_bias=use_bias, out_f32=True)
+      if center:
+        beta = linear(y, c, scope="beta", use_sn=use_sn, use_bias=use_bias, out_f32=True)
+    return standardize_batch(inputs, is_training=is_training, gamma=gamma, beta=beta,
+                             per_sample=True, relu=relu)
+
+
+def layer_norm(input_, is_training, scope):
+  raise NotImplementedError(
+      "layer_norm (arch_ops.py:448-450) is not used by any example config and has no HIP kernel.")
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / reductions / heads
+# ------------------------------------------------------------------------------------------------
+def avg_pool2(x):
+  """tf.nn.pool(x, [2,2], 'AVG', 'SAME', strides=[2,2]) (resnet_ops.py:131-133)."""
+  x = as_tensor(x)
+  if x.is_meta:
+    n, h, w, c = x.shape
+    return torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device="meta")
+  return Fn.avg_pool2(x)
+
+
+def max_pool2(x):
+  """tf.layers.max_pooling2d(pool_size=[2,2], strides=2) (arch_ops.py:741,750)."""
+  if x.is_meta:
+    n, h, w, c = x.shape
+    return torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device="meta")
+  return Fn.max_pool2(x)
+
+
+def reduce_spatial(inputs, mean):
+  """tf.reduce_mean / tf.reduce_sum over axes [1, 2] of a (possibly pending-ReLU) NHWC tensor
+  (resnet_cifar.py:154-156, resnet_biggan.py:404-405) -> [N, C] bf16."""
+  x, slope = _split_act(inputs)
+  if slope not in (None, 0.0):
+    x, slope = Act(x, slope).materialize(), None
+  n, c = x.shape[0], x.shape[-1]
+  if x.is_meta:
+    return torch.empty((n, c), dtype=BF16, device="meta")
+  hw = x.numel() // (n * c)
+  gate = x.detach() if slope is not None else None
+  return Fn.SpatialReduceFn.apply(x, gate, (1.0 / hw) if mean else 1.0)
+
+
+def output_head(pre_activation, kind):
+  """sigmoid (kind 0) or (tanh + 1) / 2 (kind 1) on the fp32 pre-activation."""
+  if pre_activation.is_meta:
+    return pre_activation
+  return Fn.HeadFn.apply(pre_activation, kind)
+
+
+# ------------------------------------------------------------------------------------------------
+# self-attention (arch_ops.py:709-758)
+# ------------------------------------------------------------------------------------------------
+def non_local_block(x, name, use_sn):
+  """SAGAN self-attention: theta/phi/g 1x1 convs, 2x2 max-pooled keys/values, fused
+  softmax(theta phi^T) g, 1x1 back-projection, x + sigma * o."""
+  with variable_scope(name):
+    n, h, w, c = x.shape
+    ca, cg = c // 8, c // 2
+    theta = conv1x1(x, ca, name="conv2d_theta", use_sn=use_sn, use_bias=False)
+    phi = max_pool2(conv1x1(x, ca, name="conv2d_phi", use_sn=use_sn, use_bias=False))
+    g = max_pool2(conv1x1(x, cg, name="conv2d_g", use_sn=use_sn, use_bias=False))
+    if x.is_meta:
+      attn_g = torch.empty((n, h, w, cg), dtype=BF16, device="meta")
+    else:
+      attn_g = Fn.AttentionFn.apply(theta.reshape(n, h * w, ca), phi.reshape(n, h * w // 4, ca),
+                                    g.reshape(n, h * w // 4, cg)).reshape(n, h, w, cg)
+    sigma = get_variable("sigma", [], constant(0.0))
+    attn_g = conv1x1(attn_g, c, name="conv2d_attn_g", use_sn=use_sn, use_bias=False)
+    if x.is_meta:
+      return x
+    return Fn.ScaledResidualFn.apply(x, attn_g, sigma.reshape(1))

@@ -1,0 +1,164 @@
+"""BigGAN ResNet, 32..512 px (reference: architectures/resnet_biggan.py:80-425).
+
+Differences to resnet_ops kept as in the reference: 1x1 shortcut convolutions (created last,
+optional), conditional batch norm fed by [z chunk, embedded y], self-attention after selected
+blocks, sum pooling and a projection head in D, no downsampling in D's last block.
+Parameter counts (resnet_biggan.py:39-62): 128 px G 70,433,988 / D 87,982,370.
+"""
+from compare_gan_amd import gin
+from compare_gan_amd.architectures import abstract_arch
+from compare_gan_amd.architectures import arch_ops as ops
+from compare_gan_amd.architectures import resnet_cifar
+from compare_gan_amd.architectures import resnet_ops
+from compare_gan_amd.hip import functional as Fn
+
+
+@gin.configurable
+class BigGanResNetBlock(resnet_ops.ResNetBlock):
+  """ResNet block with a 1x1 convolution for the (optional) shortcut connection."""
+
+  def __init__(self, add_shortcut=True, **kwargs):
+    super(BigGanResNetBlock, self).__init__(**kwargs)
+    self._add_shortcut = add_shortcut
+
+  def apply(self, inputs, z, y, is_training):
+    if inputs.shape[-1] != self._in_channels:
+      raise ValueError("Unexpected number of input channels (expected {}, got {}).".format(
+          self._in_channels, inputs.shape[-1]))
+    with ops.variable_scope(self._name):
+      outputs = self.batch_norm_relu(inputs, z=z, y=y, is_training=is_training, name="bn1")
+      outputs = self._get_conv(outputs, self._in_channels, self._out_channels, self._scale1,
+                               suffix="conv1")
+      outputs = self.batch_norm_relu(outputs, z=z, y=y, is_training=is_training, name="bn2")
+      outputs = self._get_conv(outputs, self._out_channels, self._out_channels, self._scale2,
+                               suffix="conv2")   # pooled when scale2 == "down"
+      if self._add_shortcut:
+        sc_in = inputs
+        if self._scale == "down":
+          # avg-pool commutes with a 1x1 convolution: pool first (4x fewer MACs, same result)
+          sc_in = ops.avg_pool2(inputs)
+        outputs = self._get_conv(sc_in, self._in_channels, self._out_channels, self._scale,
+                                 kernel_size=(1, 1), suffix="conv_shortcut", residual=outputs,
+                                 pool=False)
+      return outputs
+
+
+_G_CHANNEL_MULTIPLIERS = {512: [16, 16, 8, 8, 4, 2, 1, 1], 256: [16, 16, 8, 8, 4, 2, 1],
+                          128: [16, 16, 8, 4, 2, 1], 64: [16, 16, 8, 4, 2], 32: [4, 4, 4, 4]}
+_D_CHANNEL_MULTIPLIERS = {512: [1, 1, 2, 4, 8, 8, 16, 16], 256: [1, 2, 4, 8, 8, 16, 16],
+                          128: [1, 2, 4, 8, 16, 16], 64: [2, 4, 8, 16, 16], 32: [2, 2, 2, 2]}
+
+
+@gin.configurable
+class Generator(abstract_arch.AbstractGenerator):
+  """ResNet-based generator supporting resolutions 32, 64, 128, 256, 512."""
+
+  def __init__(self, ch=96, blocks_with_attention="B4", hierarchical_z=True, embed_z=False,
+               embed_y=True, embed_y_dim=128, embed_bias=False, **kwargs):
+    super(Generator, self).__init__(**kwargs)
+    self._ch = ch
+    self._blocks_with_attention = set(blocks_with_attention.split(","))
+    self._hierarchical_z = hierarchical_z
+    self._embed_z = embed_z
+    self._embed_y = embed_y
+    self._embed_y_dim = embed_y_dim
+    self._embed_bias = embed_bias
+
+  def _resnet_block(self, name, in_channels, out_channels, scale):
+    if scale not in ["up", "none"]:
+      raise ValueError("Unknown generator ResNet block scaling: {}.".format(scale))
+    return BigGanResNetBlock(name=name, in_channels=in_channels, out_channels=out_channels,
+                             scale=scale, is_gen_block=True, spectral_norm=self._spectral_norm,
+                             batch_norm=self.batch_norm, batch_norm_relu=self.batch_norm_relu)
+
+  def _get_in_out_channels(self):
+    resolution = self._image_shape[0]
+    if resolution not in _G_CHANNEL_MULTIPLIERS:
+      raise ValueError("Unsupported resolution: {}".format(resolution))
+    mult = _G_CHANNEL_MULTIPLIERS[resolution]
+    return [self._ch * c for c in mult[:-1]], [self._ch * c for c in mult[1:]]
+
+  def apply(self, z, y, is_training):
+    seed_size = 4
+    z_dim = z.shape[1]
+    in_channels, out_channels = self._get_in_out_channels()
+    num_blocks = len(in_channels)
+    if self._embed_z:
+      z = ops.linear(z, z_dim, scope="embed_z", use_sn=False, use_bias=self._embed_bias)
+    if self._embed_y:
+      y = ops.linear(y, self._embed_y_dim, scope="embed_y", use_sn=False,
+                     use_bias=self._embed_bias)
+    z0, z_per_block, y_per_block = resnet_cifar.split_z_and_condition(
+        z, y, num_blocks, self._hierarchical_z)
+    net = ops.linear(z0, in_channels[0] * seed_size * seed_size, scope="fc_noise",
+                     use_sn=self._spectral_norm)
+    net = net.reshape(-1, seed_size, seed_size, in_channels[0])
+    for block_idx in range(num_blocks):
+      name = "B{}".format(block_idx + 1)
+      block = self._resnet_block(name=name, in_channels=in_channels[block_idx],
+                                 out_channels=out_channels[block_idx], scale="up")
+      net = block(net, z=z_per_block[block_idx], y=y_per_block[block_idx],
+                  is_training=is_training)
+      if name in self._blocks_with_attention:
+        net = ops.non_local_block(net, "non_local_block", use_sn=self._spectral_norm)
+    # final processing: UNconditional batch norm (resnet_biggan.py:293-295)
+    net = ops.batch_norm(net, is_training=is_training, name="final_norm", relu=True)
+    net = ops.conv2d(net, output_dim=self._image_shape[2], k_h=3, k_w=3, d_h=1, d_w=1,
+                     name="final_conv", use_sn=self._spectral_norm, out_f32=True)
+    return ops.output_head(net, 1)  # (tanh + 1) / 2
+
+
+@gin.configurable
+class Discriminator(abstract_arch.AbstractDiscriminator):
+  """ResNet-based discriminator supporting resolutions 32, 64, 128, 256, 512."""
+
+  def __init__(self, ch=96, blocks_with_attention="B1", project_y=True, **kwargs):
+    super(Discriminator, self).__init__(**kwargs)
+    self._ch = ch
+    self._blocks_with_attention = set(blocks_with_attention.split(","))
+    self._project_y = project_y
+
+  def _resnet_block(self, name, in_channels, out_channels, scale):
+    if scale not in ["down", "none"]:
+      raise ValueError("Unknown discriminator ResNet block scaling: {}.".format(scale))
+    return BigGanResNetBlock(name=name, in_channels=in_channels, out_channels=out_channels,
+                             scale=scale, is_gen_block=False,
+                             add_shortcut=in_channels != out_channels,
+                             layer_norm=self._layer_norm, spectral_norm=self._spectral_norm,
+                             batch_norm=self.batch_norm, batch_norm_relu=self.batch_norm_relu)
+
+  def _get_in_out_channels(self, colors, resolution):
+    if colors not in [1, 3]:
+      raise ValueError("Unsupported color channels: {}".format(colors))
+    if resolution not in _D_CHANNEL_MULTIPLIERS:
+      raise ValueError("Unsupported resolution: {}".format(resolution))
+    out_channels = [self._ch * c for c in _D_CHANNEL_MULTIPLIERS[resolution]]
+    return [colors] + out_channels[:-1], out_channels
+
+  def apply(self, x, y, is_training):
+    resnet_ops.validate_image_inputs(x)
+    in_channels, out_channels = self._get_in_out_channels(colors=x.shape[-1],
+                                                          resolution=x.shape[1])
+    num_blocks = len(in_channels)
+    net = x
+    for block_idx in range(num_blocks):
+      name = "B{}".format(block_idx + 1)
+      is_last_block = block_idx == num_blocks - 1
+      block = self._resnet_block(name=name, in_channels=in_channels[block_idx],
+                                 out_channels=out_channels[block_idx],
+                                 scale="none" if is_last_block else "down")
+      net = block(net, z=None, y=y, is_training=is_training)
+      if name in self._blocks_with_attention:
+        net = ops.non_local_block(net, "non_local_block", use_sn=self._spectral_norm)
+    h = ops.reduce_spatial(ops.relu(net), mean=False)   # relu + reduce_sum over [1, 2]
+    out_logit = ops.linear(h, 1, scope="final_fc", use_sn=self._spectral_norm, out_f32=True)
+    if self._project_y:
+      if y is None:
+        raise ValueError("You must provide class information y to project.")
+      # resnet_biggan.py:411-423: glorot-normal kernel, spectrally normalised by hand
+      embedded_y = ops.linear(y, out_channels[-1], scope="embedding_fc", use_bias=False,
+                              use_sn=self._spectral_norm,
+                              kernel_initializer=ops.glorot_normal())
+      if not h.is_meta:
+        out_logit = Fn.add_f32(out_logit, Fn.RowDotFn.apply(embedded_y, h))
+    return ops.output_head(out_logit, 0), out_logit, h

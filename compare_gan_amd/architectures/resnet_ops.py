@@ -1,0 +1,113 @@
+"""ResNet building blocks (reference: architectures/resnet_ops.py:35-219).
+
+Same block semantics -- [BN -> ReLU -> conv] x 2 plus a 3x3 convolutional shortcut, generator
+blocks upsample (zero insertion) in conv1 and the shortcut, discriminator blocks average-pool
+after conv2 and the shortcut -- expressed with the fused HIP kernels: the ReLUs are input gates of
+the following convolution, the zero-inserted tensor is never materialised, the shortcut is added
+in conv2's epilogue, and (linearity) the two poolings of a "down" block collapse into one pooling
+of the sum.
+"""
+import math
+
+from compare_gan_amd.architectures import abstract_arch
+from compare_gan_amd.architectures import arch_ops as ops
+
+
+def unpool(value, name="unpool"):
+  """Zero-insertion 2x upsampling (resnet_ops.py:35-56) as a stand-alone op: a 1x1 identity gather
+  is never needed on the hot path (conv2d(upsample=True) fuses it); kept for API parity."""
+  raise NotImplementedError(
+      "unpool is fused into conv2d(..., upsample=True); call that instead (name=%s)" % name)
+
+
+def validate_image_inputs(inputs, validate_power2=True):
+  """resnet_ops.py:59-67."""
+  if inputs.dim() != 4:
+    raise ValueError("Input tensor must have rank 4.")
+  if inputs.shape[1] != inputs.shape[2]:
+    raise ValueError("Input tensor does not have equal width and height: ", inputs.shape[1:3])
+  width = inputs.shape[1]
+  if validate_power2 and math.log(width, 2) != int(math.log(width, 2)):
+    raise ValueError("Input tensor `width` is not a power of 2: ", width)
+
+
+class ResNetBlock(object):
+  """ResNet block with options for various normalizations (resnet_ops.py:70-182)."""
+
+  def __init__(self, name, in_channels, out_channels, scale, is_gen_block, layer_norm=False,
+               spectral_norm=False, batch_norm=None, batch_norm_relu=None):
+    assert scale in ["up", "down", "none"]
+    self._name = name
+    self._in_channels = in_channels
+    self._out_channels = out_channels
+    self._scale = scale
+    # Generators upscale in the first conv, discriminators downscale after the second conv.
+    self._scale1 = scale if is_gen_block else "none"
+    self._scale2 = "none" if is_gen_block else scale
+    self._layer_norm = layer_norm
+    self._spectral_norm = spectral_norm
+    self.batch_norm = batch_norm
+    self.batch_norm_relu = batch_norm_relu
+    if layer_norm:
+      raise NotImplementedError("layer_norm has no HIP kernel (unused by example configs).")
+
+  def __call__(self, inputs, z, y, is_training):
+    return self.apply(inputs=inputs, z=z, y=y, is_training=is_training)
+
+  def _get_conv(self, inputs, in_channels, out_channels, scale, suffix, kernel_size=(3, 3),
+                strides=(1, 1), residual=None, pool=True):
+    """One convolution of the block (resnet_ops.py:112-134).  `pool=False` lets the caller pool
+    the sum of two "down" branches once."""
+    if inputs.shape[-1] != in_channels:
+      raise ValueError("Unexpected number of input channels.")
+    if scale not in ["up", "down", "none"]:
+      raise ValueError("Scale: got {}, expected 'up', 'down', or 'none'.".format(scale))
+    outputs = ops.conv2d(
+        inputs, output_dim=out_channels, k_h=kernel_size[0], k_w=kernel_size[1],
+        d_h=strides[0], d_w=strides[1], use_sn=self._spectral_norm,
+        name="{}_{}".format("same" if scale == "none" else scale, suffix),
+        upsample=(scale == "up"), residual=residual)
+    if scale == "down" and pool:
+      outputs = ops.avg_pool2(outputs)
+    return outputs
+
+  def apply(self, inputs, z, y, is_training):
+    if inputs.shape[-1] != self._in_channels:
+      raise ValueError("Unexpected number of input channels.")
+    with ops.variable_scope(self._name):
+      # variables are created in the reference order: shortcut, bn1, conv1, bn2, conv2
+      shortcut = self._get_conv(inputs, self._in_channels, self._out_channels, self._scale,
+                                suffix="conv_shortcut", pool=False)
+      output = self.batch_norm_relu(inputs, z=z, y=y, is_training=is_training, name="bn1")
+      output = self._get_conv(output, self._in_channels, self._out_channels, self._scale1,
+                              suffix="conv1")
+      output = self.batch_norm_relu(output, z=z, y=y, is_training=is_training, name="bn2")
+      # conv2 + shortcut in one epilogue; pool(conv2) + pool(shortcut) == pool(conv2 + shortcut)
+      output = self._get_conv(output, self._out_channels, self._out_channels, self._scale2,
+                              suffix="conv2", residual=shortcut, pool=False)
+      if self._scale == "down":
+        output = ops.avg_pool2(output)
+      return output
+
+
+class ResNetGenerator(abstract_arch.AbstractGenerator):
+  """Abstract base class for generators based on the ResNet architecture."""
+
+  def _resnet_block(self, name, in_channels, out_channels, scale):
+    if scale not in ["up", "none"]:
+      raise ValueError("Unknown generator ResNet block scaling: {}.".format(scale))
+    return ResNetBlock(name=name, in_channels=in_channels, out_channels=out_channels,
+                       scale=scale, is_gen_block=True, spectral_norm=self._spectral_norm,
+                       batch_norm=self.batch_norm, batch_norm_relu=self.batch_norm_relu)
+
+
+class ResNetDiscriminator(abstract_arch.AbstractDiscriminator):
+  """Abstract base class for discriminators based on the ResNet architecture."""
+
+  def _resnet_block(self, name, in_channels, out_channels, scale):
+    if scale not in ["down", "none"]:
+      raise ValueError("Unknown discriminator ResNet block scaling: {}.".format(scale))
+    return ResNetBlock(name=name, in_channels=in_channels, out_channels=out_channels,
+                       scale=scale, is_gen_block=False, layer_norm=self._layer_norm,
+                       spectral_norm=self._spectral_norm, batch_norm=self.batch_norm,
+                       batch_norm_relu=self.batch_norm_relu)

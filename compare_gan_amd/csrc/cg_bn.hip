@@ -249,6 +249,21 @@ __global__ void bn_update_moving_kernel(float* __restrict__ mm, float* __restric
   mv[c] -= (1.f - decay) * (mv[c] - var[c]);
 }
 
+// to_variance == 0: second <- var + mean^2 (E[x^2]);  == 1: mean *= scale, second *= scale, then
+// second <- second - mean^2  (tpu_ops.py:112-120 parallel moments after the all-reduce SUM).
+__global__ void bn_moments_convert_kernel(float* __restrict__ mean, float* __restrict__ second,
+                                          int C, int to_variance, float scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (!to_variance) {
+    second[c] = second[c] + mean[c] * mean[c];
+  } else {
+    const float m = mean[c] * scale, q = second[c] * scale;
+    mean[c] = m;
+    second[c] = q - m * m;
+  }
+}
+
 inline int bwd_hsplits(int N, int HW, int C) {
   const int blocks = cdiv(C, 64) * N;
   int s = cdiv(1024, blocks);
@@ -318,35 +333,54 @@ extern "C" int cg_bn_apply(const void* x, int N, int HW, int C, const float* mea
 extern "C" size_t cg_bn_backward_workspace_bytes(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0) return 0;
   const size_t hs = bwd_hsplits(N, HW, C);
-  return align_up((hs * 2 * (size_t)N * C + 2 * (size_t)C) * sizeof(float), 256);
+  return align_up(hs * 2 * (size_t)N * C * sizeof(float), 256);
 }
 
-extern "C" int cg_bn_backward(const void* x, const void* y, const void* dy, int N, int HW, int C,
-                              const float* mean, const float* var, float eps, const float* gamma,
-                              int per_sample, int relu, int batch_stats, void* dx, float* dgamma,
-                              float* dbeta, void* ws, size_t ws_bytes, cgStream stream) {
-  if (!x || !dy || !dx || !mean || !var || N <= 0 || HW <= 0 || C <= 0 || (relu && !y))
-    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_backward: bad argument");
+extern "C" int cg_bn_backward_reduce(const void* x, const void* y, const void* dy, int N, int HW,
+                                     int C, const float* mean, const float* var, float eps,
+                                     const float* gamma, int per_sample, int relu, float* dgamma,
+                                     float* dbeta, float* m12, void* ws, size_t ws_bytes,
+                                     cgStream stream) {
+  if (!x || !dy || !m12 || !mean || !var || N <= 0 || HW <= 0 || C <= 0 || (relu && !y))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_backward_reduce: bad argument");
   if (!ws || ws_bytes < cg_bn_backward_workspace_bytes(N, HW, C))
-    CG_FAIL(CG_ERR_WORKSPACE, "cg_bn_backward: workspace too small");
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_bn_backward_reduce: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int hs = bwd_hsplits(N, HW, C);
   const int hps = (HW + hs - 1) / hs;
   float* part = (float*)ws;
-  float* m12 = part + (size_t)hs * 2 * N * C;
   dim3 grid(cdiv(C, 64), N, hs);
   bn_bwd_sums_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
                                            HW, C, hps, mean, var, eps, relu, part);
-  CG_CHECK_LAUNCH("cg_bn_backward(sums)");
+  CG_CHECK_LAUNCH("cg_bn_backward_reduce(sums)");
   bn_bwd_final_kernel<<<cdiv(C, 256), 256, 0, st>>>(part, hs, N, C,
                                                     1.0f / ((float)N * (float)HW), gamma,
                                                     per_sample, dgamma, dbeta, m12);
-  CG_CHECK_LAUNCH("cg_bn_backward(final)");
+  CG_CHECK_LAUNCH("cg_bn_backward_reduce(final)");
+  return CG_OK;
+}
+
+extern "C" int cg_bn_backward_apply(const void* x, const void* y, const void* dy, int N, int HW,
+                                    int C, const float* mean, const float* var, float eps,
+                                    const float* gamma, int per_sample, int relu, int batch_stats,
+                                    const float* m12, void* dx, cgStream stream) {
+  if (!x || !dy || !dx || !mean || !var || N <= 0 || HW <= 0 || C <= 0 || (relu && !y) ||
+      (batch_stats && !m12))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_backward_apply: bad argument");
   const int64_t total = (int64_t)N * HW * C;
-  bn_bwd_dx_kernel<<<grid_cap(total), 256, 0, st>>>(
+  bn_bwd_dx_kernel<<<grid_cap(total), 256, 0, (hipStream_t)stream>>>(
       (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, HW, C, total, mean, var, eps, gamma,
       per_sample, relu, batch_stats, m12, (bf16_t*)dx);
-  CG_CHECK_LAUNCH("cg_bn_backward(dx)");
+  CG_CHECK_LAUNCH("cg_bn_backward_apply");
+  return CG_OK;
+}
+
+extern "C" int cg_bn_moments_convert(float* mean, float* second, int C, int to_variance,
+                                     float scale, cgStream stream) {
+  if (!mean || !second || C <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_moments_convert: bad argument");
+  bn_moments_convert_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(mean, second, C,
+                                                                           to_variance, scale);
+  CG_CHECK_LAUNCH("cg_bn_moments_convert");
   return CG_OK;
 }
 

@@ -327,6 +327,44 @@ __global__ void inception_preprocess_kernel(const float* __restrict__ x, int N, 
   }
 }
 
+__global__ void axpby_f32_kernel(const float* __restrict__ a, float alpha,
+                                 const float* __restrict__ b, float beta, float* __restrict__ out,
+                                 int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+__global__ void axpy_dev_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ o,
+                                const float* __restrict__ sigma, bf16_t* __restrict__ out,
+                                int64_t n) {
+  const float s = *sigma;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = f2bf((x ? bf2f(x[i]) : 0.f) + s * bf2f(o[i]));
+}
+__global__ __launch_bounds__(256) void dot_bf16_part_kernel(const bf16_t* __restrict__ a,
+                                                            const bf16_t* __restrict__ b,
+                                                            int64_t n, float* __restrict__ part) {
+  __shared__ float sm4[4];
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    s += bf2f(a[i]) * bf2f(b[i]);
+  s = block_sum_256(s, sm4);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void dot_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = 0; i < nb; ++i) s += part[i];
+  *out = s;
+}
+inline int dot_blocks(int64_t n) {
+  int64_t b = (n + 2047) / 2048;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 }  // namespace
 
 #define CG_NONNEG(n, who) \
@@ -550,5 +588,43 @@ extern "C" int cg_inception_preprocess(const float* x, int N, int H, int W, int 
   inception_preprocess_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
       x, N, H, W, C, Ho, Wo, (bf16_t*)y);
   CG_CHECK_LAUNCH("cg_inception_preprocess");
+  return CG_OK;
+}
+
+extern "C" int cg_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out,
+                            int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_axpby_f32");
+  if (n == 0) return CG_OK;
+  if (!a || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_axpby_f32: null pointer");
+  axpby_f32_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(a, alpha, b, beta, out, n);
+  CG_CHECK_LAUNCH("cg_axpby_f32");
+  return CG_OK;
+}
+
+extern "C" int cg_axpy_dev(const void* x, const void* o, const float* sigma, void* out, int64_t n,
+                           cgStream stream) {
+  CG_NONNEG(n, "cg_axpy_dev");
+  if (n == 0) return CG_OK;
+  if (!o || !sigma || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_axpy_dev: null pointer");
+  axpy_dev_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)o, sigma, (bf16_t*)out, n);
+  CG_CHECK_LAUNCH("cg_axpy_dev");
+  return CG_OK;
+}
+
+extern "C" size_t cg_dot_bf16_workspace_bytes(int64_t n) {
+  return n > 0 ? align_up((size_t)dot_blocks(n) * sizeof(float), 256) : 0;
+}
+extern "C" int cg_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* ws,
+                           size_t ws_bytes, cgStream stream) {
+  if (!a || !b || !out || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_dot_bf16: bad argument");
+  if (!ws || ws_bytes < cg_dot_bf16_workspace_bytes(n))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_dot_bf16: workspace too small");
+  const int nb = dot_blocks(n);
+  hipStream_t st = (hipStream_t)stream;
+  dot_bf16_part_kernel<<<nb, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, n, (float*)ws);
+  CG_CHECK_LAUNCH("cg_dot_bf16(part)");
+  dot_final_kernel<<<1, 1, 0, st>>>((const float*)ws, nb, out);
+  CG_CHECK_LAUNCH("cg_dot_bf16(final)");
   return CG_OK;
 }

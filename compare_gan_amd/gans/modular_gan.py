@@ -1,0 +1,433 @@
+"""The GAN training step on one MI355X (or one rank of a data-parallel job).
+
+Reference: compare_gan/gans/modular_gan.py:56-670 (ModularGAN: architecture table, input split,
+G forward, D step(s), G step, optimizers, EMA) on top of abstract_gan.py:29-92.  The reference
+builds a TF1 graph for TPUEstimator; here the same step is executed directly: every arithmetic op
+is a HIP kernel (compare_gan_amd.hip), torch.autograd only records the graph, the optimiser is one
+fused multi-tensor TF-Adam(+EMA) launch per network, and the data-parallel gradient mean is one
+RCCL all-reduce of a flat bucket per network (the reference's CrossShardOptimizer,
+modular_gan.py:606-616).
+
+Step semantics = the reference's *unrolled* graph (modular_gan.py:533-584):
+`disc_iters` discriminator sub-steps, each on a fresh sub-batch (real images, z, sampled labels)
+and a fresh G forward, followed by one generator sub-step on another fresh sub-batch.
+"""
+import torch
+
+from compare_gan_amd import gin
+from compare_gan_amd import utils
+from compare_gan_amd.architectures import arch_ops as ops
+from compare_gan_amd.architectures import dcgan
+from compare_gan_amd.architectures import resnet5
+from compare_gan_amd.architectures import resnet_biggan
+from compare_gan_amd.architectures import resnet_cifar
+from compare_gan_amd.architectures import sndcgan
+from compare_gan_amd.gans import consts as c
+from compare_gan_amd.gans import loss_lib
+from compare_gan_amd.gans import penalty_lib
+from compare_gan_amd.gans.abstract_gan import AbstractGAN
+from compare_gan_amd.hip import functional as Fn
+from compare_gan_amd.hip import kernels as K
+from compare_gan_amd.tpu import tpu_ops
+from compare_gan_amd.tpu import tpu_random
+
+
+# ------------------------------------------------------------------------------------------------
+# external configurables the example configs bind (main.py:38-39 gin.tf.external_configurables)
+# ------------------------------------------------------------------------------------------------
+class AdamOptimizer(object):
+  """Hyper-parameters of tf.train.AdamOptimizer; the update itself is cg_adam_multi."""
+
+  def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, name="Adam"):
+    self.learning_rate = learning_rate
+    self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
+    self.name = name
+
+
+AdamOptimizer = gin.external_configurable(AdamOptimizer, name="AdamOptimizer", module="tf.train")
+
+
+def _random_normal(shape, mean=0.0, stddev=1.0, name=None, device=None):
+  return tpu_random.normal(shape, name or "random_normal", mean, stddev, device)
+
+
+def _random_uniform(shape, minval=0.0, maxval=1.0, name=None, device=None):
+  return tpu_random.uniform(shape, name or "random_uniform", minval, maxval, device)
+
+
+random_normal = gin.external_configurable(_random_normal, name="normal", module="tf.random")
+random_uniform = gin.external_configurable(_random_uniform, name="uniform", module="tf.random")
+
+
+class _OptimizerState(object):
+  """Adam slots (+ EMA shadows) for one network and the fused update."""
+
+  def __init__(self, named_vars, opt, with_ema, device):
+    self.names = [n for n, _ in named_vars]
+    self.params = [v for _, v in named_vars]
+    self.opt = opt
+    self.m = [torch.zeros_like(v, requires_grad=False) for v in self.params]
+    self.v = [torch.zeros_like(v, requires_grad=False) for v in self.params]
+    self.ema = [v.detach().clone() for v in self.params] if with_ema else None
+    self.table = None
+    self.flat = None
+    self.device = device
+
+  def _ensure(self, grads):
+    if self.table is None:
+      self.table = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v, self.ema)
+    else:
+      self.table.set_grads(grads)
+
+  def apply_gradients(self, step, ema_decay=0.0, ema_start=0):
+    """All-reduce (data parallel) + fused Adam(+EMA).  step: device int64 update counter."""
+    grads = []
+    for n, p in zip(self.names, self.params):
+      if p.grad is None:
+        raise RuntimeError("variable %s received no gradient" % n)
+      grads.append(p.grad.contiguous())
+    world = tpu_ops.num_replicas()
+    scale = 1.0
+    if world > 1:
+      if self.flat is None:
+        self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32,
+                                device=self.device)
+        self.flat_views = []
+        off = 0
+        for g in grads:
+          self.flat_views.append(self.flat[off:off + g.numel()].view(g.shape))
+          off += g.numel()
+        self.gather_table = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v,
+                                        self.ema)
+      self.gather_table.set_grads(grads)
+      self.gather_table.gather(self.flat)
+      tpu_ops.cross_replica_sum_(self.flat)      # CrossShardOptimizer: gradient mean
+      grads = self.flat_views
+      scale = 1.0 / world
+    self._ensure(grads)
+    o = self.opt
+    self.table.adam(o.learning_rate, o.beta1, o.beta2, o.epsilon, scale, step,
+                    ema_decay=ema_decay if self.ema is not None else 0.0, ema_start=ema_start)
+
+
+@gin.configurable(blacklist=["dataset", "parameters", "model_dir"])
+class ModularGAN(AbstractGAN):
+  """Gin-configurable GAN trainer with the reference's constructor surface."""
+
+  def __init__(self, dataset, parameters, model_dir, deprecated_split_disc_calls=False,
+               experimental_joint_gen_for_disc=False, experimental_force_graph_unroll=False,
+               g_use_ema=False, ema_decay=0.9999, ema_start_step=40000,
+               g_optimizer_fn=AdamOptimizer, d_optimizer_fn=None, g_lr=0.0002, d_lr=None,
+               conditional=False, fit_label_distribution=False):
+    super(ModularGAN, self).__init__(dataset=dataset, parameters=parameters, model_dir=model_dir)
+    self._deprecated_split_disc_calls = deprecated_split_disc_calls
+    self._experimental_joint_gen_for_disc = experimental_joint_gen_for_disc
+    self._experimental_force_graph_unroll = experimental_force_graph_unroll
+    self._g_use_ema = g_use_ema
+    self._ema_decay = ema_decay
+    self._ema_start_step = ema_start_step
+    self._g_optimizer_fn = g_optimizer_fn
+    self._d_optimizer_fn = d_optimizer_fn if d_optimizer_fn is not None else g_optimizer_fn
+    self._g_lr = g_lr
+    self._d_lr = g_lr if d_lr is None else d_lr
+    if conditional and not self._dataset.num_classes:
+      raise ValueError("Option 'conditional' selected but dataset {} does not have "
+                       "labels".format(self._dataset.name))
+    self._conditional = conditional
+    self._fit_label_distribution = fit_label_distribution
+    # Parameters that have not been ported to Gin (modular_gan.py:142-149).
+    self._architecture = parameters["architecture"]
+    self._z_dim = parameters["z_dim"]
+    self._lambda = parameters["lambda"]
+    self._disc_iters = parameters.get("disc_iters", 1)
+    self.d_loss = None
+    self.g_loss = None
+    self.penalty_loss = None
+    self._discriminator = None
+    self._generator = None
+    self.store = None
+    self._built = False
+
+  # -- architecture table (modular_gan.py:169-213) ---------------------------------------------------
+  @property
+  def conditional(self):
+    return self._conditional
+
+  @property
+  def generator(self):
+    if self._generator is None:
+      architecture_fns = {
+          c.DCGAN_ARCH: dcgan.Generator,
+          c.RESNET5_ARCH: resnet5.Generator,
+          c.RESNET_BIGGAN_ARCH: resnet_biggan.Generator,
+          c.RESNET_CIFAR_ARCH: resnet_cifar.Generator,
+          c.SNDCGAN_ARCH: sndcgan.Generator,
+      }
+      if self._architecture not in architecture_fns:
+        raise NotImplementedError(
+            "Generator architecture {} not implemented.".format(self._architecture))
+      self._generator = architecture_fns[self._architecture](
+          image_shape=self._dataset.image_shape)
+    return self._generator
+
+  @property
+  def discriminator(self):
+    if self._discriminator is None:
+      architecture_fns = {
+          c.DCGAN_ARCH: dcgan.Discriminator,
+          c.RESNET5_ARCH: resnet5.Discriminator,
+          c.RESNET_BIGGAN_ARCH: resnet_biggan.Discriminator,
+          c.RESNET_CIFAR_ARCH: resnet_cifar.Discriminator,
+          c.SNDCGAN_ARCH: sndcgan.Discriminator,
+      }
+      if self._architecture not in architecture_fns:
+        raise NotImplementedError(
+            "Discriminator architecture {} not implemented.".format(self._architecture))
+      self._discriminator = architecture_fns[self._architecture]()
+    return self._discriminator
+
+  # -- graph construction ----------------------------------------------------------------------------
+  def build(self, batch_size, device, seed=0):
+    """Creates every variable (one shape-only pass over G and D, no kernel runs), the optimiser
+    slots, EMA shadows and step counters.  batch_size is the per-replica sub-step batch."""
+    self.device = torch.device(device)
+    self.batch_size = batch_size
+    self.seed = seed
+    self.store = ops.VariableStore(self.device, seed=seed)
+    meta = "meta"
+    with ops.use_store(self.store):
+      z = torch.empty((batch_size, self._z_dim), dtype=torch.float32, device=meta)
+      y = None
+      if self.conditional:
+        y = torch.empty((batch_size, self._dataset.num_classes), dtype=torch.bfloat16,
+                        device=meta)
+      images = self.generator(z, y=y, is_training=True)
+      x = torch.empty((2 * batch_size,) + tuple(images.shape[1:]), dtype=torch.bfloat16,
+                      device=meta)
+      y2 = None if y is None else torch.empty((2 * batch_size, y.shape[1]), dtype=y.dtype,
+                                              device=meta)
+      self.discriminator(x, y=y2, is_training=True)
+      self._check_variables()
+    if self.device.type == "meta":
+      self._built = True
+      return self
+    self.global_step = torch.zeros((), dtype=torch.int64, device=self.device)
+    self.global_step_disc = torch.zeros((), dtype=torch.int64, device=self.device)
+    g_vars = self.store.trainable_variables(self.generator.name)
+    d_vars = self.store.trainable_variables(self.discriminator.name)
+    self.g_opt = _OptimizerState(g_vars, self.get_gen_optimizer(), self._g_use_ema, self.device)
+    self.d_opt = _OptimizerState(d_vars, self.get_disc_optimizer(), False, self.device)
+    tpu_random.set_random_offset(seed, self.global_step)
+    self._built = True
+    return self
+
+  def _check_variables(self):
+    """Every trainable variable belongs to exactly one of G / D (modular_gan.py:345-357)."""
+    t_vars = set(n for n, _ in self.store.trainable_variables())
+    g_vars = set(n for n, _ in self.store.trainable_variables(self.generator.name))
+    d_vars = set(n for n, _ in self.store.trainable_variables(self.discriminator.name))
+    shared = g_vars & d_vars
+    if shared:
+      raise ValueError("Shared trainable variables: %s" % shared)
+    unused = t_vars - g_vars - d_vars
+    if unused:
+      raise ValueError("Unused trainable variables: %s" % unused)
+
+  def get_disc_optimizer(self, use_tpu=True):
+    del use_tpu   # the cross-replica mean lives in _OptimizerState.apply_gradients
+    return self._d_optimizer_fn(self._d_lr, name="d_opt")
+
+  def get_gen_optimizer(self, use_tpu=True):
+    del use_tpu
+    return self._g_optimizer_fn(self._g_lr, name="g_opt")
+
+  # -- inputs ------------------------------------------------------------------------------------------
+  def _get_one_hot_labels(self, labels):
+    if not self.conditional:
+      raise ValueError("_get_one_hot_labels() called but GAN is not conditional.")
+    return K.one_hot(labels, self._dataset.num_classes)
+
+  @gin.configurable("z", blacklist=["shape", "name"])
+  def z_generator(self, shape, distribution_fn=random_uniform, minval=-1.0, maxval=1.0,
+                  stddev=1.0, name=None):
+    """Random noise for G (modular_gan.py:365-384)."""
+    return utils.call_with_accepted_args(distribution_fn, shape=shape, minval=minval,
+                                         maxval=maxval, stddev=stddev, name=name,
+                                         device=self.device)
+
+  def label_generator(self, shape, name=None):
+    """Uniform labels (modular_gan.py:386-391)."""
+    if not self.conditional:
+      raise ValueError("label_generator() called but GAN is not conditional.")
+    return tpu_random.labels(int(shape[0]), self._dataset.num_classes, name or "sampled_labels",
+                             self.device)
+
+  def _preprocess(self, images, labels, sub_step):
+    """Feature dictionary of one sub-step (modular_gan.py:393-408): real images, z, sampled
+    labels; names are unique per sub-step so every sub-step draws fresh noise."""
+    features = {"images": images,
+                "z": self.z_generator([images.shape[0], self._z_dim], name="z/%d" % sub_step)}
+    if self.conditional:
+      if self._fit_label_distribution:
+        features["sampled_labels"] = labels
+      else:
+        features["sampled_labels"] = self.label_generator(
+            [images.shape[0]], name="sampled_labels/%d" % sub_step)
+    return features, labels
+
+  # -- losses (modular_gan.py:618-670) ---------------------------------------------------------------
+  def create_loss(self, features, labels, params=None, is_training=True):
+    """Sets self.d_loss / self.g_loss (/ self.penalty_loss) for one sub-step."""
+    del params
+    images = features["images"]        # real, fp32 [B,H,W,C] in [0,1]
+    generated = features["generated"]  # fake, fp32
+    if self.conditional:
+      y = self._get_one_hot_labels(labels)
+      sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+      all_y = torch.cat([y, sampled_y], dim=0)
+    else:
+      y = sampled_y = all_y = None
+    a, b = getattr(self.discriminator, "input_affine", (1.0, 0.0))
+    if self._deprecated_split_disc_calls:
+      d_real, d_real_logits, _ = self.discriminator(
+          Fn.stage_images(images, None, a, b), y=y, is_training=is_training)
+      d_fake, d_fake_logits, _ = self.discriminator(
+          Fn.stage_images(None, generated, a, b), y=sampled_y, is_training=is_training)
+    else:
+      all_images = Fn.stage_images(images, generated, a, b)   # concat + bf16 (+ input affine)
+      d_all, d_all_logits, _ = self.discriminator(all_images, y=all_y, is_training=is_training)
+      bsz = images.shape[0]
+      d_real, d_fake = d_all[:bsz], d_all[bsz:]
+      d_real_logits, d_fake_logits = d_all_logits[:bsz], d_all_logits[bsz:]
+    self.d_loss, _, _, self.g_loss = loss_lib.get_losses(
+        d_real=d_real, d_fake=d_fake, d_real_logits=d_real_logits, d_fake_logits=d_fake_logits)
+    self.penalty_loss = None
+    if torch.is_grad_enabled() and not features.get("_generator_step", False):
+      penalty_loss = penalty_lib.get_penalty_loss(
+          x=images, x_fake=generated, y=y, is_training=is_training,
+          discriminator=self.discriminator)
+      if penalty_loss is not None:
+        self.penalty_loss = penalty_loss
+        self.d_loss = Fn.add_f32(self.d_loss.reshape(1), penalty_loss.reshape(1), 1.0,
+                                 float(self._lambda)).reshape(())
+
+  # -- training step -------------------------------------------------------------------------------
+  def _zero_grads(self, opt_state):
+    for p in opt_state.params:
+      p.grad = None
+
+  def _train_discriminator(self, features, labels):
+    """One D update (modular_gan.py:471-485)."""
+    features = dict(features)
+    features["generated"] = features["generated"].detach()
+    self._set_requires_grad(self.g_opt, False)
+    self._set_requires_grad(self.d_opt, True)
+    self._zero_grads(self.d_opt)
+    with ops.use_store(self.store):
+      self.create_loss(features, labels)
+    self.d_loss.backward()
+    self.d_opt.apply_gradients(self.global_step_disc)
+    K.counter_add(self.global_step_disc, 1)
+    return self.d_loss.detach()
+
+  def _train_generator(self, features, labels):
+    """One G update (+ EMA) (modular_gan.py:487-510); D's weights get no gradient."""
+    features = dict(features)
+    features["_generator_step"] = True
+    self._set_requires_grad(self.d_opt, False)
+    self._set_requires_grad(self.g_opt, True)
+    self._zero_grads(self.g_opt)
+    with ops.use_store(self.store):
+      sampled_y = None
+      if self.conditional:
+        sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+      features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
+      self.create_loss(features, labels)
+    self.g_loss.backward()
+    self.g_opt.apply_gradients(self.global_step, ema_decay=self._ema_decay,
+                               ema_start=self._ema_start_step)
+    K.counter_add(self.global_step, 1)
+    self._set_requires_grad(self.d_opt, True)
+    return self.g_loss.detach()
+
+  @staticmethod
+  def _set_requires_grad(opt_state, flag):
+    for p in opt_state.params:
+      p.requires_grad_(flag)
+
+  def train_step(self, images, labels):
+    """One unrolled step: images [(disc_iters+1)*B, H, W, C] fp32 in [0,1] and labels
+    [(disc_iters+1)*B] int32, already on the device (modular_gan.py:428-469,568-584).
+
+    Returns {"d_losses": [...], "g_loss": tensor} (device scalars)."""
+    if not self._built:
+      raise RuntimeError("call build() first")
+    num_sub_steps = self._disc_iters + 1
+    total = images.shape[0]
+    if total % num_sub_steps:
+      raise ValueError("batch of %d does not split into %d sub-steps" % (total, num_sub_steps))
+    bsz = total // num_sub_steps
+    fs, ls = [], []
+    for i in range(num_sub_steps):
+      f, l = self._preprocess(images[i * bsz:(i + 1) * bsz], labels[i * bsz:(i + 1) * bsz], i)
+      fs.append(f)
+      ls.append(l)
+    d_losses = []
+    with ops.use_store(self.store):
+      for i in range(self._disc_iters):
+        with torch.no_grad():
+          sampled_y = None
+          if self.conditional:
+            sampled_y = self._get_one_hot_labels(fs[i]["sampled_labels"])
+          fs[i]["generated"] = self.generator(fs[i]["z"], y=sampled_y, is_training=True)
+        d_losses.append(self._train_discriminator(fs[i], ls[i]))
+      g_loss = self._train_generator(fs[-1], ls[-1])
+    return {"d_losses": d_losses, "g_loss": g_loss}
+
+  # -- inference -----------------------------------------------------------------------------------
+  def generate(self, z, labels=None, use_ema=None):
+    """G(z, y) with is_training=False; EMA weights when g_use_ema (modular_gan.py:266-285)."""
+    use_ema = self._g_use_ema if use_ema is None else use_ema
+    swapped = None
+    if use_ema and self.g_opt.ema is not None:
+      swapped = [p.detach().clone() for p in self.g_opt.params]
+      with torch.no_grad():
+        for p, e in zip(self.g_opt.params, self.g_opt.ema):
+          p.copy_(e)
+    try:
+      with torch.no_grad(), ops.use_store(self.store):
+        y = self._get_one_hot_labels(labels) if self.conditional else None
+        return self.generator(z, y=y, is_training=False)
+    finally:
+      if swapped is not None:
+        with torch.no_grad():
+          for p, s in zip(self.g_opt.params, swapped):
+            p.copy_(s)
+
+  # -- checkpoint state (SURVEY section 5 / App. D naming) -------------------------------------------------
+  def state_dict(self):
+    sd = dict(self.store.state_dict())
+    for opt, tag in ((self.g_opt, "g_opt"), (self.d_opt, "d_opt")):
+      for n, m, v in zip(opt.names, opt.m, opt.v):
+        sd["%s/%s/Adam" % (n, tag)] = m
+        sd["%s/%s/Adam_1" % (n, tag)] = v
+      if opt.ema is not None:
+        for n, e in zip(opt.names, opt.ema):
+          sd[n + "/ExponentialMovingAverage"] = e
+    sd["global_step"] = self.global_step
+    sd["global_step_disc"] = self.global_step_disc
+    return {k: v.detach().clone() for k, v in sd.items()}
+
+  def load_state_dict(self, sd):
+    with torch.no_grad():
+      for name, var in self.store.vars.items():
+        var.copy_(sd[name])
+      for opt, tag in ((self.g_opt, "g_opt"), (self.d_opt, "d_opt")):
+        for n, m, v in zip(opt.names, opt.m, opt.v):
+          m.copy_(sd["%s/%s/Adam" % (n, tag)])
+          v.copy_(sd["%s/%s/Adam_1" % (n, tag)])
+        if opt.ema is not None:
+          for n, e in zip(opt.names, opt.ema):
+            e.copy_(sd[n + "/ExponentialMovingAverage"])
+      self.global_step.copy_(sd["global_step"])
+      self.global_step_disc.copy_(sd["global_step_disc"])

@@ -48,12 +48,19 @@ SIGNATURES = {
     "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, c_sz, vp]),
     "cg_bn_apply": (c_int, [vp, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, c_int, c_int, vp, vp]),
     "cg_bn_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
-    "cg_bn_backward": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_f32, vp, c_int, c_int,
-                               c_int, vp, vp, vp, vp, c_sz, vp]),
+    "cg_bn_backward_reduce": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_f32, vp, c_int,
+                                      c_int, vp, vp, vp, vp, c_sz, vp]),
+    "cg_bn_backward_apply": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_f32, vp, c_int,
+                                     c_int, c_int, vp, vp, vp]),
+    "cg_bn_moments_convert": (c_int, [vp, vp, c_int, c_int, c_f32, vp]),
     "cg_bn_update_moving": (c_int, [vp, vp, vp, vp, c_int, c_f32, vp]),
     "cg_lrelu": (c_int, [vp, c_f32, vp, c_i64, vp]),
     "cg_lrelu_bwd": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
     "cg_axpby": (c_int, [vp, c_f32, vp, c_f32, vp, c_i64, vp]),
+    "cg_axpby_f32": (c_int, [vp, c_f32, vp, c_f32, vp, c_i64, vp]),
+    "cg_axpy_dev": (c_int, [vp, vp, vp, vp, c_i64, vp]),
+    "cg_dot_bf16_workspace_bytes": (c_sz, [c_i64]),
+    "cg_dot_bf16": (c_int, [vp, vp, c_i64, vp, vp, c_sz, vp]),
     "cg_avgpool2": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_avgpool2_bwd": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_maxpool2": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),

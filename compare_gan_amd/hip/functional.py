@@ -1,0 +1,558 @@
+"""torch.autograd plumbing around the HIP kernels: every arithmetic step (forward AND backward) is a
+libcgamd.so launch; autograd only records the graph.  Backward passes of the convolution family
+are themselves expressed through these Functions, so torch.autograd.grad(create_graph=True)
+(WGAN-GP, penalty_lib.py:74-82) differentiates through the first backward with HIP kernels too.
+
+Conventions: activations NHWC bf16; weights fp32 in the reference layouts; fp32 for logits,
+losses, CBN gamma/beta and generator outputs.
+"""
+import torch
+
+from compare_gan_amd.hip import kernels as K
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _bf16(t):
+  """Gradient tensors may arrive as fp32 (fp32-output ops) or non-contiguous views."""
+  if t is None:
+    return None
+  if t.dtype == F32:
+    return K.cast_f32_to_bf16(t.contiguous())
+  return t.contiguous()
+
+
+class ConvSpec(object):
+  """Static description of one gather-convolution call site.
+
+  geom      : cgConvGeom of the FORWARD convolution F (input [N,Hin,Win,Ci] -> [N,Ho,Wo,Co],
+              kernel HWIO [kh,kw,Ci,Co]).
+  transpose : False -> y = F(x);  True -> y = F^T(x) (conv2d_transpose / data gradient; x lives in
+              F's output space).
+  slope_in / slope_out : leaky-ReLU slopes of the input / output gates (None = no gate).
+  out_f32   : fp32 output (logits, images, gradients w.r.t. network inputs).
+  """
+
+  def __init__(self, geom, transpose=False, slope_in=None, slope_out=None, out_f32=False):
+    self.geom = geom
+    self.transpose = transpose
+    self.slope_in = slope_in
+    self.slope_out = slope_out
+    self.out_f32 = out_f32
+
+  def adjoint(self, out_f32=False):
+    return ConvSpec(self.geom, not self.transpose, self.slope_out, self.slope_in, out_f32)
+
+  @property
+  def out_shape(self):
+    g = self.geom
+    return (g.N, g.Hin, g.Win, g.Ci) if self.transpose else (g.N, g.Ho, g.Wo, g.Co)
+
+
+def _run_gconv(spec, x, w, bias, gate_in, gate_out, residual):
+  g = spec.geom
+  if spec.transpose:
+    _, bt = K.weight_prep(w, want_fwd=False, want_bwd=True)
+    geom = K.geom_adjoint(g)
+  else:
+    bt, _ = K.weight_prep(w, want_fwd=True, want_bwd=False)
+    geom = g
+  return K.gconv(geom, x, bt, bias=bias,
+                 gate_in=gate_in if spec.slope_in is not None else None,
+                 slope_in=spec.slope_in or 0.0,
+                 gate_out=gate_out if spec.slope_out is not None else None,
+                 slope_out=spec.slope_out or 0.0, residual=residual, out_f32=spec.out_f32)
+
+
+_SKIP_PARAM_GRADS = [False]
+
+
+class only_input_grads(object):
+  """Context for torch.autograd.grad(outputs, [network input], create_graph=True): the weight /
+  bias gradients of that inner backward are discarded by the engine, so do not compute them."""
+
+  def __enter__(self):
+    self._old = _SKIP_PARAM_GRADS[0]
+    _SKIP_PARAM_GRADS[0] = True
+
+  def __exit__(self, *exc):
+    _SKIP_PARAM_GRADS[0] = self._old
+
+
+class GConvFn(torch.autograd.Function):
+  """y = D(gate_out) * (conv_spec(D(gate_in) * x, w) + bias) + residual.
+
+  gate tensors are constants for autograd (the derivative of a piecewise-linear activation is
+  piecewise constant); gate_in may be x itself (y = conv(lrelu(x)))."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, residual, gate_in, gate_out, spec, dx_f32):
+    x = x.contiguous()
+    y = _run_gconv(spec, x, w, bias, gate_in, gate_out, residual)
+    ctx.spec, ctx.dx_f32 = spec, dx_f32
+    ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+    ctx.save_for_backward(x, w, gate_in, gate_out)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w, gate_in, gate_out = ctx.saved_tensors
+    spec = ctx.spec
+    dy16 = _bf16(dy)
+    need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+    if _SKIP_PARAM_GRADS[0]:
+      need_w = need_b = False
+    dx = dw = db = dr = None
+    if need_r and ctx.has_res:
+      dr = dy16
+    if need_x:
+      aspec = spec.adjoint(out_f32=ctx.dx_f32)
+      dx = GConvFn.apply(dy16, w, None, None, gate_out, gate_in, aspec, False)
+    if need_w or (need_b and ctx.has_bias):
+      want_b = bool(need_b and ctx.has_bias)
+      if torch.is_grad_enabled():
+        dw = GWgradFn.apply(x, dy16, gate_in, gate_out, spec) if need_w else None
+        if want_b:
+          db = K.colsum(_gated(dy16, gate_out, spec.slope_out).reshape(-1, dy16.shape[-1]))
+      else:
+        dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
+    return dx, dw, db, dr, None, None, None, None
+
+
+def _gated(t, gate, slope):
+  if gate is None or slope is None:
+    return t
+  return K.lrelu_bwd(gate, t, slope)
+
+
+def _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b):
+  """dw (+ dbias) for y = conv_spec(D(gate_in) x, w): roles swap for the transposed form."""
+  g = spec.geom
+  gi = gate_in if spec.slope_in is not None else None
+  go = gate_out if spec.slope_out is not None else None
+  if not spec.transpose:
+    dw, db = K.gwgrad(g, x, dy16, gate_in=gi, slope_in=spec.slope_in or 0.0, gate_dy=go,
+                      slope_dy=spec.slope_out or 0.0, want_dbias=want_b)
+    return dw, db
+  # y = F^T(x): dw = Wg_F(in = D(go) dy, "dy" = D(gi) x); dbias = colsum over y's pixels
+  dw, _ = K.gwgrad(g, dy16, x, gate_in=go, slope_in=spec.slope_out or 0.0, gate_dy=gi,
+                   slope_dy=spec.slope_in or 0.0)
+  db = None
+  if want_b:
+    db = K.colsum(_gated(dy16, go, spec.slope_out).reshape(-1, dy16.shape[-1]))
+  return dw, db
+
+
+class GWgradFn(torch.autograd.Function):
+  """dw = Wg_spec(x, dy) as a differentiable node (only built under create_graph=True)."""
+
+  @staticmethod
+  def forward(ctx, x, dy16, gate_in, gate_out, spec):
+    dw, _ = _run_wgrad(spec, x, dy16, gate_in, gate_out, False)
+    ctx.spec = spec
+    ctx.save_for_backward(x, dy16, gate_in, gate_out)
+    return dw
+
+  @staticmethod
+  def backward(ctx, ddw):
+    x, dy16, gate_in, gate_out = ctx.saved_tensors
+    spec = ctx.spec
+    ddw = ddw.contiguous()
+    dx = ddy = None
+    if ctx.needs_input_grad[0]:
+      # d<ddw, Wg(x,dy)>/dx = D(gi) * conv_spec^T(D(go) dy, ddw)
+      dx = GConvFn.apply(dy16, ddw, None, None, gate_out, gate_in, spec.adjoint(), False)
+    if ctx.needs_input_grad[1]:
+      # d/d(dy) = D(go) * conv_spec(D(gi) x, ddw)
+      fwd = ConvSpec(spec.geom, spec.transpose, spec.slope_in, spec.slope_out, False)
+      ddy = GConvFn.apply(x, ddw, None, None, gate_in, gate_out, fwd, False)
+    return dx, ddy, None, None, None
+
+
+def gconv(x, w, bias=None, residual=None, gate_in=None, gate_out=None, spec=None, dx_f32=False):
+  return GConvFn.apply(x, w, bias, residual, gate_in, gate_out, spec, dx_f32)
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral norm
+# ------------------------------------------------------------------------------------------------
+class SpectralNormFn(torch.autograd.Function):
+  """w_bar = w / sigma after one power iteration; updates u_var in place (arch_ops.py:479-535).
+
+  First-order only: the gradient of the rank-one correction itself is not differentiated (no
+  example config combines a gradient penalty with a spectrally normalised D)."""
+
+  @staticmethod
+  def forward(ctx, w, u_var, mode, eps):
+    w2 = w.reshape(-1, w.shape[-1])
+    v, sigma, inv_sigma = K.spectral_norm(w2, u_var.view(-1), mode, eps)
+    wbar = K.scale_f32(w2, inv_sigma).reshape(w.shape)
+    ctx.mode = mode
+    ctx.save_for_backward(w2, u_var.detach().view(-1).clone(), v, sigma)
+    return wbar
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dwbar):
+    w2, u_new, v, sigma = ctx.saved_tensors
+    a_k, b_co = (u_new, v) if ctx.mode == 0 else (v, u_new)
+    dw = K.sn_backward(dwbar.contiguous().reshape(w2.shape), w2, a_k, b_co, sigma)
+    return dw.reshape(dwbar.shape), None, None, None
+
+
+def spectral_norm(w, u_var, mode, eps):
+  return SpectralNormFn.apply(w, u_var, mode, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm (+ ReLU)
+# ------------------------------------------------------------------------------------------------
+class BatchNormActFn(torch.autograd.Function):
+  """y = act((x - mean) * rsqrt(var + eps) * gamma + beta).
+
+  training: mean/var are this batch's moments (returned for the moving-average / accumulator
+  bookkeeping); eval: the given moments are used as constants."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, mean_in, var_in, eps, per_sample, relu, sync_fn):
+    shape = x.shape
+    N, C = shape[0], shape[-1]
+    x3 = x.contiguous().reshape(N, -1, C)
+    batch_stats = mean_in is None
+    if batch_stats:
+      mean, var = K.bn_stats(x3)
+      if sync_fn is not None:
+        mean, var = sync_fn.forward_sync(mean, var)
+    else:
+      mean, var = mean_in, var_in
+    y3 = K.bn_apply(x3, mean, var, eps, gamma, beta, per_sample, relu)
+    ctx.cfg = (eps, per_sample, relu, batch_stats, shape, sync_fn)
+    ctx.save_for_backward(x3, y3, gamma, mean, var)
+    ctx.mark_non_differentiable(mean, var)
+    return y3.reshape(shape), mean, var
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dy, _dm, _dv):
+    x3, y3, gamma, mean, var = ctx.saved_tensors
+    eps, per_sample, relu, batch_stats, shape, sync_fn = ctx.cfg
+    dy3 = _bf16(dy).reshape(x3.shape)
+    dx, dgamma, dbeta = K.bn_backward(
+        x3, y3, dy3, mean, var, eps, gamma, per_sample, relu, batch_stats,
+        want_dgamma=ctx.needs_input_grad[1], want_dbeta=ctx.needs_input_grad[2],
+        sync_fn=sync_fn.backward_sync if sync_fn is not None else None)
+    return dx.reshape(shape), dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, mean=None, var=None, eps=1e-5, per_sample=False, relu=False,
+                   sync_fn=None):
+  return BatchNormActFn.apply(x, gamma, beta, mean, var, eps, per_sample, relu, sync_fn)
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone leaky ReLU (only where the consumer cannot take an input gate)
+# ------------------------------------------------------------------------------------------------
+class LreluFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, slope):
+    x = x.contiguous()
+    ctx.slope = slope
+    ctx.save_for_backward(x)
+    return K.lrelu(x, slope)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, = ctx.saved_tensors
+    return GateFn.apply(_bf16(dy), x, ctx.slope), None
+
+
+class GateFn(torch.autograd.Function):
+  """t * D(gate): self-adjoint in t."""
+
+  @staticmethod
+  def forward(ctx, t, gate, slope):
+    ctx.slope = slope
+    ctx.save_for_backward(gate)
+    return K.lrelu_bwd(gate, t.contiguous(), slope)
+
+  @staticmethod
+  def backward(ctx, d):
+    gate, = ctx.saved_tensors
+    return GateFn.apply(_bf16(d), gate, ctx.slope), None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / reductions
+# ------------------------------------------------------------------------------------------------
+class AvgPool2Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return K.avgpool2(x.contiguous())
+
+  @staticmethod
+  def backward(ctx, dy):
+    return AvgPool2BwdFn.apply(_bf16(dy))
+
+
+class AvgPool2BwdFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, dy):
+    return K.avgpool2_bwd(dy.contiguous())
+
+  @staticmethod
+  def backward(ctx, ddx):
+    return AvgPool2Fn.apply(_bf16(ddx))
+
+
+class MaxPool2Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    x = x.contiguous()
+    ctx.save_for_backward(x)
+    return K.maxpool2(x)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dy):
+    x, = ctx.saved_tensors
+    return K.maxpool2_bwd(x, _bf16(dy))
+
+
+class SpatialReduceFn(torch.autograd.Function):
+  """out[n,c] = scale * sum_hw x * D(gate), gate constant (gate = x gives relu + reduce)."""
+
+  @staticmethod
+  def forward(ctx, x, gate, scale):
+    x = x.contiguous()
+    ctx.scale, ctx.shape = scale, x.shape
+    ctx.save_for_backward(gate)
+    return K.spatial_reduce(x, gate, scale)
+
+  @staticmethod
+  def backward(ctx, dout):
+    gate, = ctx.saved_tensors
+    return SpatialReduceBwdFn.apply(_bf16(dout), gate, ctx.scale, ctx.shape), None, None
+
+
+class SpatialReduceBwdFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, dout, gate, scale, shape):
+    ctx.scale = scale
+    ctx.save_for_backward(gate)
+    return K.spatial_reduce_bwd(gate, dout.contiguous(), shape, scale)
+
+  @staticmethod
+  def backward(ctx, ddx):
+    gate, = ctx.saved_tensors
+    return SpatialReduceFn.apply(_bf16(ddx), gate, ctx.scale), None, None, None
+
+
+def avg_pool2(x):
+  return AvgPool2Fn.apply(x)
+
+
+def max_pool2(x):
+  return MaxPool2Fn.apply(x)
+
+
+def relu_mean(x):
+  hw = x.numel() // (x.shape[0] * x.shape[-1])
+  return SpatialReduceFn.apply(x, x.detach(), 1.0 / hw)
+
+
+def relu_sum(x):
+  return SpatialReduceFn.apply(x, x.detach(), 1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# heads, input staging, projection
+# ------------------------------------------------------------------------------------------------
+class HeadFn(torch.autograd.Function):
+  """fp32 pre-activation -> image in [0,1]: kind 0 sigmoid, 1 (tanh+1)/2."""
+
+  @staticmethod
+  def forward(ctx, x, kind):
+    y = K.head(x.contiguous(), kind)
+    ctx.kind = kind
+    ctx.save_for_backward(y)
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dy):
+    y, = ctx.saved_tensors
+    return K.head_bwd(y, ctx.kind, dy.contiguous()), None
+
+
+class StageImagesFn(torch.autograd.Function):
+  """all_images = concat([images, generated]) * a + b, cast to bf16 (modular_gan.py:657;
+  sndcgan.py:108 folds its `x * 2 - 1` here).  Either part may be None."""
+
+  @staticmethod
+  def forward(ctx, real, fake, a, b):
+    parts = [t for t in (real, fake) if t is not None]
+    n = sum(t.shape[0] for t in parts)
+    out = torch.empty((n,) + tuple(parts[0].shape[1:]), dtype=BF16, device=parts[0].device)
+    off = 0
+    for t in parts:
+      K.cast_f32_to_bf16(t.contiguous(), a, b, out=out[off:off + t.shape[0]])
+      off += t.shape[0]
+    ctx.a = a
+    ctx.n_real = real.shape[0] if real is not None else 0
+    ctx.has_fake = fake is not None
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dy):
+    dfake = None
+    if ctx.has_fake and ctx.needs_input_grad[1]:
+      d = dy[ctx.n_real:].contiguous()
+      if d.dtype == BF16:
+        d = K.cast_bf16_to_f32(d)
+      dfake = K.scale_f32(d, None, ctx.a) if ctx.a != 1.0 else d
+    return None, dfake, None, None
+
+
+def stage_images(real, fake, a=1.0, b=0.0):
+  return StageImagesFn.apply(real, fake, a, b)
+
+
+class CastFn(torch.autograd.Function):
+  """fp32 -> bf16 (z, embeddings) with a straight-through fp32 gradient."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return K.cast_f32_to_bf16(x.contiguous())
+
+  @staticmethod
+  def backward(ctx, dy):
+    return K.cast_bf16_to_f32(dy.contiguous()) if dy.dtype == BF16 else dy
+
+
+class ToF32Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return K.cast_bf16_to_f32(x.contiguous())
+
+  @staticmethod
+  def backward(ctx, dy):
+    return _bf16(dy)
+
+
+class RowDotFn(torch.autograd.Function):
+  """out[b] = sum_c a[b,c] * h[b,c] (projection term, resnet_biggan.py:423)."""
+
+  @staticmethod
+  def forward(ctx, a, h):
+    a, h = a.contiguous(), h.contiguous()
+    ctx.save_for_backward(a, h)
+    return K.rowdot(a, h)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dout):
+    a, h = ctx.saved_tensors
+    da, dh = K.rowdot_bwd(a, h, dout.contiguous(), ctx.needs_input_grad[0],
+                          ctx.needs_input_grad[1])
+    return da, dh
+
+
+class AddF32Fn(torch.autograd.Function):
+  """alpha * a + beta * b on small fp32 tensors (logit + projection; loss + lambda * penalty)."""
+
+  @staticmethod
+  def forward(ctx, a, b, alpha, beta):
+    ctx.ab = (alpha, beta)
+    return K.axpby_f32(a.contiguous(), alpha, b.contiguous(), beta)
+
+  @staticmethod
+  def backward(ctx, d):
+    alpha, beta = ctx.ab
+    d = d.contiguous()
+    da = d if alpha == 1.0 else K.axpby_f32(d, alpha)
+    db = d if beta == 1.0 else K.axpby_f32(d, beta)
+    return da, db, None, None
+
+
+def add_f32(a, b, alpha=1.0, beta=1.0):
+  return AddF32Fn.apply(a, b, alpha, beta)
+
+
+class AttentionFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, theta, phi, g):
+    theta, phi, g = theta.contiguous(), phi.contiguous(), g.contiguous()
+    out, lse = K.attention_fwd(theta, phi, g)
+    ctx.save_for_backward(theta, phi, g, out, lse)
+    return out
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dout):
+    theta, phi, g, out, lse = ctx.saved_tensors
+    return K.attention_bwd(theta, phi, g, out, lse, _bf16(dout))
+
+
+class ScaledResidualFn(torch.autograd.Function):
+  """x + sigma * o with a trainable scalar sigma (arch_ops.py:755-758)."""
+
+  @staticmethod
+  def forward(ctx, x, o, sigma):
+    x, o = x.contiguous(), o.contiguous()
+    ctx.save_for_backward(o, sigma)
+    return K.axpy_dev(x, o, sigma)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dy):
+    o, sigma = ctx.saved_tensors
+    dy16 = _bf16(dy)
+    do = K.axpy_dev(None, dy16, sigma) if ctx.needs_input_grad[1] else None
+    dsig = K.dot_bf16(dy16, o).reshape(sigma.shape) if ctx.needs_input_grad[2] else None
+    return dy16, do, dsig
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / penalties
+# ------------------------------------------------------------------------------------------------
+class GanLossFn(torch.autograd.Function):
+  """(d_loss, d_loss_real, d_loss_fake, g_loss) from fp32 logits [2B,1] (real then fake)."""
+
+  @staticmethod
+  def forward(ctx, logits, kind):
+    losses, dd, dg = K.gan_loss(kind, logits.contiguous())
+    ctx.save_for_backward(dd, dg)
+    ctx.shape = logits.shape
+    return tuple(losses[i].clone() for i in range(4))
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, g_d, g_real, g_fake, g_g):
+    dd, dg = ctx.saved_tensors
+    # only d_loss and g_loss are ever differentiated (modular_gan.py:480-497)
+    out = None
+    for up, base in ((g_d, dd), (g_g, dg)):
+      if up is None:
+        continue
+      term = K.scale_f32(base, up.reshape(1).to(F32).contiguous())
+      out = term if out is None else K.axpby_f32(out, 1.0, term, 1.0)
+    return out.reshape(ctx.shape), None
+
+
+class GradientPenaltyFn(torch.autograd.Function):
+  """mean((sqrt(1e-4 + sum g^2) - 1)^2) over fp32 input gradients g [B, ...]."""
+
+  @staticmethod
+  def forward(ctx, g):
+    g = g.contiguous()
+    slopes, pen = K.gradient_penalty(g)
+    ctx.save_for_backward(g, slopes)
+    return pen.reshape(())
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, up):
+    g, slopes = ctx.saved_tensors
+    return K.gradient_penalty_bwd(g, slopes, up.reshape(1).to(F32).contiguous())

@@ -203,7 +203,8 @@ def bn_apply(x3, mean, var, eps, gamma=None, beta=None, per_sample=False, relu=F
 
 
 def bn_backward(x3, y3, dy3, mean, var, eps, gamma=None, per_sample=False, relu=False,
-                batch_stats=True, want_dgamma=True, want_dbeta=True):
+                batch_stats=True, want_dgamma=True, want_dbeta=True, sync_fn=None):
+    """Two-stage BN backward; sync_fn(m12) all-reduces the per-channel means across replicas."""
     _req(x3, BF16, "x")
     _req(dy3, BF16, "dy")
     _req(y3, BF16, "y", not relu)
@@ -212,12 +213,26 @@ def bn_backward(x3, y3, dy3, mean, var, eps, gamma=None, per_sample=False, relu=
     pshape = (N, C) if per_sample else (C,)
     dgamma = torch.empty(pshape, dtype=F32, device=x3.device) if want_dgamma else None
     dbeta = torch.empty(pshape, dtype=F32, device=x3.device) if want_dbeta else None
+    m12 = torch.empty((2 * C,), dtype=F32, device=x3.device)
     ws = _ws(lib().cg_bn_backward_workspace_bytes(N, HW, C), x3)
-    check(lib().cg_bn_backward(_p(x3), _p(y3), _p(dy3), N, HW, C, _p(mean), _p(var), float(eps),
-                               _p(gamma), int(per_sample), int(relu), int(batch_stats), _p(dx),
-                               _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream()),
-          "cg_bn_backward")
+    check(lib().cg_bn_backward_reduce(_p(x3), _p(y3), _p(dy3), N, HW, C, _p(mean), _p(var),
+                                      float(eps), _p(gamma), int(per_sample), int(relu),
+                                      _p(dgamma), _p(dbeta), _p(m12), _p(ws), ws.numel(),
+                                      _stream()), "cg_bn_backward_reduce")
+    if sync_fn is not None and batch_stats:
+        m12 = sync_fn(m12)
+    check(lib().cg_bn_backward_apply(_p(x3), _p(y3), _p(dy3), N, HW, C, _p(mean), _p(var),
+                                     float(eps), _p(gamma), int(per_sample), int(relu),
+                                     int(batch_stats), _p(m12), _p(dx), _stream()),
+          "cg_bn_backward_apply")
     return dx, dgamma, dbeta
+
+
+def bn_moments_convert(mean, second, to_variance, scale=1.0):
+    _req(mean, F32, "mean")
+    _req(second, F32, "second")
+    check(lib().cg_bn_moments_convert(_p(mean), _p(second), mean.numel(), int(to_variance),
+                                      float(scale), _stream()), "cg_bn_moments_convert")
 
 
 def bn_update_moving(moving_mean, moving_var, mean, var, decay):
@@ -250,6 +265,36 @@ def axpby(a, alpha, b=None, beta=0.0):
     out = torch.empty_like(a)
     check(lib().cg_axpby(_p(a), float(alpha), _p(b), float(beta), _p(out), a.numel(), _stream()),
           "cg_axpby")
+    return out
+
+
+def axpby_f32(a, alpha, b=None, beta=0.0):
+    _req(a, F32, "a")
+    _req(b, F32, "b", True)
+    out = torch.empty_like(a)
+    check(lib().cg_axpby_f32(_p(a), float(alpha), _p(b), float(beta), _p(out), a.numel(),
+                             _stream()), "cg_axpby_f32")
+    return out
+
+
+def axpy_dev(x, o, sigma):
+    """x + sigma * o (bf16) with sigma a 1-element fp32 device tensor; x may be None."""
+    _req(o, BF16, "o")
+    _req(x, BF16, "x", True)
+    _req(sigma, F32, "sigma")
+    out = torch.empty_like(o)
+    check(lib().cg_axpy_dev(_p(x), _p(o), _p(sigma), _p(out), o.numel(), _stream()),
+          "cg_axpy_dev")
+    return out
+
+
+def dot_bf16(a, b):
+    _req(a, BF16, "a")
+    _req(b, BF16, "b")
+    out = torch.empty((1,), dtype=F32, device=a.device)
+    ws = _ws(lib().cg_dot_bf16_workspace_bytes(a.numel()), a)
+    check(lib().cg_dot_bf16(_p(a), _p(b), a.numel(), _p(out), _p(ws), ws.numel(), _stream()),
+          "cg_dot_bf16")
     return out
 
 
@@ -467,19 +512,22 @@ def gradient_penalty_bwd(g, slopes, upstream):
 # optimiser / counters / rng
 # ------------------------------------------------------------------------------------------------
 class AdamTable(object):
-    """Device-resident cgAdamEntry table for a fixed list of (param, grad, m, v, ema) tensors."""
+    """Device-resident cgAdamEntry table for a fixed list of (param, grad, m, v, ema) tensors.
+
+    The table lives at a stable device address; set_grads() re-points the gradient column (the
+    autograd engine hands out fresh gradient tensors every step) and re-uploads it."""
 
     def __init__(self, params, grads, ms, vs, emas=None):
         n = len(params)
-        entries = (_lib.AdamEntry * n)()
+        self.entries = (_lib.AdamEntry * n)()
         chunk = 0
         offs = []
         off = 0
         for i in range(n):
-            for t in (params[i], grads[i], ms[i], vs[i]):
+            for t in (params[i], ms[i], vs[i]):
                 _req(t, F32, "adam tensor")
-            e = entries[i]
-            e.param, e.grad = params[i].data_ptr(), grads[i].data_ptr()
+            e = self.entries[i]
+            e.param = params[i].data_ptr()
             e.m, e.v = ms[i].data_ptr(), vs[i].data_ptr()
             e.ema = emas[i].data_ptr() if emas is not None and emas[i] is not None else None
             e.n = params[i].numel()
@@ -491,10 +539,26 @@ class AdamTable(object):
         self.total_chunks = chunk
         self.total_elems = off
         dev = params[0].device
-        raw = bytes(entries)
-        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.table = torch.empty(ctypes.sizeof(self.entries), dtype=torch.uint8, device=dev)
         self.offsets = torch.tensor(offs, dtype=torch.int64).to(dev)
-        self._keep = (params, grads, ms, vs, emas)
+        self._keep = (params, ms, vs, emas)
+        self._grad_ptrs = None
+        self.set_grads(grads)
+
+    def set_grads(self, grads):
+        ptrs = tuple(g.data_ptr() for g in grads)
+        for g, e in zip(grads, self.entries):
+            _req(g, F32, "grad")
+            if g.numel() != e.n:
+                raise ValueError("gradient has %d elements, parameter %d" % (g.numel(), e.n))
+        self._keep_grads = grads
+        if ptrs == self._grad_ptrs:
+            return
+        for p, e in zip(ptrs, self.entries):
+            e.grad = p
+        host = torch.frombuffer(bytearray(bytes(self.entries)), dtype=torch.uint8)
+        self.table.copy_(host)
+        self._grad_ptrs = ptrs
 
     def adam(self, lr, beta1, beta2, eps, grad_scale, step, ema_decay=0.0, ema_start=0):
         check(lib().cg_adam_multi(_p(self.table), self.n, self.total_chunks, float(lr),

@@ -1,0 +1,44 @@
+"""Deterministic stateless random numbers for ops inside the training step.
+
+Reference: compare_gan/tpu/tpu_random.py:54-154 -- every random op gets a stable id derived from
+its name and is re-keyed per training step and per replica, so a step's randomness is reproducible
+and differs across steps and cores (tpu_random_test.py:87-168).  Here: Philox4x32-10 in a HIP
+kernel keyed by (seed, op id), counter = (element, replica, device-resident step), which keeps the
+whole step hipGraph-capturable (the step is read on the device).
+"""
+import hashlib
+
+from compare_gan_amd.hip import kernels as K
+from compare_gan_amd.tpu import tpu_ops
+
+_STATE = {"seed": 0, "step": None}
+
+
+def _op_id(name):
+  """tpu_random.py:81-86: sha512(name) mod (2^31 - 1)."""
+  return int(hashlib.sha512(name.encode("utf-8")).hexdigest(), 16) % (2 ** 31 - 1)
+
+
+def set_random_offset(seed, step_tensor):
+  """The analogue of set_random_offset_from_features (tpu_random.py:54-78): binds the step counter
+  (device int64 tensor) and the run seed used by subsequent calls."""
+  _STATE["seed"] = int(seed)
+  _STATE["step"] = step_tensor
+
+
+def uniform(shape, name, minval=0.0, maxval=1.0, device=None):
+  step = _STATE["step"]
+  return K.random(0, minval, maxval, _STATE["seed"], _op_id(name), tpu_ops.replica_id(), step,
+                  tuple(shape), device if device is not None else step.device)
+
+
+def normal(shape, name, mean=0.0, stddev=1.0, device=None):
+  step = _STATE["step"]
+  return K.random(1, mean, stddev, _STATE["seed"], _op_id(name), tpu_ops.replica_id(), step,
+                  tuple(shape), device if device is not None else step.device)
+
+
+def labels(n, num_classes, name, device=None):
+  step = _STATE["step"]
+  return K.random_labels(num_classes, _STATE["seed"], _op_id(name), tpu_ops.replica_id(), step, n,
+                         device if device is not None else step.device)

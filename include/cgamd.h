@@ -140,16 +140,26 @@ int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var, voi
 int cg_bn_apply(const void* x, int N, int HW, int C, const float* mean, const float* var,
                 float eps, const float* gamma, const float* beta, int per_sample, int relu,
                 void* y, cgStream stream);
-/* Backward of cg_bn_apply in training mode (mean/var are functions of x):
- *   dz = dy * (y > 0) if relu;  dbeta = sum dz;  dgamma = sum dz * xhat  (per [C] or per [N,C]);
- *   dx = rstd * (g*dz - mean_n(g*dz) - xhat * mean_n(g*dz*xhat))   when batch_stats != 0
- *   dx = rstd * g * dz                                              when batch_stats == 0 (eval).
+/* Backward of cg_bn_apply, in two stream-ordered stages so that data-parallel sync-BN can
+ * all-reduce the per-channel means in between (tpu_ops.py:94-125 applied to the backward sums):
+ *   reduce: dz = dy * (y > 0) if relu;  dbeta = sum dz;  dgamma = sum dz * xhat (per [C] or [N,C]);
+ *           m12[0:C] = mean_n(g*dz), m12[C:2C] = mean_n(g*dz*xhat)   (local batch means)
+ *   apply : dx = rstd * (g*dz - m12[0] - xhat * m12[1])   when batch_stats != 0
+ *           dx = rstd * g * dz                              when batch_stats == 0 (eval; m12 unused)
  * dgamma/dbeta may be NULL.  ws >= cg_bn_backward_workspace_bytes(N, HW, C). */
 size_t cg_bn_backward_workspace_bytes(int N, int HW, int C);
-int cg_bn_backward(const void* x, const void* y, const void* dy, int N, int HW, int C,
-                   const float* mean, const float* var, float eps, const float* gamma,
-                   int per_sample, int relu, int batch_stats, void* dx, float* dgamma,
-                   float* dbeta, void* ws, size_t ws_bytes, cgStream stream);
+int cg_bn_backward_reduce(const void* x, const void* y, const void* dy, int N, int HW, int C,
+                          const float* mean, const float* var, float eps, const float* gamma,
+                          int per_sample, int relu, float* dgamma, float* dbeta, float* m12,
+                          void* ws, size_t ws_bytes, cgStream stream);
+int cg_bn_backward_apply(const void* x, const void* y, const void* dy, int N, int HW, int C,
+                         const float* mean, const float* var, float eps, const float* gamma,
+                         int per_sample, int relu, int batch_stats, const float* m12, void* dx,
+                         cgStream stream);
+/* In-place helpers around the sync-BN all-reduce: to_variance == 0: second <- var + mean^2;
+ * to_variance == 1: mean *= scale; second *= scale; second <- second - mean^2. */
+int cg_bn_moments_convert(float* mean, float* second, int C, int to_variance, float scale,
+                          cgStream stream);
 /* Moving averages m <- m - (1-decay) * (m - batch)  (arch_ops.py:105-114), both vectors [C]. */
 int cg_bn_update_moving(float* moving_mean, float* moving_var, const float* mean,
                         const float* var, int C, float decay, cgStream stream);
@@ -164,6 +174,18 @@ int cg_lrelu_bwd(const void* x, const void* dy, float slope, void* dx, int64_t n
 /* out = a*alpha + b*beta (bf16), b may be NULL. */
 int cg_axpby(const void* a, float alpha, const void* b, float beta, void* out, int64_t n,
              cgStream stream);
+/* out = alpha*a + beta*b on fp32 (logit + projection term, resnet_biggan.py:423;
+ * d_loss += lambda * penalty, modular_gan.py:670).  b may be NULL. */
+int cg_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, int64_t n,
+                 cgStream stream);
+/* out = x + (*sigma) * o on bf16 with a device-resident trainable scalar
+ * (arch_ops.py:755-758 `x + sigma * attn_g`); x may be NULL (out = sigma * o). */
+int cg_axpy_dev(const void* x, const void* o, const float* sigma, void* out, int64_t n,
+                cgStream stream);
+/* <a, b> of two bf16 arrays into one fp32 (gradient of that scalar). */
+size_t cg_dot_bf16_workspace_bytes(int64_t n);
+int cg_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* ws, size_t ws_bytes,
+                cgStream stream);
 /* 2x2 average pooling, stride 2 (resnet_ops.py:131-133), x [N,H,W,C] -> y [N,H/2,W/2,C]. */
 int cg_avgpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream);
 int cg_avgpool2_bwd(const void* dy, int N, int H, int W, int C, void* dx, cgStream stream);

@@ -21,6 +21,30 @@ import torch
 import torch.nn.functional as F
 
 
+def _bf16(t):
+  return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundBoth(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return _bf16(x)
+
+  @staticmethod
+  def backward(ctx, g):
+    return _RoundBoth.apply(g)
+
+
+class _RoundFwd(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return _bf16(x)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g
+
+
 # ------------------------------------------------------------------------------------------------
 # Variable store (tf.get_variable / tf.variable_scope(reuse=AUTO_REUSE) stand-in)
 # ------------------------------------------------------------------------------------------------
@@ -28,13 +52,34 @@ class VarStore(object):
   """name -> tensor, created on first use in call order (abstract_arch.py:71-74 AUTO_REUSE)."""
 
   def __init__(self, dtype=torch.float64, seed=0, weights_initializer="normal",
-               weights_stddev=0.02):
+               weights_stddev=0.02, emulate_bf16=False):
+    # emulate_bf16: snap every tensor the HIP path STORES in bf16 (activations, their gradients,
+    # MFMA weight operands) to the bf16 grid, keeping all arithmetic in fp64.  ReLU networks have
+    # discontinuous gradients, so the exact-fp64 oracle and a bf16 pipeline disagree by O(sqrt(eps))
+    # through flipped ReLU masks; this mode removes that effect and isolates real defects.
+    self.emulate_bf16 = emulate_bf16
     self.vars = {}
     self.trainable = []
     self.dtype = dtype
     self.gen = torch.Generator().manual_seed(seed)
     self.weights_initializer = weights_initializer  # gin "weights.initializer"
     self.weights_stddev = weights_stddev            # gin "weights.stddev"
+
+  def q(self, t):
+    """Activation / gradient storage rounding (identity unless emulate_bf16)."""
+    return _RoundBoth.apply(t) if self.emulate_bf16 else t
+
+  def q_in(self, t):
+    """Rounding of an op INPUT that is already stored in bf16: idempotent in the forward pass; in
+    the backward pass it is where the consumer's input-gradient gets stored (bf16 unless
+    round_input_grads is switched off to model fp32 gradient tensors)."""
+    if not self.emulate_bf16:
+      return t
+    return _RoundBoth.apply(t) if getattr(self, "round_input_grads", True) else _RoundFwd.apply(t)
+
+  def qw(self, w):
+    """MFMA weight-operand rounding: forward only (weight gradients stay fp32)."""
+    return _RoundFwd.apply(w) if self.emulate_bf16 else w
 
   def get(self, name, shape, init, trainable=True):
     if name not in self.vars:
@@ -203,35 +248,43 @@ class SNConfig(object):
 
 
 def linear(vs, x, output_size, scope, sn_cfg, bias_start=0.0, use_sn=False, use_bias=True,
-           kernel_init=None):
+           kernel_init=None, out_f32=False):
+  """out_f32 marks outputs the HIP path keeps in fp32 (logits, CBN gamma/beta): no storage
+  rounding in emulate_bf16 mode."""
   kernel = vs.get(scope + "/kernel", (x.shape[1], output_size),
                   kernel_init or vs.weight_init())
   if use_sn:
     kernel = spectral_norm(vs, kernel, scope + "/kernel", sn_cfg.epsilon, sn_cfg.singular_value)
-  out = x @ kernel
+  out = vs.q_in(x) @ vs.qw(kernel)
   if use_bias:
     out = out + vs.get(scope + "/bias", (output_size,), vs.const_init(bias_start))
-  return out
+  return out if out_f32 else vs.q(out)
 
 
-def conv2d(vs, x, output_dim, k_h, k_w, d_h, d_w, name, sn_cfg, use_sn=False, use_bias=True):
+def conv2d(vs, x, output_dim, k_h, k_w, d_h, d_w, name, sn_cfg, use_sn=False, use_bias=True,
+           residual=None, out_f32=False):
+  """`residual` is added before the (emulated) storage rounding, as the fused HIP epilogue does;
+  in exact arithmetic conv + bias + residual is the reference's `output += shortcut`."""
   w = vs.get(name + "/kernel", (k_h, k_w, x.shape[-1], output_dim), vs.weight_init())
   if use_sn:
     w = spectral_norm(vs, w, name + "/kernel", sn_cfg.epsilon, sn_cfg.singular_value)
   assert d_h == d_w
-  out = conv2d_same(x, w, d_h)
+  out = conv2d_same(vs.q_in(x), vs.qw(w), d_h)
   if use_bias:
     out = out + vs.get(name + "/bias", (output_dim,), vs.const_init(0.0))
-  return out
+  if residual is not None:
+    out = out + residual
+  return out if out_f32 else vs.q(out)
 
 
-def deconv2d(vs, x, output_shape, k_h, k_w, d_h, d_w, name, sn_cfg, use_sn=False):
+def deconv2d(vs, x, output_shape, k_h, k_w, d_h, d_w, name, sn_cfg, use_sn=False, out_f32=False):
   w = vs.get(name + "/kernel", (k_h, k_w, output_shape[-1], x.shape[-1]), vs.weight_init())
   if use_sn:
     w = spectral_norm(vs, w, name + "/kernel", sn_cfg.epsilon, sn_cfg.singular_value)
   assert d_h == d_w
-  out = conv2d_transpose_same(x, w, (output_shape[1], output_shape[2]), d_h)
-  return out + vs.get(name + "/bias", (output_shape[-1],), vs.const_init(0.0))
+  out = conv2d_transpose_same(vs.q_in(x), vs.qw(w), (output_shape[1], output_shape[2]), d_h)
+  out = out + vs.get(name + "/bias", (output_shape[-1],), vs.const_init(0.0))
+  return out if out_f32 else vs.q(out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -301,42 +354,55 @@ def standardize_batch(vs, x, is_training, scope, bn_cfg):
   return out
 
 
-def batch_norm(vs, x, is_training, name, bn_cfg, center=True, scale=True):
+def _finish_bn(vs, out, relu):
+  """tf.nn.relu follows every BN of the example generators (resnet_ops.py:165,175); the HIP kernel
+  stores relu(bn(x)) once, so the storage rounding sits after the ReLU."""
+  if relu:
+    out = torch.relu(out)
+  return vs.q(out) if getattr(vs, "round_bn_output_grads", True) else vs.qw(out)
+
+
+def batch_norm(vs, x, is_training, name, bn_cfg, center=True, scale=True, relu=False):
   """arch_ops.py:327-367 (name = full scope, e.g. 'generator/B1/bn1')."""
-  out = standardize_batch(vs, x, is_training, name + "/", bn_cfg)
+  out = standardize_batch(vs, vs.q_in(x), is_training, name + "/", bn_cfg)
   c = x.shape[-1]
   if scale:
     out = out * vs.get(name + "/gamma", (c,), vs.const_init(1.0))
   if center:
     out = out + vs.get(name + "/beta", (c,), vs.const_init(0.0))
-  return out
+  return _finish_bn(vs, out, relu)
 
 
-def conditional_batch_norm(vs, x, y, is_training, use_sn, name, bn_cfg, sn_cfg, use_bias=False):
+def conditional_batch_norm(vs, x, y, is_training, use_sn, name, bn_cfg, sn_cfg, use_bias=False,
+                           relu=False):
   """arch_ops.py:423-445: gamma = linear(y), beta = linear(y), NO +1 offset."""
   if y is None:
     raise ValueError("You must provide y for conditional batch normalization.")
   if y.dim() != 2:
     raise ValueError("Conditioning must have rank 2.")
-  out = standardize_batch(vs, x, is_training, name + "/", bn_cfg)
+  out = standardize_batch(vs, vs.q_in(x), is_training, name + "/", bn_cfg)
   c = x.shape[-1]
-  gamma = linear(vs, y, c, name + "/condition/gamma", sn_cfg, use_sn=use_sn, use_bias=use_bias)
-  beta = linear(vs, y, c, name + "/condition/beta", sn_cfg, use_sn=use_sn, use_bias=use_bias)
-  return out * gamma.reshape(-1, 1, 1, c) + beta.reshape(-1, 1, 1, c)
+  gamma = linear(vs, y, c, name + "/condition/gamma", sn_cfg, use_sn=use_sn, use_bias=use_bias,
+                 out_f32=True)
+  beta = linear(vs, y, c, name + "/condition/beta", sn_cfg, use_sn=use_sn, use_bias=use_bias,
+                out_f32=True)
+  return _finish_bn(vs, out * gamma.reshape(-1, 1, 1, c) + beta.reshape(-1, 1, 1, c), relu)
 
 
-def self_modulated_batch_norm(vs, x, z, is_training, use_sn, name, bn_cfg, sn_cfg, num_hidden=32):
+def self_modulated_batch_norm(vs, x, z, is_training, use_sn, name, bn_cfg, sn_cfg, num_hidden=32,
+                              relu=False):
   """arch_ops.py:370-420."""
   if z is None:
     raise ValueError("You must provide z for self modulation.")
-  out = standardize_batch(vs, x, is_training, name + "/", bn_cfg)
+  out = standardize_batch(vs, vs.q_in(x), is_training, name + "/", bn_cfg)
   c = x.shape[-1]
   h = z
   if num_hidden > 0:
     h = torch.relu(linear(vs, h, num_hidden, name + "/sbn/hidden", sn_cfg, use_sn=use_sn))
-  gamma = linear(vs, h, c, name + "/sbn/gamma", sn_cfg, bias_start=1.0, use_sn=use_sn)
-  beta = linear(vs, h, c, name + "/sbn/beta", sn_cfg, use_sn=use_sn)
-  return out * gamma.reshape(-1, 1, 1, c) + beta.reshape(-1, 1, 1, c)
+  gamma = linear(vs, h, c, name + "/sbn/gamma", sn_cfg, bias_start=1.0, use_sn=use_sn,
+                 out_f32=True)
+  beta = linear(vs, h, c, name + "/sbn/beta", sn_cfg, use_sn=use_sn, out_f32=True)
+  return _finish_bn(vs, out * gamma.reshape(-1, 1, 1, c) + beta.reshape(-1, 1, 1, c), relu)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -352,8 +418,8 @@ def non_local_block(vs, x, name, use_sn, sn_cfg):
   attn = torch.softmax(theta @ phi.transpose(1, 2), dim=-1)
   g = conv2d(vs, x, cg, 1, 1, 1, 1, name + "/conv2d_g", sn_cfg, use_sn, use_bias=False)
   g = max_pool2(g).reshape(n, h * w // 4, cg)
-  attn_g = (attn @ g).reshape(n, h, w, cg)
+  attn_g = vs.q((attn @ g).reshape(n, h, w, cg))
   sigma = vs.get(name + "/sigma", (), vs.const_init(0.0))
   attn_g = conv2d(vs, attn_g, c, 1, 1, 1, 1, name + "/conv2d_attn_g", sn_cfg, use_sn,
                   use_bias=False)
-  return x + sigma * attn_g
+  return vs.q(x + sigma * attn_g)

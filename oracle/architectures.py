@@ -29,26 +29,29 @@ class ArchConfig(object):
     self.arch_kwargs = arch_kwargs
 
 
-def _batch_norm(vs, cfg, x, name, z=None, y=None, is_training=True, use_sn=None):
-  """abstract_arch.py:76-83 / :121-128 dispatch via call_with_accepted_args."""
+def _batch_norm(vs, cfg, x, name, z=None, y=None, is_training=True, use_sn=None, relu=False):
+  """abstract_arch.py:76-83 / :121-128 dispatch via call_with_accepted_args; relu=True is the
+  tf.nn.relu that follows the call in every block (kept inside so that emulate_bf16 rounds once)."""
   fn = cfg.batch_norm_fn
   if fn is None or fn == "no_batch_norm":
-    return x
+    return torch.relu(x) if relu else x
   if use_sn is None:
     use_sn = cfg.spectral_norm
   if fn == "batch_norm":
-    return ops.batch_norm(vs, x, is_training, name, cfg.bn_cfg)
+    return ops.batch_norm(vs, x, is_training, name, cfg.bn_cfg, relu=relu)
   if fn == "conditional_batch_norm":
     return ops.conditional_batch_norm(vs, x, y, is_training, use_sn, name, cfg.bn_cfg, cfg.sn_cfg,
-                                      cfg.cbn_use_bias)
+                                      cfg.cbn_use_bias, relu=relu)
   if fn == "self_modulated_batch_norm":
     return ops.self_modulated_batch_norm(vs, x, z, is_training, use_sn, name, cfg.bn_cfg,
-                                         cfg.sn_cfg, cfg.sbn_num_hidden)
+                                         cfg.sn_cfg, cfg.sbn_num_hidden, relu=relu)
   raise ValueError("unknown batch_norm_fn %r" % fn)
 
 
-def _get_conv(vs, cfg, x, in_ch, out_ch, scale, suffix, scope, kernel=(3, 3)):
-  """resnet_ops.py:112-134."""
+def _get_conv(vs, cfg, x, in_ch, out_ch, scale, suffix, scope, kernel=(3, 3), residual=None,
+              pool=True):
+  """resnet_ops.py:112-134.  residual / pool=False let the caller form pool(conv2 + shortcut),
+  which equals the reference's pool(conv2) + pool(shortcut) (average pooling is linear)."""
   if x.shape[-1] != in_ch:
     raise ValueError("Unexpected number of input channels.")
   if scale not in ("up", "down", "none"):
@@ -58,9 +61,9 @@ def _get_conv(vs, cfg, x, in_ch, out_ch, scale, suffix, scope, kernel=(3, 3)):
     out = ops.unpool(out)
   name = "{}/{}_{}".format(scope, "same" if scale == "none" else scale, suffix)
   out = ops.conv2d(vs, out, out_ch, kernel[0], kernel[1], 1, 1, name, cfg.sn_cfg,
-                   use_sn=cfg.spectral_norm)
-  if scale == "down":
-    out = ops.avg_pool2(out)
+                   use_sn=cfg.spectral_norm, residual=residual)
+  if scale == "down" and pool:
+    out = vs.q(ops.avg_pool2(out))
   return out
 
 
@@ -70,14 +73,16 @@ def resnet_block(vs, cfg, x, scope, in_ch, out_ch, scale, is_gen_block, z, y, is
     raise ValueError("Unexpected number of input channels.")
   scale1 = scale if is_gen_block else "none"
   scale2 = "none" if is_gen_block else scale
-  shortcut = _get_conv(vs, cfg, x, in_ch, out_ch, scale, "conv_shortcut", scope)
-  out = _batch_norm(vs, cfg, x, scope + "/bn1", z=z, y=y, is_training=is_training)
-  out = torch.relu(out)
+  shortcut = _get_conv(vs, cfg, x, in_ch, out_ch, scale, "conv_shortcut", scope, pool=False)
+  out = _batch_norm(vs, cfg, x, scope + "/bn1", z=z, y=y, is_training=is_training, relu=True)
   out = _get_conv(vs, cfg, out, in_ch, out_ch, scale1, "conv1", scope)
-  out = _batch_norm(vs, cfg, out, scope + "/bn2", z=z, y=y, is_training=is_training)
-  out = torch.relu(out)
-  out = _get_conv(vs, cfg, out, out_ch, out_ch, scale2, "conv2", scope)
-  return out + shortcut
+  out = _batch_norm(vs, cfg, out, scope + "/bn2", z=z, y=y, is_training=is_training, relu=True)
+  # output += shortcut (resnet_ops.py:181), pooled once when the block downsamples
+  out = _get_conv(vs, cfg, out, out_ch, out_ch, scale2, "conv2", scope, residual=shortcut,
+                  pool=False)
+  if scale == "down":
+    out = vs.q(ops.avg_pool2(out))
+  return out
 
 
 def biggan_block(vs, cfg, x, scope, in_ch, out_ch, scale, is_gen_block, z, y, is_training,
@@ -88,14 +93,17 @@ def biggan_block(vs, cfg, x, scope, in_ch, out_ch, scale, is_gen_block, z, y, is
         in_ch, x.shape[-1]))
   scale1 = scale if is_gen_block else "none"
   scale2 = "none" if is_gen_block else scale
-  out = _batch_norm(vs, cfg, x, scope + "/bn1", z=z, y=y, is_training=is_training)
-  out = torch.relu(out)
+  out = _batch_norm(vs, cfg, x, scope + "/bn1", z=z, y=y, is_training=is_training, relu=True)
   out = _get_conv(vs, cfg, out, in_ch, out_ch, scale1, "conv1", scope)
-  out = _batch_norm(vs, cfg, out, scope + "/bn2", z=z, y=y, is_training=is_training)
-  out = torch.relu(out)
+  out = _batch_norm(vs, cfg, out, scope + "/bn2", z=z, y=y, is_training=is_training, relu=True)
   out = _get_conv(vs, cfg, out, out_ch, out_ch, scale2, "conv2", scope)
   if add_shortcut:
-    out = out + _get_conv(vs, cfg, x, in_ch, out_ch, scale, "conv_shortcut", scope, kernel=(1, 1))
+    sc_in = x
+    if scale == "down":
+      # pool(conv1x1(x)) == conv1x1(pool(x)): average pooling commutes with a 1x1 convolution
+      sc_in = vs.q(ops.avg_pool2(x))
+    out = _get_conv(vs, cfg, sc_in, in_ch, out_ch, scale, "conv_shortcut", scope, kernel=(1, 1),
+                    residual=out, pool=False)
   return out
 
 
@@ -127,10 +135,9 @@ def resnet_cifar_generator(vs, cfg, z, y, is_training, image_shape=(32, 32, 3)):
   for b in range(3):
     out = resnet_block(vs, cfg, out, "%s/B%d" % (s, b + 1), 256, 256, "up", True,
                        z_per_block[b], y_per_block[b], is_training)
-  out = _batch_norm(vs, cfg, out, s + "/final_norm", z=z, y=y, is_training=is_training)
-  out = torch.relu(out)
+  out = _batch_norm(vs, cfg, out, s + "/final_norm", z=z, y=y, is_training=is_training, relu=True)
   out = ops.conv2d(vs, out, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg,
-                   use_sn=cfg.spectral_norm)
+                   use_sn=cfg.spectral_norm, out_f32=True)
   return torch.sigmoid(out)
 
 
@@ -145,8 +152,9 @@ def resnet_cifar_discriminator(vs, cfg, x, y, is_training):
     out = resnet_block(vs, cfg, out, "%s/B%d" % (s, b + 1), colors if b == 0 else 128, 128,
                        "down" if b <= 1 else "none", False, None, y, is_training)
   out = torch.relu(out)
-  h = out.mean(dim=(1, 2))
-  logit = ops.linear(vs, h, 1, s + "/disc_final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm)
+  h = vs.q(out.mean(dim=(1, 2)))
+  logit = ops.linear(vs, h, 1, s + "/disc_final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm,
+                     out_f32=True)
   if project_y:
     if y is None:
       raise ValueError("You must provide class information y to project.")
@@ -176,9 +184,9 @@ def resnet5_generator(vs, cfg, z, y, is_training, image_shape=(128, 128, 3)):
     net = resnet_block(vs, cfg, net, "%s/B%d" % (s, b + 1), ch * channels[b],
                        ch * channels[b + 1], "up" if b < up_layers else "none", True, z, y,
                        is_training)
-  net = _batch_norm(vs, cfg, net, s + "/final_norm", z=z, y=y, is_training=is_training)
-  net = torch.relu(net)
-  net = ops.conv2d(vs, net, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg)
+  net = _batch_norm(vs, cfg, net, s + "/final_norm", z=z, y=y, is_training=is_training, relu=True)
+  net = ops.conv2d(vs, net, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg,
+                   out_f32=True)
   return torch.sigmoid(net)
 
 
@@ -194,8 +202,9 @@ def resnet5_discriminator(vs, cfg, x, y, is_training):
     out = resnet_block(vs, cfg, out, "%s/B%d" % (s, b + 1), ch * channels[b],
                        ch * channels[b + 1], "down", False, None, y, is_training)
   out = torch.relu(out)
-  pre = out.mean(dim=(1, 2))
-  logit = ops.linear(vs, pre, 1, s + "/disc_final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm)
+  pre = vs.q(out.mean(dim=(1, 2)))
+  logit = ops.linear(vs, pre, 1, s + "/disc_final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm,
+                     out_f32=True)
   return torch.sigmoid(logit), logit, pre
 
 
@@ -245,10 +254,9 @@ def biggan_generator(vs, cfg, z, y, is_training, image_shape=(128, 128, 3)):
                        z_per_block[b], y_per_block[b], is_training)
     if name in attn_blocks:
       net = ops.non_local_block(vs, net, s + "/non_local_block", cfg.spectral_norm, cfg.sn_cfg)
-  net = ops.batch_norm(vs, net, is_training, s + "/final_norm", cfg.bn_cfg)  # unconditional :295
-  net = torch.relu(net)
+  net = ops.batch_norm(vs, net, is_training, s + "/final_norm", cfg.bn_cfg, relu=True)  # :295
   net = ops.conv2d(vs, net, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg,
-                   use_sn=cfg.spectral_norm)
+                   use_sn=cfg.spectral_norm, out_f32=True)
   return (torch.tanh(net) + 1.0) / 2.0
 
 
@@ -276,8 +284,9 @@ def biggan_discriminator(vs, cfg, x, y, is_training):
     if name in attn_blocks:
       net = ops.non_local_block(vs, net, s + "/non_local_block", cfg.spectral_norm, cfg.sn_cfg)
   net = torch.relu(net)
-  h = net.sum(dim=(1, 2))
-  logit = ops.linear(vs, h, 1, s + "/final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm)
+  h = vs.q(net.sum(dim=(1, 2)))
+  logit = ops.linear(vs, h, 1, s + "/final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm,
+                     out_f32=True)
   if project_y:
     if y is None:
       raise ValueError("You must provide class information y to project.")
@@ -285,7 +294,7 @@ def biggan_discriminator(vs, cfg, x, y, is_training):
     if cfg.spectral_norm:
       kernel = ops.spectral_norm(vs, kernel, s + "/embedding_fc/kernel", cfg.sn_cfg.epsilon,
                                  cfg.sn_cfg.singular_value)
-    logit = logit + ((y @ kernel) * h).sum(dim=1, keepdim=True)
+    logit = logit + (vs.q(vs.q(y) @ vs.qw(kernel)) * h).sum(dim=1, keepdim=True)
   return torch.sigmoid(logit), logit, h
 
 
@@ -307,14 +316,16 @@ def dcgan_generator(vs, cfg, z, y, is_training, image_shape=(64, 64, 3)):
   h16, w16 = _half(h8), _half(w8)
   net = ops.linear(vs, z, gf * 8 * h16 * w16, s + "/g_fc1", cfg.sn_cfg)
   net = net.reshape(-1, h16, w16, gf * 8)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn1", z=z, y=y, is_training=is_training))
+  bn = lambda t, nm: _batch_norm(vs, cfg, t, s + nm, z=z, y=y, is_training=is_training, relu=True)
+  net = bn(net, "/g_bn1")
   net = ops.deconv2d(vs, net, [bs, h8, w8, gf * 4], 5, 5, 2, 2, s + "/g_dc1", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn2", z=z, y=y, is_training=is_training))
+  net = bn(net, "/g_bn2")
   net = ops.deconv2d(vs, net, [bs, h4, w4, gf * 2], 5, 5, 2, 2, s + "/g_dc2", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn3", z=z, y=y, is_training=is_training))
+  net = bn(net, "/g_bn3")
   net = ops.deconv2d(vs, net, [bs, h2, w2, gf], 5, 5, 2, 2, s + "/g_dc3", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn4", z=z, y=y, is_training=is_training))
-  net = ops.deconv2d(vs, net, [bs, h, w, colors], 5, 5, 2, 2, s + "/g_dc4", cfg.sn_cfg)
+  net = bn(net, "/g_bn4")
+  net = ops.deconv2d(vs, net, [bs, h, w, colors], 5, 5, 2, 2, s + "/g_dc4", cfg.sn_cfg,
+                     out_f32=True)
   return 0.5 * torch.tanh(net) + 0.5
 
 
@@ -330,7 +341,8 @@ def dcgan_discriminator(vs, cfg, x, y, is_training):
   net = ops.lrelu(_batch_norm(vs, cfg, net, s + "/d_bn2", y=y, is_training=is_training))
   net = ops.conv2d(vs, net, df * 8, 5, 5, 2, 2, s + "/d_conv4", cfg.sn_cfg, use_sn=sn)
   net = ops.lrelu(_batch_norm(vs, cfg, net, s + "/d_bn3", y=y, is_training=is_training))
-  logit = ops.linear(vs, net.reshape(bs, -1), 1, s + "/d_fc4", cfg.sn_cfg, use_sn=sn)
+  logit = ops.linear(vs, net.reshape(bs, -1), 1, s + "/d_fc4", cfg.sn_cfg, use_sn=sn,
+                     out_f32=True)
   return torch.sigmoid(logit), logit, net
 
 
@@ -342,22 +354,24 @@ def sndcgan_generator(vs, cfg, z, y, is_training, image_shape=(128, 128, 3)):
   h4, w4 = _half(h2), _half(w2)
   h8, w8 = _half(h4), _half(w4)
   net = ops.linear(vs, z, h8 * w8 * 512, s + "/g_fc1", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn1", z=z, y=y, is_training=is_training))
+  bn = lambda t, nm: _batch_norm(vs, cfg, t, s + nm, z=z, y=y, is_training=is_training, relu=True)
+  net = bn(net, "/g_bn1")
   net = net.reshape(bs, h8, w8, 512)
   net = ops.deconv2d(vs, net, [bs, h4, w4, 256], 4, 4, 2, 2, s + "/g_dc2", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn2", z=z, y=y, is_training=is_training))
+  net = bn(net, "/g_bn2")
   net = ops.deconv2d(vs, net, [bs, h2, w2, 128], 4, 4, 2, 2, s + "/g_dc3", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn3", z=z, y=y, is_training=is_training))
+  net = bn(net, "/g_bn3")
   net = ops.deconv2d(vs, net, [bs, h, w, 64], 4, 4, 2, 2, s + "/g_dc4", cfg.sn_cfg)
-  net = torch.relu(_batch_norm(vs, cfg, net, s + "/g_bn4", z=z, y=y, is_training=is_training))
-  net = ops.deconv2d(vs, net, [bs, h, w, colors], 3, 3, 1, 1, s + "/g_dc5", cfg.sn_cfg)
+  net = bn(net, "/g_bn4")
+  net = ops.deconv2d(vs, net, [bs, h, w, colors], 3, 3, 1, 1, s + "/g_dc5", cfg.sn_cfg,
+                     out_f32=True)
   return (torch.tanh(net) + 1.0) / 2.0
 
 
 def sndcgan_discriminator(vs, cfg, x, y, is_training):
   s = "discriminator"
   sn = cfg.spectral_norm
-  x = x * 2.0 - 1.0
+  x = vs.q(x * 2.0 - 1.0)
   spec = [(64, 3, 1), (128, 4, 2), (128, 3, 1), (256, 4, 2), (256, 3, 1), (512, 4, 2), (512, 3, 1)]
   net = x
   for i, (co, k, st) in enumerate(spec):
@@ -365,7 +379,7 @@ def sndcgan_discriminator(vs, cfg, x, y, is_training):
     net = ops.lrelu(net, 0.1)
   bs = x.shape[0]
   net = net.reshape(bs, -1)
-  logit = ops.linear(vs, net, 1, s + "/d_fc1", cfg.sn_cfg, use_sn=sn)
+  logit = ops.linear(vs, net, 1, s + "/d_fc1", cfg.sn_cfg, use_sn=sn, out_f32=True)
   return torch.sigmoid(logit), logit, net
 
 

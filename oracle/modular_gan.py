@@ -1,0 +1,104 @@
+"""ORACLE -- test infrastructure only.
+
+CPU restatement of the training-step structure of the reference's gans/modular_gan.py:
+  _split_inputs_and_generate_samples :428-469, _train_discriminator :471-485,
+  _train_generator :487-510, model_fn (unrolled) :568-584, create_loss :618-670.
+No reference test pins numbers for this path ("parity unpinned": modular_gan_test.py only checks
+that one step runs and the step counters, :142-177); the counters are pinned in
+tests/test_modular_gan_gpu.py.
+"""
+import torch
+import torch.nn.functional as F
+
+from oracle import architectures as A
+from oracle import gan as ogan
+
+
+class OracleGAN(object):
+
+  def __init__(self, vs, architecture, g_cfg, d_cfg, image_shape, loss="non_saturating",
+               penalty="no_penalty", lamba=1.0, disc_iters=1, conditional=False, num_classes=None,
+               g_lr=0.0002, d_lr=None, beta1=0.9, beta2=0.999, g_use_ema=False,
+               ema_decay=0.9999, ema_start_step=40000):
+    self.vs = vs
+    self.arch = architecture
+    self.g_cfg, self.d_cfg = g_cfg, d_cfg
+    self.image_shape = image_shape
+    self.loss, self.penalty, self.lamba = loss, penalty, lamba
+    self.disc_iters = disc_iters
+    self.conditional, self.num_classes = conditional, num_classes
+    self.g_lr, self.d_lr = g_lr, g_lr if d_lr is None else d_lr
+    self.beta1, self.beta2 = beta1, beta2
+    self.g_use_ema, self.ema_decay, self.ema_start_step = g_use_ema, ema_decay, ema_start_step
+    self.global_step = 0
+    self.global_step_disc = 0
+    self.g_opt = self.d_opt = None
+    self.ema = None
+
+  def one_hot(self, labels):
+    return F.one_hot(labels.long(), self.num_classes).to(self.vs.dtype)
+
+  def G(self, z, y, is_training=True):
+    return A.GENERATORS[self.arch](self.vs, self.g_cfg, z, y, is_training, self.image_shape)
+
+  def D(self, x, y, is_training=True):
+    return A.DISCRIMINATORS[self.arch](self.vs, self.d_cfg, x, y, is_training)
+
+  def g_vars(self):
+    return [self.vs.vars[n] for n in self.vs.trainable if n.startswith("generator")]
+
+  def d_vars(self):
+    return [self.vs.vars[n] for n in self.vs.trainable if n.startswith("discriminator")]
+
+  def create_loss(self, images, generated, labels, sampled_labels, alpha=None, with_penalty=True):
+    """modular_gan.py:618-670 -> (d_loss, g_loss, d_all_logits)."""
+    if self.conditional:
+      y, sampled_y = self.one_hot(labels), self.one_hot(sampled_labels)
+      all_y = torch.cat([y, sampled_y], 0)
+    else:
+      y = sampled_y = all_y = None
+    all_images = torch.cat([images, generated], 0)                       # :657
+    d_all, d_all_logits, _ = self.D(all_images, all_y)                   # :658-659
+    b = images.shape[0]
+    d_loss, _, _, g_loss = ogan.get_losses(self.loss, d_all[:b], d_all[b:], d_all_logits[:b],
+                                           d_all_logits[b:])             # :663-665
+    if with_penalty and self.penalty == "wgangp_penalty":
+      pen = ogan.wgangp_penalty(lambda x, yy, t: self.D(x, yy, t), images, generated.detach(), y,
+                                True, alpha.reshape(-1, 1, 1, 1))
+      d_loss = d_loss + self.lamba * pen                                 # :670
+    return d_loss, g_loss, d_all_logits
+
+  def _ensure_opts(self):
+    if self.g_opt is None:
+      self.g_opt = ogan.TFAdam(self.g_vars(), self.g_lr, self.beta1, self.beta2)
+      self.d_opt = ogan.TFAdam(self.d_vars(), self.d_lr, self.beta1, self.beta2)
+      if self.g_use_ema:
+        self.ema = [p.detach().clone() for p in self.g_vars()]
+
+  def train_step(self, subs):
+    """subs: list of disc_iters+1 dicts {images, z, labels, sampled_labels, alpha}."""
+    self._ensure_opts()
+    d_losses = []
+    for i in range(self.disc_iters):
+      s = subs[i]
+      with torch.no_grad():
+        sy = self.one_hot(s["sampled_labels"]) if self.conditional else None
+        generated = self.G(s["z"], sy)
+      d_loss, _, _ = self.create_loss(s["images"], generated, s.get("labels"),
+                                      s.get("sampled_labels"), s.get("alpha"))
+      grads = torch.autograd.grad(d_loss, self.d_vars())
+      self.d_opt.step(grads)
+      self.global_step_disc += 1
+      d_losses.append(float(d_loss.detach()))
+    s = subs[-1]
+    sy = self.one_hot(s["sampled_labels"]) if self.conditional else None
+    generated = self.G(s["z"], sy)
+    _, g_loss, _ = self.create_loss(s["images"], generated, s.get("labels"),
+                                    s.get("sampled_labels"), with_penalty=False)
+    grads = torch.autograd.grad(g_loss, self.g_vars())
+    self.g_opt.step(grads)
+    if self.g_use_ema:
+      decay = self.ema_decay if self.global_step >= self.ema_start_step else 0.0
+      ogan.ema_update(self.ema, self.g_vars(), decay)
+    self.global_step += 1
+    return d_losses, float(g_loss.detach())
