@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one unrolled GAN training step (disc_iters D updates + 1 G update)
+of resnet_cifar10.gin (SN-ResNet, non-saturating loss) at batch 64 per GPU, bf16, synthetic data.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Rank 0 prints ONE JSON line.  `value` = real images consumed per second by the whole job
+(B_global * (disc_iters + 1) / t_step), inputs resident in HBM before the
+timed region.  On N = 1 two extra legs run AFTER the timed region:
+  roofline     : the convolution kernel families re-run with HIP-event brackets on the launch
+                 stream (cg_prof_*); achieved = useful FLOPs / kernel time of the dominant family
+                 against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (restatement of the reference, PyTorch-CPU fp32, all host cores)
+                 on the same workload for a bounded sample.  The reference's own TF1 path cannot be
+                 installed here, hence kind = "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIG_DIR = os.path.join(ROOT, "tests", "golden", "example_configs")
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--config", default="resnet_cifar10.gin")
+    p.add_argument("--batch-per-gpu", type=int, default=64)
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=2)
+    return p.parse_args()
+
+
+def cpu_baseline(config, batch, steps):
+    """The oracle's train step on the host cores (bounded sample)."""
+    from oracle import arch_ops as oops
+    from tests import gan_util as U
+    torch.set_num_threads(os.cpu_count() or 1)
+    vs = oops.VarStore(dtype=torch.float32, seed=1)
+    ora = U.build_oracle(config, vs)
+    nsub = ora.disc_iters + 1
+    h, w, c = ora.image_shape
+    gen = torch.Generator().manual_seed(547)
+    subs = [{"images": torch.rand(batch, h, w, c, generator=gen),
+             "z": torch.rand(batch, 128, generator=gen) * 2 - 1} for _ in range(nsub)]
+    ora.train_step(subs)  # builds variables / warms the allocator
+    t0 = time.time()
+    for _ in range(steps):
+        ora.train_step(subs)
+    dt = time.time() - t0
+    return {"value": round(batch * nsub * steps / dt, 2), "unit": "img/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full unrolled steps (%d D + 1 G sub-steps) of %s at batch %d, fp32 "
+                      "PyTorch-CPU restatement of the reference (oracle/)" % (
+                          steps, ora.disc_iters, config, batch)}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from compare_gan_amd import datasets, gin, runner_lib
+    from compare_gan_amd import eval_gan_lib  # noqa: F401  (registers eval_z)
+    from compare_gan_amd.gans import modular_gan  # noqa: F401
+    from compare_gan_amd.hip import kernels as K
+
+    gin.parse_config_files_and_bindings([os.path.join(CONFIG_DIR, args.config)], [])
+    options = runner_lib.get_options_dict()
+    dataset = datasets.get_dataset()
+    bsz = args.batch_per_gpu
+    gan = options["gan_class"](dataset=dataset, parameters=options, model_dir="/tmp/cg_bench")
+    gan.build(batch_size=bsz, device=dev, seed=3)
+    nsub = options["disc_iters"] + 1
+
+    # synthetic inputs, resident in HBM before the timed region (datasets.py:136-145 semantics)
+    batches = dataset.train_batches(bsz * nsub, seed=547 + rank)
+    pool = []
+    for _ in range(4):
+        images, labels = next(batches)
+        pool.append((torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev)))
+
+    use_graph = (not args.no_graph) and world == 1
+    step_fn = gan.capture_train_step() if use_graph else gan.train_step
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step_fn(*pool[i % len(pool)])
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step_fn(*pool[i % len(pool)])
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    g_loss = float(out["g_loss"])
+    if not np.isfinite(g_loss):
+        raise SystemExit("non-finite generator loss after the timed region: %r" % g_loss)
+
+    result = {
+        "metric": "train img/s (G+D step)",
+        "value": round(bsz * world * nsub * args.steps / dt, 2),
+        "unit": "img/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "%s full unrolled train step: %d D sub-steps + 1 G sub-step, "
+                               "batch %d per GPU, %dx%dx%d" % (
+                                   args.config, options["disc_iters"], bsz, *dataset.image_shape),
+                   "global_batch": bsz * world, "images_per_step": bsz * world * nsub,
+                   "parallelism": "dp%d" % world, "hip_graph": bool(use_graph)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        K.prof_reset()
+        K.prof_enable(True)
+        n_prof = max(1, min(args.steps, 3))
+        for i in range(n_prof):
+            gan.train_step(*pool[i % len(pool)])   # eager: event brackets cannot be captured
+        torch.cuda.synchronize()
+        K.prof_enable(False)
+        fam = K.prof_collect()
+        name, st = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        achieved = st["flops"] / (st["ms"] * 1e-3) / 1e12 if st["ms"] > 0 else 0.0
+        result["roofline"] = {
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_step": st["launches"] / n_prof,
+            "avg_launch_us": round(1e3 * st["ms"] / max(st["launches"], 1), 3),
+            "avg_launch_gflop": round(st["flops"] / max(st["launches"], 1) / 1e9, 3),
+            "families": {k: {"ms_per_step": round(v["ms"] / n_prof, 4),
+                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                             "algorithmic_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
+                             "launches_per_step": v["launches"] / n_prof}
+                         for k, v in fam.items()},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.config, bsz, args.cpu_steps)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

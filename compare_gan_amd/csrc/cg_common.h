@@ -86,5 +86,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm4) {
   return sm4[0] + sm4[1] + sm4[2] + sm4[3];
 }
 
+// ---- optional HIP-event timing of the dominant kernel families (cg_error.hip) -----------------
+#define CG_PROF_GCONV_MAIN 0   /* gconv_kernel<128,128,64,2,2,true>: fwd / dgrad / deconv / linear */
+#define CG_PROF_GCONV_OTHER 1  /* narrow-N and scalar-gather instantiations */
+#define CG_PROF_GWGRAD_MAIN 2  /* gwgrad_kernel<128,128,true,true> (+ split reduce) */
+#define CG_PROF_GWGRAD_OTHER 3
+void cg_prof_begin(int family, double flops, double bytes, hipStream_t st);
+void cg_prof_end(int family, hipStream_t st);
+bool cg_prof_enabled();
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

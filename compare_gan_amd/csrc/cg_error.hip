@@ -1,5 +1,6 @@
 // Thread-local error string + ABI version.
 #include <stdarg.h>
+#include <vector>
 #include "cg_common.h"
 
 static thread_local char g_err[512] = {0};
@@ -13,3 +14,76 @@ void cg_set_error(const char* fmt, ...) {
 
 extern "C" int cg_abi_version(void) { return 1; }
 extern "C" const char* cg_last_error(void) { return g_err; }
+
+// ---- optional per-kernel-family timing with HIP events (bench.py's roofline leg) -------------
+namespace {
+struct ProfSlot {
+  std::vector<hipEvent_t> ev;   // start/stop pairs
+  std::vector<double> flops, bytes;
+  double total_ms = 0, total_flops = 0, total_bytes = 0;
+  int64_t launches = 0;
+};
+bool g_prof_on = false;
+ProfSlot g_prof[CG_PROF_FAMILIES];
+}  // namespace
+
+bool cg_prof_enabled() { return g_prof_on; }
+
+void cg_prof_begin(int family, double flops, double bytes, hipStream_t st) {
+  if (!g_prof_on || family < 0 || family >= CG_PROF_FAMILIES) return;
+  ProfSlot& p = g_prof[family];
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  p.ev.push_back(a);
+  p.ev.push_back(b);
+  p.flops.push_back(flops);
+  p.bytes.push_back(bytes);
+  hipEventRecord(a, st);
+}
+
+void cg_prof_end(int family, hipStream_t st) {
+  if (!g_prof_on || family < 0 || family >= CG_PROF_FAMILIES) return;
+  ProfSlot& p = g_prof[family];
+  if (p.ev.size() >= 2) hipEventRecord(p.ev.back(), st);
+}
+
+extern "C" int cg_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return CG_OK;
+}
+
+extern "C" int cg_prof_collect(int family, double* total_ms, int64_t* launches, double* flops,
+                               double* bytes) {
+  if (family < 0 || family >= CG_PROF_FAMILIES) CG_FAIL(CG_ERR_BAD_ARG, "cg_prof_collect: family");
+  ProfSlot& p = g_prof[family];
+  for (size_t i = 0; i + 1 < p.ev.size(); i += 2) {
+    hipEventSynchronize(p.ev[i + 1]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
+      p.total_ms += ms;
+      p.total_flops += p.flops[i / 2];
+      p.total_bytes += p.bytes[i / 2];
+      p.launches += 1;
+    }
+    hipEventDestroy(p.ev[i]);
+    hipEventDestroy(p.ev[i + 1]);
+  }
+  p.ev.clear();
+  p.flops.clear();
+  p.bytes.clear();
+  if (total_ms) *total_ms = p.total_ms;
+  if (launches) *launches = p.launches;
+  if (flops) *flops = p.total_flops;
+  if (bytes) *bytes = p.total_bytes;
+  return CG_OK;
+}
+
+extern "C" int cg_prof_reset(void) {
+  for (int f = 0; f < CG_PROF_FAMILIES; ++f) {
+    cg_prof_collect(f, nullptr, nullptr, nullptr, nullptr);
+    g_prof[f].total_ms = g_prof[f].total_flops = g_prof[f].total_bytes = 0;
+    g_prof[f].launches = 0;
+  }
+  return CG_OK;
+}

@@ -557,6 +557,17 @@ int check_geom(const cgConvGeom* g, const char* who) {
   return CG_OK;
 }
 
+// Useful MACs (structural zeros of the zero-inserted input are not counted) and the minimum
+// bf16 HBM traffic of one launch.
+void algorithmic_cost(const cgConvGeom* g, double* flops, double* bytes) {
+  const double m = (double)g->N * g->Ho * g->Wo;
+  double taps = (double)g->kh * g->kw;
+  if (g->U > 1) taps /= (double)g->U * g->U;
+  *flops = 2.0 * m * taps * g->Ci * g->Co;
+  *bytes = 2.0 * ((double)g->N * g->Hin * g->Win * g->Ci + m * g->Co +
+                  (double)g->kh * g->kw * g->Ci * g->Co);
+}
+
 }  // namespace
 
 extern "C" int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,
@@ -619,12 +630,19 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   a.dCi = make_fastdiv(g->Ci); a.dKw = make_fastdiv(g->kw);
   const bool vec = (g->Ci % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
+  const int fam = (g->Co > 64 && vec) ? CG_PROF_GCONV_MAIN : CG_PROF_GCONV_OTHER;
+  if (cg_prof_enabled()) {
+    double flops, bytes;
+    algorithmic_cost(g, &flops, &bytes);
+    cg_prof_begin(fam, flops, bytes, st);
+  }
   if (g->Co > 64)
     launch_gconv<128, 128, 2, 2>(a, vec, st);
   else if (g->Co > 32)
     launch_gconv<128, 64, 2, 2>(a, vec, st);
   else
     launch_gconv<128, 32, 4, 1>(a, vec, st);
+  cg_prof_end(fam, st);
   CG_CHECK_LAUNCH("cg_gconv");
   return CG_OK;
 }
@@ -692,6 +710,13 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(K, tk), cdiv(g->Co, tn), splits);
+  const int fam = (tk == 128 && tn == 128 && g->Ci % 8 == 0 && g->Co % 8 == 0)
+                      ? CG_PROF_GWGRAD_MAIN : CG_PROF_GWGRAD_OTHER;
+  if (cg_prof_enabled()) {
+    double flops, bytes;
+    algorithmic_cost(g, &flops, &bytes);
+    cg_prof_begin(fam, flops, bytes, st);
+  }
   const bool vx = (g->Ci % 8) == 0, vy = (g->Co % 8) == 0;
 #define CG_WG(TK_, TN_)                                                        \
   do {                                                                         \
@@ -716,5 +741,6 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
       CG_CHECK_LAUNCH("cg_gwgrad(reduce bias)");
     }
   }
+  cg_prof_end(fam, st);
   return CG_OK;
 }

@@ -70,14 +70,22 @@ class _OptimizerState(object):
     self.v = [torch.zeros_like(v, requires_grad=False) for v in self.params]
     self.ema = [v.detach().clone() for v in self.params] if with_ema else None
     self.table = None
+    self.captured_tables = []
     self.flat = None
     self.device = device
 
   def _ensure(self, grads):
+    if torch.cuda.is_current_stream_capturing():
+      # every captured update keeps its own table: its gradient tensors live at addresses that
+      # are fixed for all replays, and the table is only read when the graph runs
+      t = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v, self.ema)
+      self.captured_tables.append(t)
+      return t
     if self.table is None:
       self.table = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v, self.ema)
     else:
       self.table.set_grads(grads)
+    return self.table
 
   def apply_gradients(self, step, ema_decay=0.0, ema_start=0):
     """All-reduce (data parallel) + fused Adam(+EMA).  step: device int64 update counter."""
@@ -104,9 +112,9 @@ class _OptimizerState(object):
       tpu_ops.cross_replica_sum_(self.flat)      # CrossShardOptimizer: gradient mean
       grads = self.flat_views
       scale = 1.0 / world
-    self._ensure(grads)
+    table = self._ensure(grads)
     o = self.opt
-    self.table.adam(o.learning_rate, o.beta1, o.beta2, o.epsilon, scale, step,
+    table.adam(o.learning_rate, o.beta1, o.beta2, o.epsilon, scale, step,
                     ema_decay=ema_decay if self.ema is not None else 0.0, ema_start=ema_start)
 
 
@@ -383,6 +391,48 @@ class ModularGAN(AbstractGAN):
         d_losses.append(self._train_discriminator(fs[i], ls[i]))
       g_loss = self._train_generator(fs[-1], ls[-1])
     return {"d_losses": d_losses, "g_loss": g_loss}
+
+  # -- hipGraph capture of the whole step ---------------------------------------------------------------
+  def capture_train_step(self, num_warmup=2):
+    """Captures one unrolled step (all kernels of disc_iters D updates + the G update) into a
+    hipGraph: small configs are launch-bound, replay removes the per-launch
+    host cost.  Inputs are copied into static device buffers before each replay.  Returns
+    run(images, labels) -> same dict as train_step."""
+    if tpu_ops.num_replicas() > 1:
+      raise NotImplementedError("graph capture with RCCL collectives is not enabled; use "
+                                "train_step() under data parallelism")
+    nsub = self._disc_iters + 1
+    shape = (nsub * self.batch_size,) + tuple(self._dataset.image_shape)
+    self._static_images = torch.zeros(shape, dtype=torch.float32, device=self.device)
+    self._static_labels = torch.zeros((shape[0],), dtype=torch.int32, device=self.device)
+
+    def run_eager(images, labels):
+      self._static_images.copy_(images)
+      self._static_labels.copy_(labels)
+      return self.train_step(self._static_images, self._static_labels)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(num_warmup):
+        self.train_step(self._static_images, self._static_labels)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    self._graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self._graph):
+      self._graph_out = self.train_step(self._static_images, self._static_labels)
+    for opt in (self.g_opt, self.d_opt):
+      for t in opt.captured_tables:
+        t.flush()
+
+    def run(images, labels):
+      self._static_images.copy_(images, non_blocking=True)
+      self._static_labels.copy_(labels, non_blocking=True)
+      self._graph.replay()
+      return self._graph_out
+
+    del run_eager
+    return run
 
   # -- inference -----------------------------------------------------------------------------------
   def generate(self, z, labels=None, use_ema=None):

@@ -35,6 +35,9 @@ GP = ctypes.POINTER(ConvGeom)
 SIGNATURES = {
     "cg_abi_version": (c_int, []),
     "cg_last_error": (ctypes.c_char_p, []),
+    "cg_prof_enable": (c_int, [c_int]),
+    "cg_prof_reset": (c_int, []),
+    "cg_prof_collect": (c_int, [c_int, vp, vp, vp, vp]),
     "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
     "cg_gwgrad_workspace_bytes": (c_sz, [GP]),

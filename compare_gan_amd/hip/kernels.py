@@ -515,13 +515,15 @@ class AdamTable(object):
     """Device-resident cgAdamEntry table for a fixed list of (param, grad, m, v, ema) tensors.
 
     The table lives at a stable device address; set_grads() re-points the gradient column (the
-    autograd engine hands out fresh gradient tensors every step) and re-uploads it."""
+    autograd engine hands out fresh gradient tensors every step) and re-uploads it.  While a
+    hipGraph is being captured no host-to-device copy may be recorded, so the upload is deferred:
+    the kernels only read the table when the graph is replayed -- call flush() after capture."""
 
     def __init__(self, params, grads, ms, vs, emas=None):
         n = len(params)
         self.entries = (_lib.AdamEntry * n)()
         chunk = 0
-        offs = []
+        self._offs = []
         off = 0
         for i in range(n):
             for t in (params[i], ms[i], vs[i]):
@@ -533,17 +535,25 @@ class AdamTable(object):
             e.n = params[i].numel()
             e.chunk_begin = chunk
             chunk += (e.n + _lib.ADAM_CHUNK - 1) // _lib.ADAM_CHUNK
-            offs.append(off)
+            self._offs.append(off)
             off += e.n
         self.n = n
         self.total_chunks = chunk
         self.total_elems = off
-        dev = params[0].device
-        self.table = torch.empty(ctypes.sizeof(self.entries), dtype=torch.uint8, device=dev)
-        self.offsets = torch.tensor(offs, dtype=torch.int64).to(dev)
+        self.device = params[0].device
+        self.table = torch.empty(ctypes.sizeof(self.entries), dtype=torch.uint8,
+                                 device=self.device)
+        self._offsets = None
         self._keep = (params, ms, vs, emas)
         self._grad_ptrs = None
+        self.dirty = False
         self.set_grads(grads)
+
+    @property
+    def offsets(self):
+        if self._offsets is None:
+            self._offsets = torch.tensor(self._offs, dtype=torch.int64).to(self.device)
+        return self._offsets
 
     def set_grads(self, grads):
         ptrs = tuple(g.data_ptr() for g in grads)
@@ -556,9 +566,16 @@ class AdamTable(object):
             return
         for p, e in zip(ptrs, self.entries):
             e.grad = p
-        host = torch.frombuffer(bytearray(bytes(self.entries)), dtype=torch.uint8)
-        self.table.copy_(host)
         self._grad_ptrs = ptrs
+        self.dirty = True
+        if not torch.cuda.is_current_stream_capturing():
+            self.flush()
+
+    def flush(self):
+        if self.dirty:
+            host = torch.frombuffer(bytearray(bytes(self.entries)), dtype=torch.uint8)
+            self.table.copy_(host)
+            self.dirty = False
 
     def adam(self, lr, beta1, beta2, eps, grad_scale, step, ema_decay=0.0, ema_start=0):
         check(lib().cg_adam_multi(_p(self.table), self.n, self.total_chunks, float(lr),
@@ -660,3 +677,29 @@ def pool2d(x, k, s, p, kind, Ho, Wo):
     y = torch.empty((N, Ho, Wo, C), dtype=BF16, device=x.device)
     check(lib().cg_pool2d(_p(x), N, H, W, C, k, s, p, kind, Ho, Wo, _p(y), _stream()), "cg_pool2d")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel-family timing (bench.py roofline leg)
+# ------------------------------------------------------------------------------------------------
+PROF_FAMILIES = ["gconv_main", "gconv_other", "gwgrad_main", "gwgrad_other"]
+
+
+def prof_enable(on):
+    check(lib().cg_prof_enable(int(on)), "cg_prof_enable")
+
+
+def prof_reset():
+    check(lib().cg_prof_reset(), "cg_prof_reset")
+
+
+def prof_collect():
+    """{family: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
+    out = {}
+    for i, name in enumerate(PROF_FAMILIES):
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        n = ctypes.c_int64()
+        check(lib().cg_prof_collect(i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl),
+                                    ctypes.byref(by)), "cg_prof_collect")
+        out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+    return out

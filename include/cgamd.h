@@ -41,6 +41,17 @@ int cg_abi_version(void);
 /* Human-readable description of the last error on this thread ("" if none). */
 const char* cg_last_error(void);
 
+/* Optional timing of the convolution kernel families with HIP events recorded on the launch
+ * stream (bench.py's roofline measurement).  Families: 0 gconv main tile (128x128, vector
+ * gather), 1 other gconv tiles, 2 gwgrad main tile, 3 other gwgrad tiles.  While enabled every
+ * launch of a family is bracketed by an event pair; cg_prof_collect synchronises on them and
+ * returns the accumulated kernel time, launch count and ALGORITHMIC flops / bytes (useful MACs x 2;
+ * minimum bf16 traffic 2*(in + out + weights) bytes).  Not capturable into a hipGraph. */
+#define CG_PROF_FAMILIES 4
+int cg_prof_enable(int on);
+int cg_prof_reset(void);
+int cg_prof_collect(int family, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------------
  * Generalised convolution geometry.
  *

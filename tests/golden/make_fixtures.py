@@ -8,10 +8,24 @@ container, where /root/reference exists; the GPU box only ever sees the committe
 """
 import json
 import os
+import re
 import shutil
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _variable_lists(path):
+  """The (name, shape) literals of every expected_variables list in a reference test file."""
+  src = open(path).read()
+  parts = re.split(r"\n  def (test\w+)\(self\):", src)
+  out = {}
+  for i in range(1, len(parts), 2):
+    items = re.findall(r'\("([^"]+):0",\s*\[([0-9,* ]*)\]\)', parts[i + 1])
+    if items:
+      out[parts[i]] = [[n, [int(eval(d)) for d in dims.split(",") if d.strip()]]  # "3 * 3 * 256"
+                       for n, dims in items]
+  return out
 
 
 def main():
@@ -39,6 +53,10 @@ def main():
           "resnet_biggan_arch_128": {"G": 70433988, "D": 87982370},
           "resnet_cifar_arch": {"G": 5849603, "D": 1483137},
       },
+      "resnet_cifar_variables": dict(
+          source="compare_gan/architectures/resnet_norm_test.py:30-369 (expected_variables lists; "
+                 "the last test lists tf.global_variables, the others tf.trainable_variables)",
+          **_variable_lists(os.path.join(REF, "compare_gan/architectures/resnet_norm_test.py"))),
       "step_counters": {"source": "compare_gan/gans/modular_gan_test.py:175-177",
                         "rule": "global_step_disc == steps * disc_iters; global_step == steps"},
   }

@@ -1,0 +1,201 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes exercising the host-side collectives of
+compare_gan_amd/tpu/tpu_ops.py (the RCCL path on the GPU box runs the same code with backend
+"nccl") and the data-parallel arithmetic they must reproduce.
+
+Reference pins / properties:
+  * cross-replica batch norm == full-batch batch norm    tpu/tpu_ops_test.py, arch_ops_tpu_test.py:112-133
+  * cross_replica_concat ordering                          tpu/tpu_ops.py:29-72
+  * CrossShardOptimizer: mean of per-replica gradients ==  modular_gan.py:606-616
+    gradient of the global-batch loss (equal shards)
+  * per-replica random streams are distinct, per-step reproducible   tpu/tpu_random_test.py:146-168
+"""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 2
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _worker(rank, port, fn_name, errq):
+  try:
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    globals()[fn_name](rank)
+    dist.barrier()
+    dist.destroy_process_group()
+  except Exception:  # pylint: disable=broad-except
+    errq.put("rank %d:\n%s" % (rank, traceback.format_exc()))
+
+
+def _run(fn_name):
+  ctx = mp.get_context("spawn")
+  errq = ctx.SimpleQueue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, port, fn_name, errq)) for r in range(WORLD)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(180)
+  errs = []
+  while not errq.empty():
+    errs.append(errq.get())
+  for p in procs:
+    if p.is_alive():
+      p.terminate()
+      errs.append("worker timed out")
+    elif p.exitcode != 0:
+      errs.append("worker exit code %s" % p.exitcode)
+  assert not errs, "\n".join(errs)
+
+
+# ---- bodies (run inside each rank) ---------------------------------------------------------------
+def _body_collectives(rank):
+  from compare_gan_amd.tpu import tpu_ops
+  assert tpu_ops.num_replicas() == WORLD and tpu_ops.replica_id() == rank
+  g = torch.Generator().manual_seed(11)
+  full = torch.randn(8, 4, 4, 6, generator=g, dtype=torch.float64)
+  mine = full[rank * 4:(rank + 1) * 4]
+  # mean
+  m = tpu_ops.cross_replica_mean(mine.mean(dim=(0, 1, 2)))
+  assert torch.allclose(m, full.mean(dim=(0, 1, 2)), atol=1e-12)
+  # group_size = 1 is the identity (tpu_ops.py:80-81)
+  assert torch.equal(tpu_ops.cross_replica_mean(mine, group_size=1), mine)
+  # moments, both formulations (tpu_ops.py:109-125)
+  for parallel in (True, False):
+    mean, var = tpu_ops.cross_replica_moments(mine, axis=(0, 1, 2), parallel=parallel)
+    assert torch.allclose(mean, full.mean(dim=(0, 1, 2)), atol=1e-12)
+    assert torch.allclose(var, full.var(dim=(0, 1, 2), unbiased=False), atol=1e-10)
+  # concat keeps replica order
+  cat = tpu_ops.cross_replica_concat(mine, rank, WORLD)
+  assert torch.equal(cat, full)
+  # in-place sum
+  t = torch.full((3,), float(rank + 1), dtype=torch.float32)
+  out, n = tpu_ops.cross_replica_sum_(t)
+  assert n == WORLD and out.tolist() == [3.0, 3.0, 3.0]
+  # replica context switch (arch_ops.py:258-263)
+  assert not tpu_ops.in_replica_context()
+  tpu_ops.enable_cross_replica(True)
+  assert tpu_ops.in_replica_context()
+  tpu_ops.enable_cross_replica(False)
+
+
+def _body_sync_bn_matches_full_batch(rank):
+  """arch_ops_tpu_test.py:112-133: BN over shards with cross-replica moments equals BN over the
+  concatenated batch -- forward AND the gradient w.r.t. the input."""
+  from compare_gan_amd.tpu import tpu_ops
+  from oracle import arch_ops as oops
+
+  class _AllReduceMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+      return tpu_ops.cross_replica_mean(t)
+
+    @staticmethod
+    def backward(ctx, g):   # adjoint of the mean over replicas
+      return tpu_ops.cross_replica_mean(g)
+
+  def sync(mean, mean_sq):
+    return _AllReduceMean.apply(mean), _AllReduceMean.apply(mean_sq)
+
+  g = torch.Generator().manual_seed(5)
+  full = torch.randn(8, 3, 3, 5, generator=g, dtype=torch.float64)
+  w = torch.randn(8, 3, 3, 5, generator=g, dtype=torch.float64)
+  # reference: single-process full batch
+  xf = full.clone().requires_grad_(True)
+  vs = oops.VarStore()
+  yf = oops.standardize_batch(vs, xf, True, "", oops.BNConfig(0.9, 1e-5))
+  (yf * w).sum().backward()
+  # sharded
+  xs = full[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+  vs2 = oops.VarStore()
+  ys = oops.standardize_batch(vs2, xs, True, "", oops.BNConfig(0.9, 1e-5, cross_replica=sync))
+  # each replica's loss is the sum over its shard; the global loss is the sum over replicas, and
+  # the adjoint of mean-over-replicas is again mean-over-replicas, so x.grad is the global gradient
+  (ys * w[rank * 4:(rank + 1) * 4]).sum().backward()
+  assert torch.allclose(ys, yf[rank * 4:(rank + 1) * 4], atol=1e-10)
+  assert torch.allclose(xs.grad, xf.grad[rank * 4:(rank + 1) * 4], atol=1e-9)
+  assert torch.allclose(vs2.vars["moving_mean"], vs.vars["moving_mean"], atol=1e-12)
+  assert torch.allclose(vs2.vars["moving_variance"], vs.vars["moving_variance"], atol=1e-12)
+
+
+def _body_gradient_mean_equals_global_batch(rank):
+  """One D sub-step of resnet_cifar10.gin (no BN in D): the all-reduced mean of the per-replica
+  gradients equals the gradient of the loss over the global batch."""
+  from compare_gan_amd.tpu import tpu_ops
+  from oracle import arch_ops as oops
+  from tests import gan_util as U
+  bsz = 2
+  g = torch.Generator().manual_seed(9)
+  images = torch.rand(WORLD * bsz, 32, 32, 3, generator=g, dtype=torch.float64)
+  fakes = torch.rand(WORLD * bsz, 32, 32, 3, generator=g, dtype=torch.float64)
+
+  def d_grads(img, fk):
+    vs = oops.VarStore(seed=1)
+    ora = U.build_oracle("resnet_cifar10.gin", vs)
+    d_loss, _, _ = ora.create_loss(img, fk, None, None)
+    return torch.autograd.grad(d_loss, ora.d_vars()), float(d_loss)
+
+  grads_full, loss_full = d_grads(images, fakes)
+  sl = slice(rank * bsz, (rank + 1) * bsz)
+  grads_mine, loss_mine = d_grads(images[sl], fakes[sl])
+  flat = torch.cat([t.reshape(-1) for t in grads_mine]).to(torch.float32)   # bucket
+  tpu_ops.cross_replica_sum_(flat)
+  flat = flat.double() / WORLD
+  ref = torch.cat([t.reshape(-1) for t in grads_full])
+  assert float((flat - ref).norm() / ref.norm()) < 1e-6
+  lm = tpu_ops.cross_replica_mean(torch.tensor([loss_mine], dtype=torch.float64))
+  assert abs(float(lm) - loss_full) < 1e-10
+
+
+def _body_per_replica_streams(rank):
+  from compare_gan_amd.tpu import tpu_ops
+  from oracle import rng as orng
+  from tests import gan_util as U
+  z = orng.uniform(64, -1, 1, 3, U.op_id("z/0"), tpu_ops.replica_id(), 0)
+  zs = [torch.zeros(64, dtype=torch.float64) for _ in range(WORLD)]
+  dist.all_gather(zs, torch.from_numpy(np.asarray(z, dtype=np.float64)))
+  assert not torch.equal(zs[0], zs[1])
+  again = orng.uniform(64, -1, 1, 3, U.op_id("z/0"), rank, 0)
+  assert np.array_equal(z, again)
+  # the synthetic input pipeline shards by replica (runner_lib: seed + replica id)
+  from compare_gan_amd import datasets
+  ds = datasets.DATASETS["cifar10"](seed=547)
+  a = next(ds.train_batches(4, seed=547 + rank))[0]
+  parts = [torch.zeros(a.shape, dtype=torch.float32) for _ in range(WORLD)]
+  dist.all_gather(parts, torch.from_numpy(a))
+  assert not torch.equal(parts[0], parts[1])
+
+
+# ---- tests -----------------------------------------------------------------------------------------
+def test_collectives_world2():
+  _run("_body_collectives")
+
+
+def test_sync_bn_matches_full_batch_world2():
+  _run("_body_sync_bn_matches_full_batch")
+
+
+def test_gradient_mean_equals_global_batch_world2():
+  _run("_body_gradient_mean_equals_global_batch")
+
+
+def test_per_replica_streams_world2():
+  _run("_body_per_replica_streams")

@@ -1,0 +1,206 @@
+"""Host-side boundary tests that need no GPU: the gin surface, the architecture registry, variable
+naming / shapes / counts (built on the "meta" device: variables and shapes only, no arithmetic),
+and the C-ABI library's exported symbols.
+
+Reference pins: architectures/resnet_norm_test.py:30-369 (variable lists),
+architectures/resnet_biggan_test.py:139,154 (BigGAN parameter totals), SURVEY.md App. B (totals of
+the other example configs), App. C (gin surface), runner_lib.py:72-111 (options dict).
+"""
+import ctypes
+import json
+import os
+
+import pytest
+import torch
+
+import __graft_entry__ as entry
+from tests import gan_util as U
+
+PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.json")))
+CONFIGS = sorted(f for f in os.listdir(U.CONFIG_DIR) if f.endswith(".gin"))
+
+PARAM_TOTALS = {   # SURVEY.md App. B; the BigGAN / ResNet-CIFAR rows are reference-test pins
+    "biggan_imagenet128.gin": (70433988, 87982370),
+    "resnet_cifar10.gin": (5849603, 1483137),
+    "dcgan_celeba64.gin": (5364739, 4314753),
+    "sndcgan_celebahq128.gin": (19926019, 5983745),
+    "resnet_lsun-bedroom128.gin": (13786115, 15086529),
+}
+
+
+def test_example_configs_are_the_reference_files():
+  assert CONFIGS == ["biggan_imagenet128.gin", "dcgan_celeba64.gin", "resnet_cifar10.gin",
+                     "resnet_lsun-bedroom128.gin", "sndcgan_celebahq128.gin"]
+
+
+@pytest.mark.parametrize("config", CONFIGS)
+def test_config_parses_and_builds(config):
+  gan, options, dataset = U.build_product(config, 4, "meta")
+  g = sum(v.numel() for _, v in gan.store.trainable_variables("generator"))
+  d = sum(v.numel() for _, v in gan.store.trainable_variables("discriminator"))
+  assert (g, d) == PARAM_TOTALS[config]
+  for key in ("architecture", "batch_size", "gan_class", "lambda", "training_steps", "z_dim",
+              "disc_iters"):
+    assert key in options
+  # every trainable variable belongs to exactly one network (modular_gan.py:345-357)
+  names = [n for n, _ in gan.store.trainable_variables()]
+  assert all(n.startswith("generator/") or n.startswith("discriminator/") for n in names)
+
+
+def test_biggan_pins():
+  pin = PINS["param_counts"]["resnet_biggan_arch_128"]
+  assert PARAM_TOTALS["biggan_imagenet128.gin"] == (pin["G"], pin["D"])
+  gan, options, _ = U.build_product("biggan_imagenet128.gin", 2, "meta")
+  assert options["disc_iters"] == 2 and options["batch_size"] == 2048
+  v = gan.store.vars
+  # hierarchical z: 120 / 6 = 20 dims per chunk; CBN conditions on z chunk (20) + embed_y (128)
+  assert tuple(v["generator/fc_noise/kernel"].shape) == (20, 4 * 4 * 16 * 96)
+  assert tuple(v["generator/B1/bn1/condition/gamma/kernel"].shape) == (148, 1536)
+  assert tuple(v["generator/embed_y/kernel"].shape) == (1000, 128)
+  assert "generator/embed_y/kernel/u_var" not in v            # embed_y is not spectrally normed
+  assert tuple(v["discriminator/embedding_fc/kernel"].shape) == (1000, 1536)
+  # singular_value="auto": the vector sits on the smaller side (arch_ops.py:487-498)
+  assert tuple(v["generator/fc_noise/kernel/u_var"].shape) == (20, 1)
+  assert tuple(v["discriminator/B6/same_conv1/kernel/u_var"].shape) == (1, 1536)
+  assert gan.store.initializers["generator/B1/up_conv1/kernel"] == "orthogonal"
+  assert gan.store.initializers["discriminator/embedding_fc/kernel"] == "glorot_normal"
+  assert gan.store.initializers["generator/non_local_block/sigma"] == "zeros"
+
+
+def _cifar_vars(module_kind, trainable_only=True, **kwargs):
+  from compare_gan_amd import gin
+  from compare_gan_amd.architectures import arch_ops as ops
+  from compare_gan_amd.architectures import resnet_cifar
+  gin.clear_config()
+  store = ops.VariableStore("meta")
+  with ops.use_store(store):
+    y = torch.empty((8, 10), dtype=torch.bfloat16, device="meta")
+    if module_kind == "G":
+      z = torch.empty((8, 128), dtype=torch.float32, device="meta")
+      out = resnet_cifar.Generator(image_shape=(32, 32, 3), **kwargs)(z, y=y, is_training=True)
+      assert tuple(out.shape) == (8, 32, 32, 3)
+    else:
+      x = torch.empty((8, 32, 32, 3), dtype=torch.bfloat16, device="meta")
+      resnet_cifar.Discriminator(**kwargs)(x, y=y, is_training=True)
+  if trainable_only:
+    return [[n, list(v.shape)] for n, v in store.trainable_variables()]
+  return [[n, list(v.shape)] for n, v in store.global_variables()]
+
+
+def test_resnet_cifar_variable_lists():
+  """Names, shapes AND creation order of the reference's expected_variables lists."""
+  from compare_gan_amd.architectures import arch_ops as ops
+  pins = PINS["resnet_cifar_variables"]
+  assert _cifar_vars("G") == pins["testDefaultGenerator"]
+  assert _cifar_vars("D") == pins["testDefaultDiscriminator"]
+  assert _cifar_vars("G", batch_norm_fn=ops.batch_norm) == pins["testDefaultGeneratorWithBatchNorm"]
+  assert _cifar_vars("G", batch_norm_fn=ops.conditional_batch_norm) == \
+      pins["testDefaultGeneratorWithConditionalBatchNorm"]
+  assert _cifar_vars("G", batch_norm_fn=ops.self_modulated_batch_norm) == \
+      pins["testDefaultGeneratorWithSelfModulatedBatchNorm"]
+  assert _cifar_vars("G", trainable_only=False, spectral_norm=True) == \
+      pins["testDefaultGeneratorWithSpectralNorm"]
+
+
+def test_unknown_architecture_raises():
+  gan, options, dataset = U.build_product("resnet_cifar10.gin", 2, "meta")
+  from compare_gan_amd.gans import modular_gan
+  params = dict(options)
+  params["architecture"] = "no_such_arch"
+  g = modular_gan.ModularGAN(dataset=dataset, parameters=params, model_dir="/tmp/x")
+  with pytest.raises(NotImplementedError):
+    g.generator  # pylint: disable=pointless-statement
+  with pytest.raises(NotImplementedError):
+    g.discriminator  # pylint: disable=pointless-statement
+
+
+def test_conditional_without_labels_raises():
+  with pytest.raises(ValueError):
+    U.build_product("dcgan_celeba64.gin", 2, "meta", bindings=["ModularGAN.conditional = True"])
+
+
+def test_error_conventions():
+  from compare_gan_amd.architectures import arch_ops as ops
+  store = ops.VariableStore("meta")
+  with ops.use_store(store):
+    with pytest.raises(ValueError):   # arch_ops.py:276-279
+      ops.standardize_batch(torch.empty((2, 3, 4), device="meta"), is_training=True)
+    with pytest.raises(ValueError):   # arch_ops.py:255-257
+      ops.standardize_batch(torch.empty((2, 3), device="meta"), is_training=True, data_format="NWC")
+    with pytest.raises(ValueError):   # arch_ops.py:427-430
+      ops.conditional_batch_norm(torch.empty((2, 4, 4, 3), device="meta"), None, True, False)
+    with pytest.raises(ValueError):   # arch_ops.py:400-401
+      ops.self_modulated_batch_norm(torch.empty((2, 4, 4, 3), device="meta"), None, True, False)
+    with pytest.raises(ValueError):   # arch_ops.py:470-472
+      ops.spectral_norm(torch.empty((5,), device="meta"))
+    with pytest.raises(ValueError):   # arch_ops.py:59-63
+      ops.weight_initializer(initializer="nope")
+
+
+def test_gin_surface():
+  from compare_gan_amd import gin
+  U.build_product("biggan_imagenet128.gin", 2, "meta")
+  assert gin.query_parameter("spectral_norm.singular_value") == "auto"
+  assert gin.query_parameter("standardize_batch.use_moving_averages") is False
+  assert gin.query_parameter("options.lamba") == 1
+  assert gin.query_parameter("resnet_biggan.Generator.hierarchical_z") is True
+  s = gin.operative_config_str()
+  assert "ModularGAN.g_use_ema = True" in s
+  # required arguments left unbound must be reported, not silently defaulted (runner_lib.py:73-76)
+  gin.clear_config()
+  from compare_gan_amd import runner_lib
+  with pytest.raises(Exception):
+    runner_lib.get_options_dict()
+
+
+def test_call_with_accepted_args():
+  from compare_gan_amd import utils
+
+  def f(a, b=2):
+    return a + b
+  assert utils.call_with_accepted_args(f, a=1, c=5) == 3
+  assert utils.call_with_accepted_args(f, a=1, b=5, zzz=0) == 6
+
+
+# -- C-ABI ---------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+  from compare_gan_amd.hip import _lib
+  assert os.path.exists(_lib.LIB_PATH), "run python -m compare_gan_amd.csrc.build"
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  declared = entry.declared_symbols()
+  assert len(declared) >= 60
+  for name in declared:
+    assert hasattr(lib, name), "libcgamd.so does not export %s" % name
+  # the ctypes binding covers exactly the declared surface
+  assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_library_argument_errors_without_gpu():
+  """Bad-argument paths return error codes before any launch (include/cgamd.h: never throws)."""
+  from compare_gan_amd.hip import _lib
+  lib = _lib.load()
+  assert lib.cg_abi_version() >= 1
+  geom = _lib.ConvGeom(0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+  rc = lib.cg_gconv(ctypes.byref(geom), None, None, None, 0, None, None, 0.0, None, 0.0, None, None)
+  assert rc == -1 and b"cg_gconv" in lib.cg_last_error()
+  geom = _lib.ConvGeom(1, 4, 4, 8, 4, 4, 8, 3, 3, 1, 3, 1, 1)    # U = 3 is not a power of two
+  rc = lib.cg_gconv(ctypes.byref(geom), None, None, None, 0, None, None, 0.0, None, 0.0, None, None)
+  assert rc == -2
+
+
+def test_product_refuses_cpu_tensors():
+  from compare_gan_amd.hip import kernels as K
+  with pytest.raises(ValueError, match="no CPU fallback"):
+    K.lrelu(torch.zeros(4, dtype=torch.bfloat16), 0.2)
+
+
+def test_product_never_imports_the_oracle():
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  bad = []
+  for dirpath, _, files in os.walk(os.path.join(root, "compare_gan_amd")):
+    for f in files:
+      if f.endswith(".py"):
+        text = open(os.path.join(dirpath, f)).read()
+        if "import oracle" in text or "from oracle" in text:
+          bad.append(os.path.join(dirpath, f))
+  assert not bad, bad
