@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcgamd.so")
-SOURCES = ["cg_error.hip", "cg_gconv.hip", "cg_elem.hip", "cg_bn.hip", "cg_sn.hip",
+SOURCES = ["cg_error.hip", "cg_gconv.hip", "cg_conv_fast.hip", "cg_elem.hip", "cg_bn.hip", "cg_sn.hip",
            "cg_optim.hip", "cg_attn.hip", "cg_fid.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -25,7 +25,8 @@ def _newer(src, dst):
 def _compile(src):
     obj = os.path.join(LIB_DIR, "obj", os.path.splitext(src)[0] + ".o")
     srcp = os.path.join(HERE, src)
-    deps = [srcp, os.path.join(HERE, "cg_common.h"), os.path.join(ROOT, "include", "cgamd.h")]
+    deps = [srcp, os.path.join(HERE, "cg_common.h"), os.path.join(HERE, "cg_conv_fast.h"),
+            os.path.join(ROOT, "include", "cgamd.h")]
     if any(_newer(d, obj) for d in deps):
         cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,17 @@
+// Internal interface of the fast convolution paths (cg_conv_fast.hip), used by the dispatchers in
+// cg_gconv.hip.  Not part of the C-ABI.
+#pragma once
+#include "cg_common.h"
+
+bool cg_fast_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                            float slope_in);
+void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                         int out_is_f32, const float* bias, const void* gate_in,
+                         const void* gate_out, float slope_out, const void* residual,
+                         hipStream_t st);
+
+bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                             float slope_in, const void* gate_dy);
+size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g);
+void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
+                          float* dw, int accumulate, float* dbias, void* ws, hipStream_t st);

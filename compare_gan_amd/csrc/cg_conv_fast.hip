@@ -1,0 +1,676 @@
+// Fast paths of the gather convolution for gfx950 (the shapes that carry the FLOPs of the hot path:
+// channel counts that are multiples of 64).  Contract and reference call sites: include/cgamd.h
+// (cg_gconv / cg_gwgrad); this file only adds faster kernels behind the same entry points.
+//
+// Design (MI355X_MICROARCH.md / cdna_hip_programming.md sections 2, 3, 5):
+//  * im2col-free implicit GEMM.  One K-slice = 64 consecutive channels of ONE filter tap, i.e. a
+//    128-byte contiguous run per output pixel, so a tile row is one cache line and the tap decode is
+//    wave-uniform (scalar registers); per-lane work in the K loop is a bounds test and an add.
+//  * global -> LDS with the direct-to-LDS DMA (global_load_lds_dwordx4): no staging VGPRs, no
+//    ds_write pass.  The LDS image is lane-linear, so the bank-conflict swizzle is applied on the
+//    per-lane SOURCE address (16-byte chunk c of row r is stored at slot c ^ ((r >> 1) & 7)) and on
+//    the fragment reads; with 128-byte rows this makes every ds_read_b128 lane group hit 16 distinct
+//    16-byte slots.  Out-of-image taps / out-of-range rows read a 16-byte zero page instead.
+//  * zero-inserted inputs (resnet_ops.unpool + conv, conv2d_transpose, the data gradient of a
+//    stride-2 conv) are decomposed into U*U output phases, each a dense convolution over the taps
+//    that can touch a non-zero sample: no MAC is spent on structural zeros (4x fewer for U = 2).
+//  * MFMA operands are swapped (D[co][pixel] = W^T X^T) so that every lane owns 4 consecutive output
+//    channels of one pixel: the epilogue (bias, ReLU'-gate, residual) runs on 8-byte vectors and
+//    stores 8 (bf16) / 16 (fp32) bytes per lane.
+//  * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous range
+//    of tiles, neighbouring M tiles share their halo rows and the weight panel in that L2.
+//  * weight gradient: both operands are K(=pixel)-major in memory but the MFMA wants K contiguous
+//    per lane; the 4x4 hardware transpose read ds_read_b64_tr_b16 delivers exactly that from the
+//    row-major LDS image, so the DMA staging is shared with the forward kernel.
+#include "cg_conv_fast.h"
+
+#define CG_FAST_BIAS_SPLITS 64
+
+namespace {
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ void glds16(const void* gptr, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gptr, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8_t relu_bf16x8(bf16x8_t v) {
+  // bf16 sign bit == int16 sign bit: max_i16(x, 0) is relu(x) (and maps -0.0 to +0.0)
+  s16x8_t s = __builtin_bit_cast(s16x8_t, v);
+  const s16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  s = __builtin_elementwise_max(s, z);
+  return __builtin_bit_cast(bf16x8_t, s);
+}
+
+// bijective XCD remap (block b runs on XCD b % 8): XCD x owns a contiguous range of work ids
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// -------------------------------------------------------------------------------------------
+// forward / data-gradient / transposed convolution
+// -------------------------------------------------------------------------------------------
+struct FastConvArgs {
+  const bf16_t* in;
+  const bf16_t* bt;
+  void* out;
+  const float* bias;
+  const bf16_t* gate_out;
+  const bf16_t* residual;
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, U, pt, pl;
+  int Kp;
+  int Hp, Wp, Mp;  // per-phase output grid (Ho/U, Wo/U) and N*Hp*Wp
+  int cblocks;     // Ci / 64
+  int mtiles, ntiles;
+  int relu_in, out_f32;
+  float slope_out;
+  FastDiv dWp, dHp, dNt;
+};
+
+template <int BM, bool RELU>
+__global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
+  constexpr int BN = 128;
+  constexpr int AJ = BM / 32;  // A staging instructions per wave (8 rows of 128 B each)
+  constexpr int TM = BM / 64;  // 32-pixel MFMA tiles per wave
+  constexpr int A_ELEMS = BM * 64, B_ELEMS = BN * 64;
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (A_ELEMS + B_ELEMS)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = (int)fdiv((uint32_t)wg, a.dNt);
+  const int nt = wg - mt * a.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- phase geometry (wave-uniform) ----
+  const int phase = blockIdx.y;
+  int r0 = 0, s0 = 0, nr = a.kh, ns = a.kw, bh = -a.pt, bw = -a.pl, ph = 0, pw = 0;
+  if (a.U == 2) {
+    ph = phase >> 1;
+    pw = phase & 1;
+    r0 = (a.pt + ph) & 1;
+    s0 = (a.pl + pw) & 1;
+    nr = (a.kh - r0 + 1) >> 1;
+    ns = (a.kw - s0 + 1) >> 1;
+    bh = (ph - a.pt + r0) >> 1;  // exact: the numerator is even
+    bw = (pw - a.pl + s0) >> 1;
+  }
+  const int nk = nr * ns * a.cblocks;
+
+  // ---- per-thread staging descriptors ----
+  // instruction group g = wave*AJ + j stages rows g*8 .. g*8+7; lane -> row g*8 + (lane >> 3),
+  // LDS slot (lane & 7) which must hold source chunk (lane & 7) ^ ((row >> 1) & 7)
+  int a_off[AJ], a_ih[AJ], a_iw[AJ];
+  bool a_ok[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int g = wave * AJ + j;
+    const int row = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    a_ok[j] = m < a.Mp;
+    const uint32_t mm = a_ok[j] ? (uint32_t)m : 0u;
+    const uint32_t t1 = fdiv(mm, a.dWp);
+    const int owp = (int)(mm - t1 * a.Wp);
+    const uint32_t n = fdiv(t1, a.dHp);
+    const int ohp = (int)(t1 - n * a.Hp);
+    a_ih[j] = (a.U == 2) ? ohp + bh : ohp * a.S + bh;
+    a_iw[j] = (a.U == 2) ? owp + bw : owp * a.S + bw;
+    a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.Ci + c * 8;
+  }
+  int b_off[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = wave * 4 + j;
+    const int row = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    b_ok[j] = (n0 + row) < a.Co;
+    b_off[j] = (n0 + row) * a.Kp + c * 8;
+  }
+
+  auto Abuf = [&](int buf) { return smem + buf * (A_ELEMS + B_ELEMS); };
+  auto Bbuf = [&](int buf) { return smem + buf * (A_ELEMS + B_ELEMS) + A_ELEMS; };
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  // tap iteration state of the NEXT slice to stage (all scalar)
+  int st_ri = 0, st_si = 0, st_cb = 0;
+  auto stage = [&](int buf) {
+    const int tapoff = (st_ri * a.Win + st_si) * a.Ci + st_cb * 64;
+    const int koff = ((r0 + a.U * st_ri) * a.kw + (s0 + a.U * st_si)) * a.Ci + st_cb * 64;
+    bf16_t* Ab = Abuf(buf) + (wave * AJ) * 512;
+    bf16_t* Bb = Bbuf(buf) + (wave * 4) * 512;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const bool ok = a_ok[j] && (unsigned)(a_ih[j] + st_ri) < (unsigned)a.Hin &&
+                      (unsigned)(a_iw[j] + st_si) < (unsigned)a.Win;
+      const bf16_t* p = ok ? a.in + (int64_t)(a_off[j] + tapoff) : zero;
+      glds16(p, Ab + j * 512);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t* p = b_ok[j] ? a.bt + (int64_t)(b_off[j] + koff) : zero;
+      glds16(p, Bb + j * 512);
+    }
+    if (++st_cb == a.cblocks) {
+      st_cb = 0;
+      if (++st_si == ns) {
+        st_si = 0;
+        ++st_ri;
+      }
+    }
+  };
+
+  f32x16_t acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // fragment addressing: row = base + (lane & 31), chunk = kk*2 + (lane >> 5), swizzled
+  const int frow = lane & 31;
+  const int swz = (frow >> 1) & 7;
+  int koffs[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koffs[kk] = (((kk * 2 + (lane >> 5)) ^ swz) << 3);
+  const int arow0 = (wm * (BM / 2) + frow) * 64;
+  const int brow0 = (wn * 64 + frow) * 64;
+
+  if (nk > 0) {
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) stage(buf ^ 1);
+    const bf16_t* Ab = Abuf(buf);
+    const bf16_t* Bb = Bbuf(buf);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t af[TM], bfr[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
+        if (RELU) af[i] = relu_bf16x8(af[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel (lane & 31) of each M sub-tile and, per 8-channel group q, the
+  // 4 consecutive channels 8*q + 4*(lane >> 5) + {0..3}
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + frow;
+    if (m >= a.Mp) continue;
+    const uint32_t t1 = fdiv((uint32_t)m, a.dWp);
+    const int owp = m - (int)t1 * a.Wp;
+    const uint32_t n = fdiv(t1, a.dHp);
+    const int ohp = (int)t1 - (int)n * a.Hp;
+    const int64_t opix =
+        ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + wn * 64 + j * 32 + q * 8 + 4 * (lane >> 5);
+        if (co >= a.Co) continue;
+        float v0 = acc[i][j][q * 4 + 0], v1 = acc[i][j][q * 4 + 1], v2 = acc[i][j][q * 4 + 2],
+              v3 = acc[i][j][q * 4 + 3];
+        if (a.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+          v0 += b4.x; v1 += b4.y; v2 += b4.z; v3 += b4.w;
+        }
+        const int64_t o = opix + co;
+        if (a.gate_out) {
+          const uint2 g2 = *reinterpret_cast<const uint2*>(a.gate_out + o);
+          if (!(bf2f((bf16_t)(g2.x & 0xffff)) > 0.f)) v0 *= a.slope_out;
+          if (!(bf2f((bf16_t)(g2.x >> 16)) > 0.f)) v1 *= a.slope_out;
+          if (!(bf2f((bf16_t)(g2.y & 0xffff)) > 0.f)) v2 *= a.slope_out;
+          if (!(bf2f((bf16_t)(g2.y >> 16)) > 0.f)) v3 *= a.slope_out;
+        }
+        if (a.residual) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(a.residual + o);
+          v0 += bf2f((bf16_t)(r2.x & 0xffff));
+          v1 += bf2f((bf16_t)(r2.x >> 16));
+          v2 += bf2f((bf16_t)(r2.y & 0xffff));
+          v3 += bf2f((bf16_t)(r2.y >> 16));
+        }
+        if (a.out_f32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) =
+              make_float4(v0, v1, v2, v3);
+        } else {
+          uint2 w2;
+          w2.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+          w2.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o) = w2;
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// weight gradient
+// -------------------------------------------------------------------------------------------
+struct FastWgradArgs {
+  const bf16_t* in;
+  const bf16_t* dy;
+  float* out;       // dw (splits == 1) or partials [splits][K*Co]
+  float* bias_out;  // NULL, dbias (splits == 1) or partials [splits][Co]
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, U, pt, pl;
+  int Hp, Wp, Mp;   // per-phase output grid
+  int K;            // kh*kw*Ci
+  int cblocks;      // Ci / 128
+  int ktiles, ntiles;
+  int rows_per_split;  // multiple of 64
+  int relu_in, accumulate;
+  FastDiv dWp, dHp, dCb, dNt;
+};
+
+// tile: 128 (k: one tap x 128 channels) x 128 (co), reduction over pixels in slices of 64 rows.
+// LDS rows are 256 B (128 channels); chunk c (16 B) of row r is stored at slot c ^ ((r & 3) << 1),
+// which spreads the 4 rows of every transpose-read block over 4 distinct 32-byte bank windows.
+template <bool RELU>
+__global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
+  constexpr int MR = 64;
+  constexpr int X_ELEMS = MR * 128, Y_ELEMS = MR * 128;
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (X_ELEMS + Y_ELEMS)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int kt = (int)fdiv((uint32_t)wg, a.dNt);
+  const int nt = wg - kt * a.ntiles;
+  const int c0 = nt * 128;
+  // k tile -> (tap, channel block)
+  const int tap = (int)fdiv((uint32_t)kt, a.dCb);
+  const int cb = kt - tap * a.cblocks;
+  const int r = tap / a.kw, s = tap - r * a.kw;
+  int ph = 0, pw = 0, bh, bw;
+  if (a.U == 2) {
+    ph = (a.pt + r) & 1;
+    pw = (a.pl + s) & 1;
+    bh = (ph - a.pt + r) >> 1;
+    bw = (pw - a.pl + s) >> 1;
+  } else {
+    bh = r - a.pt;
+    bw = s - a.pl;
+  }
+  const int mbeg = blockIdx.y * a.rows_per_split;
+  const int mend = min(a.Mp, mbeg + a.rows_per_split);
+  const int nit = (mend - mbeg + MR - 1) / MR;
+
+  // staging: instruction group g = wave*4 + j covers rows g*4 .. g*4+3 (256 B each);
+  // lane -> row g*4 + (lane >> 4), LDS slot lane & 15 <- source chunk (lane & 15) ^ ((row & 3) << 1)
+  const int srow = lane >> 4;                       // row & 3
+  const int schunk = (lane & 15) ^ (srow << 1);
+  const bool y_ok = (c0 + schunk * 8) < a.Co;       // Co % 8 == 0
+  auto Xbuf = [&](int buf) { return smem + buf * (X_ELEMS + Y_ELEMS); };
+  auto Ybuf = [&](int buf) { return smem + buf * (X_ELEMS + Y_ELEMS) + X_ELEMS; };
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  auto stage = [&](int buf, int it) {
+    const int mb = mbeg + it * MR;
+    bf16_t* Xb = Xbuf(buf) + (wave * 4) * 512;
+    bf16_t* Yb = Ybuf(buf) + (wave * 4) * 512;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + (wave * 4 + j) * 4 + srow;
+      const bool mok = m < mend;
+      const uint32_t mm = mok ? (uint32_t)m : 0u;
+      const uint32_t t1 = fdiv(mm, a.dWp);
+      const int owp = (int)(mm - t1 * a.Wp);
+      const uint32_t n = fdiv(t1, a.dHp);
+      const int ohp = (int)(t1 - n * a.Hp);
+      const int ih = (a.U == 2) ? ohp + bh : ohp * a.S + bh;
+      const int iw = (a.U == 2) ? owp + bw : owp * a.S + bw;
+      const bool xok = mok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const int64_t xoff =
+          ((int64_t)((int)n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * 128 + schunk * 8;
+      glds16(xok ? a.in + xoff : zero, Xb + j * 512);
+      const int64_t yoff =
+          ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + c0 +
+          schunk * 8;
+      glds16((mok && y_ok) ? a.dy + yoff : zero, Yb + j * 512);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  float bias_acc = 0.f;
+  const bool do_bias = (a.bias_out != nullptr) && (kt == 0);
+
+  // transpose-read addressing.  MFMA operand element (col = lane & 31, k = (lane >> 5)*8 + e):
+  // a 16-lane group reads a [4 rows][16 cols] block, lane supplying row (l16 >> 2), 4 consecutive
+  // columns (l16 & 3)*4 and receiving column l16 of the 4 rows.
+  const int l16 = lane & 15;
+  const int trow = l16 >> 2;                                 // row within the 4-row block
+  const int tcol = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;   // element column within a 32-col tile
+  const int mrow0 = (lane >> 5) * 8 + trow;                  // + mm*16 (+4 for the second read)
+  auto tr_addr = [&](const bf16_t* base, int row, int col) {
+    // row-major [64][128] image with the 16-byte chunk swizzle
+    const int chunk = (col >> 3) ^ ((row & 3) << 1);
+    return base + row * 128 + chunk * 8 + (col & 7);
+  };
+
+  if (nit > 0) {
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) stage(buf ^ 1, it + 1);
+    const bf16_t* Xb = Xbuf(buf);
+    const bf16_t* Yb = Ybuf(buf);
+#pragma unroll
+    for (int mm = 0; mm < MR / 16; ++mm) {
+      bf16x8_t xf[2], yf[2];
+      const int row = mm * 16 + mrow0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = wk * 64 + i * 32 + tcol;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Xb, row, col));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Xb, row + 4, col));
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        xf[i] = __builtin_bit_cast(bf16x8_t, v);
+        if (RELU) xf[i] = relu_bf16x8(xf[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + tcol;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Yb, row, col));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Yb, row + 4, col));
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        yf[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bias && tid < 128) {
+      // column sums of the dy tile (bias gradient); slot of (row, chunk c) is c ^ ((row & 3) << 1)
+#pragma unroll 8
+      for (int rr = 0; rr < MR; ++rr) {
+        const int chunk = (tid >> 3) ^ ((rr & 3) << 1);
+        bias_acc += bf2f(Yb[rr * 128 + chunk * 8 + (tid & 7)]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const bool direct = (gridDim.y == 1);
+  float* outp = a.out + (direct ? 0 : (int64_t)blockIdx.y * a.K * a.Co);
+  const int kbase = tap * a.Ci + cb * 128;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = c0 + wn * 64 + j * 32 + (lane & 31);
+      if (co >= a.Co) continue;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = kbase + wk * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        const int64_t o = (int64_t)k * a.Co + co;
+        if (direct && a.accumulate)
+          outp[o] += acc[i][j][v];
+        else
+          outp[o] = acc[i][j][v];
+      }
+    }
+  }
+  if (do_bias && tid < 128 && c0 + tid < a.Co) {
+    float* bp = a.bias_out + (direct ? 0 : (int64_t)blockIdx.y * a.Co);
+    if (direct && a.accumulate)
+      bp[c0 + tid] += bias_acc;
+    else
+      bp[c0 + tid] = bias_acc;
+  }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i], 4 floats per thread
+__global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restrict__ part,
+                                                            int splits, int64_t n4,
+                                                            float* __restrict__ out,
+                                                            int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < splits; ++z) {
+    const float4 p = reinterpret_cast<const float4*>(part)[(int64_t)z * n4 + i];
+    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+  }
+  float4* o = reinterpret_cast<float4*>(out) + i;
+  if (accumulate) {
+    const float4 q = *o;
+    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+  }
+  *o = s;
+}
+
+// part[z][c] = sum over rows [z*rps, (z+1)*rps) of y[row][c]   (bias gradient when the weight
+// gradient itself only visits one output phase per tap); 8 channels per thread, 8 rows in flight
+__global__ __launch_bounds__(256) void colsum_part8_kernel(const bf16_t* __restrict__ y,
+                                                           int64_t rows, int C, int64_t rps,
+                                                           float* __restrict__ part) {
+  __shared__ float sm[8][32][9];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int cv = blockIdx.x * 32 + cg;
+  const int64_t r0 = (int64_t)blockIdx.y * rps, r1 = min(rows, r0 + rps);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (cv * 8 < C) {
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      union { uint4 q; bf16_t h[8]; } v;
+      v.q = *reinterpret_cast<const uint4*>(y + r * C + (int64_t)cv * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += bf2f(v.h[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sm[rl][cg][e] = s[e];
+  __syncthreads();
+  const int cg2 = threadIdx.x >> 3, e2 = threadIdx.x & 7;
+  const int cv2 = blockIdx.x * 32 + cg2;
+  if (cv2 * 8 < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += sm[r][cg2][e2];
+    part[(int64_t)blockIdx.y * C + cv2 * 8 + e2] = t;
+  }
+}
+
+int ilog2x(int x) {
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return ((1 << l) == x) ? l : -1;
+}
+
+bool phase_ok(const cgConvGeom* g) {
+  if (g->U == 1) return true;
+  return g->U == 2 && g->S == 1 && (g->Ho % 2) == 0 && (g->Wo % 2) == 0;
+}
+
+}  // namespace
+
+bool cg_fast_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                            float slope_in) {
+  if (g->Ci % 64 != 0 || g->Co % 4 != 0) return false;
+  if (!phase_ok(g)) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  if ((int64_t)g->N * g->Hin * g->Win * g->Ci >= (1ll << 31)) return false;
+  if ((int64_t)g->Co * (((int64_t)g->kh * g->kw * g->Ci + 7) & ~7ll) >= (1ll << 31)) return false;
+  return true;
+}
+
+void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                         int out_is_f32, const float* bias, const void* gate_in,
+                         const void* gate_out, float slope_out, const void* residual,
+                         hipStream_t st) {
+  FastConvArgs a;
+  a.in = (const bf16_t*)in;
+  a.bt = (const bf16_t*)bt;
+  a.out = out;
+  a.bias = bias;
+  a.gate_out = (const bf16_t*)gate_out;
+  a.residual = (const bf16_t*)residual;
+  a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
+  a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;
+  a.S = g->S; a.U = g->U; a.pt = g->pt; a.pl = g->pl;
+  a.Kp = (g->kh * g->kw * g->Ci + 7) & ~7;
+  a.Hp = g->Ho / g->U; a.Wp = g->Wo / g->U;
+  a.Mp = g->N * a.Hp * a.Wp;
+  a.cblocks = g->Ci / 64;
+  a.relu_in = gate_in != nullptr;
+  a.out_f32 = out_is_f32;
+  a.slope_out = slope_out;
+  a.dWp = make_fastdiv(a.Wp); a.dHp = make_fastdiv(a.Hp);
+  const int phases = g->U * g->U;
+  a.ntiles = cdiv(g->Co, 128);
+  a.dNt = make_fastdiv(a.ntiles);
+  const int tiles128 = cdiv(a.Mp, 128) * a.ntiles * phases;
+  if (tiles128 >= 256) {
+    a.mtiles = cdiv(a.Mp, 128);
+    dim3 grid(a.mtiles * a.ntiles, phases);
+    if (a.relu_in)
+      fast_conv_kernel<128, true><<<grid, 256, 0, st>>>(a);
+    else
+      fast_conv_kernel<128, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    a.mtiles = cdiv(a.Mp, 64);
+    dim3 grid(a.mtiles * a.ntiles, phases);
+    if (a.relu_in)
+      fast_conv_kernel<64, true><<<grid, 256, 0, st>>>(a);
+    else
+      fast_conv_kernel<64, false><<<grid, 256, 0, st>>>(a);
+  }
+}
+
+bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                             float slope_in, const void* gate_dy) {
+  if (g->Ci % 128 != 0 || g->Co % 8 != 0) return false;
+  if (!phase_ok(g)) return false;
+  if (gate_dy) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  if ((int64_t)g->kh * g->kw * g->Ci * g->Co >= (1ll << 31)) return false;
+  return true;
+}
+
+void cg_fast_wgrad_plan(const cgConvGeom* g, int* splits, int* rows_per_split) {
+  const int Mp = g->N * (g->Ho / g->U) * (g->Wo / g->U);
+  const int tiles = g->kh * g->kw * (g->Ci / 128) * cdiv(g->Co, 128);
+  int s = cdiv(512, tiles);
+  const int max_by_rows = Mp / 128 > 0 ? Mp / 128 : 1;  // >= 2 slices of 64 rows per split
+  if (s > max_by_rows) s = max_by_rows;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  int rps = cdiv(Mp, s);
+  rps = (rps + 63) / 64 * 64;
+  s = cdiv(Mp, rps);
+  *splits = s;
+  *rows_per_split = rps;
+}
+
+size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g) {
+  int splits, rps;
+  cg_fast_wgrad_plan(g, &splits, &rps);
+  const size_t K = (size_t)g->kh * g->kw * g->Ci;
+  size_t need = 256;
+  if (splits > 1) need = (size_t)splits * (K * g->Co + g->Co) * sizeof(float);
+  const size_t bias_need = (size_t)CG_FAST_BIAS_SPLITS * g->Co * sizeof(float);
+  if (g->U != 1 && need < bias_need) need = bias_need;
+  return align_up(need, 256);
+}
+
+void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
+                          const void* dy, float* dw, int accumulate, float* dbias, void* ws,
+                          hipStream_t st) {
+  int splits, rps;
+  cg_fast_wgrad_plan(g, &splits, &rps);
+  FastWgradArgs a;
+  a.in = (const bf16_t*)in;
+  a.dy = (const bf16_t*)dy;
+  a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
+  a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;
+  a.S = g->S; a.U = g->U; a.pt = g->pt; a.pl = g->pl;
+  a.Hp = g->Ho / g->U; a.Wp = g->Wo / g->U;
+  a.Mp = g->N * a.Hp * a.Wp;
+  a.K = g->kh * g->kw * g->Ci;
+  a.cblocks = g->Ci / 128;
+  a.ktiles = g->kh * g->kw * a.cblocks;
+  a.ntiles = cdiv(g->Co, 128);
+  a.rows_per_split = rps;
+  a.relu_in = gate_in != nullptr;
+  a.accumulate = accumulate;
+  a.dWp = make_fastdiv(a.Wp); a.dHp = make_fastdiv(a.Hp);
+  a.dCb = make_fastdiv(a.cblocks); a.dNt = make_fastdiv(a.ntiles);
+  float* wsf = (float*)ws;
+  const size_t KC = (size_t)a.K * g->Co;
+  // with zero insertion every tap only visits one output phase, so the bias gradient (a sum over
+  // ALL output pixels) is reduced by its own pass below
+  const bool bias_in_kernel = dbias && g->U == 1;
+  if (splits == 1) {
+    a.out = dw;
+    a.bias_out = bias_in_kernel ? dbias : nullptr;
+  } else {
+    a.out = wsf;
+    a.bias_out = bias_in_kernel ? wsf + (size_t)splits * KC : nullptr;
+  }
+  dim3 grid(a.ktiles * a.ntiles, splits);
+  if (a.relu_in)
+    fast_wgrad_kernel<true><<<grid, 256, 0, st>>>(a);
+  else
+    fast_wgrad_kernel<false><<<grid, 256, 0, st>>>(a);
+  const int64_t c4 = g->Co / 4;
+  if (splits > 1) {
+    const int64_t n4 = (int64_t)(KC / 4);  // Ci % 128 == 0 and Co % 8 == 0 -> divisible
+    split_reduce4_kernel<<<cdiv(n4, 256), 256, 0, st>>>(wsf, splits, n4, dw, accumulate);
+    if (bias_in_kernel)
+      split_reduce4_kernel<<<cdiv(c4, 256), 256, 0, st>>>(wsf + (size_t)splits * KC, splits, c4,
+                                                         dbias, accumulate);
+  }
+  if (dbias && !bias_in_kernel) {
+    // stream-ordered after the reduce above: the partial area of the workspace is free again
+    const int64_t rows = (int64_t)g->N * g->Ho * g->Wo;
+    int bs = (int)(rows / 256 > 0 ? rows / 256 : 1);
+    if (bs > CG_FAST_BIAS_SPLITS) bs = CG_FAST_BIAS_SPLITS;
+    const int64_t rps = (rows + bs - 1) / bs;
+    bs = (int)((rows + rps - 1) / rps);
+    dim3 bgrid(cdiv(g->Co / 8, 32), bs);
+    colsum_part8_kernel<<<bgrid, 256, 0, st>>>((const bf16_t*)dy, rows, g->Co, rps, wsf);
+    split_reduce4_kernel<<<cdiv(c4, 256), 256, 0, st>>>(wsf, bs, c4, dbias, accumulate);
+  }
+}

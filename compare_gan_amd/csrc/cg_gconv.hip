@@ -8,6 +8,7 @@
 // (BM/WM) x (BN/WN) sub-tile built from v_mfma_f32_32x32x16_bf16.  LDS rows are padded by 16 B
 // (144 B stride) which makes every ds_read_b128 fragment read bank-conflict free.
 #include "cg_common.h"
+#include "cg_conv_fast.h"
 
 namespace {
 
@@ -609,6 +610,19 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   int rc = check_geom(g, "cg_gconv");
   if (rc) return rc;
   if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
+  if (cg_fast_conv_supported(g, in, gate_in, slope_in)) {
+    hipStream_t fst = (hipStream_t)stream;
+    if (cg_prof_enabled()) {
+      double flops, bytes;
+      algorithmic_cost(g, &flops, &bytes);
+      cg_prof_begin(CG_PROF_GCONV_MAIN, flops, bytes, fst);
+    }
+    cg_fast_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
+                        fst);
+    cg_prof_end(CG_PROF_GCONV_MAIN, fst);
+    CG_CHECK_LAUNCH("cg_gconv(fast)");
+    return CG_OK;
+  }
   GConvArgs a;
   a.in = (const bf16_t*)in;
   a.bt = (const bf16_t*)bt;
@@ -630,7 +644,7 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   a.dCi = make_fastdiv(g->Ci); a.dKw = make_fastdiv(g->kw);
   const bool vec = (g->Ci % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
-  const int fam = (g->Co > 64 && vec) ? CG_PROF_GCONV_MAIN : CG_PROF_GCONV_OTHER;
+  const int fam = CG_PROF_GCONV_OTHER;
   if (cg_prof_enabled()) {
     double flops, bytes;
     algorithmic_cost(g, &flops, &bytes);
@@ -646,6 +660,8 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   CG_CHECK_LAUNCH("cg_gconv");
   return CG_OK;
 }
+
+static size_t gwgrad_slow_workspace_bytes(const cgConvGeom* g);
 
 static void wgrad_plan(const cgConvGeom* g, int* tk, int* tn, int* splits, int* rows_per_split) {
   const int K = g->kh * g->kw * g->Ci;
@@ -667,6 +683,15 @@ static void wgrad_plan(const cgConvGeom* g, int* tk, int* tn, int* splits, int* 
 
 extern "C" size_t cg_gwgrad_workspace_bytes(const cgConvGeom* g) {
   if (!g) return 0;
+  // the fast path may or may not be taken (it depends on the gates): size for the larger need
+  size_t fast = 0;
+  if (cg_fast_wgrad_supported(g, nullptr, nullptr, 0.f, nullptr))
+    fast = cg_fast_wgrad_workspace_bytes(g);
+  const size_t slow = gwgrad_slow_workspace_bytes(g);
+  return fast > slow ? fast : slow;
+}
+
+static size_t gwgrad_slow_workspace_bytes(const cgConvGeom* g) {
   int tk, tn, splits, rps;
   wgrad_plan(g, &tk, &tn, &splits, &rps);
   if (splits == 1) return 256;
@@ -681,12 +706,24 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
   int rc = check_geom(g, "cg_gwgrad");
   if (rc) return rc;
   if (!in || !dy || !dw) CG_FAIL(CG_ERR_BAD_ARG, "cg_gwgrad: null tensor");
+  if (!ws || ws_bytes < cg_gwgrad_workspace_bytes(g))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_gwgrad: workspace too small (%zu < %zu)", ws_bytes,
+            cg_gwgrad_workspace_bytes(g));
+  if (cg_fast_wgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
+    hipStream_t fst = (hipStream_t)stream;
+    if (cg_prof_enabled()) {
+      double flops, bytes;
+      algorithmic_cost(g, &flops, &bytes);
+      cg_prof_begin(CG_PROF_GWGRAD_MAIN, flops, bytes, fst);
+    }
+    cg_fast_wgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, ws, fst);
+    cg_prof_end(CG_PROF_GWGRAD_MAIN, fst);
+    CG_CHECK_LAUNCH("cg_gwgrad(fast)");
+    return CG_OK;
+  }
   int tk, tn, splits, rps;
   wgrad_plan(g, &tk, &tn, &splits, &rps);
   const int K = g->kh * g->kw * g->Ci;
-  if (splits > 1 && (!ws || ws_bytes < cg_gwgrad_workspace_bytes(g)))
-    CG_FAIL(CG_ERR_WORKSPACE, "cg_gwgrad: workspace too small (%zu < %zu)", ws_bytes,
-            cg_gwgrad_workspace_bytes(g));
   GWgradArgs a;
   a.in = (const bf16_t*)in; a.gate_in = (const bf16_t*)gate_in;
   a.dy = (const bf16_t*)dy; a.gate_dy = (const bf16_t*)gate_dy;
@@ -710,8 +747,7 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(K, tk), cdiv(g->Co, tn), splits);
-  const int fam = (tk == 128 && tn == 128 && g->Ci % 8 == 0 && g->Co % 8 == 0)
-                      ? CG_PROF_GWGRAD_MAIN : CG_PROF_GWGRAD_OTHER;
+  const int fam = CG_PROF_GWGRAD_OTHER;
   if (cg_prof_enabled()) {
     double flops, bytes;
     algorithmic_cost(g, &flops, &bytes);

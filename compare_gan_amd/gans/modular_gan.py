@@ -70,15 +70,21 @@ class _OptimizerState(object):
     self.v = [torch.zeros_like(v, requires_grad=False) for v in self.params]
     self.ema = [v.detach().clone() for v in self.params] if with_ema else None
     self.table = None
+    self.zero_grads = {}
     self.captured_tables = []
+    self.reserved = []
     self.flat = None
     self.device = device
 
   def _ensure(self, grads):
     if torch.cuda.is_current_stream_capturing():
       # every captured update keeps its own table: its gradient tensors live at addresses that
-      # are fixed for all replays, and the table is only read when the graph runs
-      t = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v, self.ema)
+      # are fixed for all replays, and the table is only read when the graph runs.  The table
+      # bytes come from reserve_tables() (allocated outside the capture, never recycled).
+      if not self.reserved:
+        raise RuntimeError("call reserve_tables() before capturing an optimiser update")
+      t = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v, self.ema,
+                      table=self.reserved.pop())
       self.captured_tables.append(t)
       return t
     if self.table is None:
@@ -87,13 +93,21 @@ class _OptimizerState(object):
       self.table.set_grads(grads)
     return self.table
 
-  def apply_gradients(self, step, ema_decay=0.0, ema_start=0):
-    """All-reduce (data parallel) + fused Adam(+EMA).  step: device int64 update counter."""
-    grads = []
-    for n, p in zip(self.names, self.params):
-      if p.grad is None:
+  def reserve_tables(self, n):
+    """Device buffers for the Adam tables of `n` captured updates (see AdamTable)."""
+    nbytes = K.AdamTable.table_bytes(len(self.params))
+    self.reserved = [torch.empty(nbytes, dtype=torch.uint8, device=self.device) for _ in range(n)]
+
+  def apply_gradients(self, step, ema_decay=0.0, ema_start=0, grads=None):
+    """All-reduce (data parallel) + fused Adam(+EMA).  step: device int64 update counter.
+    grads: one tensor per variable (defaults to the variables' .grad fields)."""
+    if grads is None:
+      grads = [p.grad for p in self.params]
+    grads = list(grads)
+    for i, (n, g) in enumerate(zip(self.names, grads)):
+      if g is None:
         raise RuntimeError("variable %s received no gradient" % n)
-      grads.append(p.grad.contiguous())
+      grads[i] = g.contiguous()
     world = tpu_ops.num_replicas()
     scale = 1.0
     if world > 1:
@@ -330,13 +344,18 @@ class ModularGAN(AbstractGAN):
     features["generated"] = features["generated"].detach()
     self._set_requires_grad(self.g_opt, False)
     self._set_requires_grad(self.d_opt, True)
-    self._zero_grads(self.d_opt)
     with ops.use_store(self.store):
       self.create_loss(features, labels)
-    self.d_loss.backward()
-    self.d_opt.apply_gradients(self.global_step_disc)
+    # torch.autograd.grad hands the gradients over directly: no AccumulateGrad nodes, whose
+    # stream affinity would break hipGraph capture (they run on the stream they were created on)
+    grads = torch.autograd.grad(self.d_loss, self.d_opt.params, allow_unused=True)
+    self.d_opt.apply_gradients(self.global_step_disc, grads=self._fill_unused(self.d_opt, grads))
     K.counter_add(self.global_step_disc, 1)
-    return self.d_loss.detach()
+    self.d_loss = self.d_loss.detach()
+    if self.penalty_loss is not None:
+      self.penalty_loss = self.penalty_loss.detach()
+    self.g_loss = self.g_loss.detach()
+    return self.d_loss
 
   def _train_generator(self, features, labels):
     """One G update (+ EMA) (modular_gan.py:487-510); D's weights get no gradient."""
@@ -344,19 +363,35 @@ class ModularGAN(AbstractGAN):
     features["_generator_step"] = True
     self._set_requires_grad(self.d_opt, False)
     self._set_requires_grad(self.g_opt, True)
-    self._zero_grads(self.g_opt)
     with ops.use_store(self.store):
       sampled_y = None
       if self.conditional:
         sampled_y = self._get_one_hot_labels(features["sampled_labels"])
       features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
-    self.g_loss.backward()
+    grads = torch.autograd.grad(self.g_loss, self.g_opt.params, allow_unused=True)
     self.g_opt.apply_gradients(self.global_step, ema_decay=self._ema_decay,
-                               ema_start=self._ema_start_step)
+                               ema_start=self._ema_start_step,
+                               grads=self._fill_unused(self.g_opt, grads))
     K.counter_add(self.global_step, 1)
     self._set_requires_grad(self.d_opt, True)
-    return self.g_loss.detach()
+    self.g_loss = self.g_loss.detach()
+    self.d_loss = self.d_loss.detach()
+    return self.g_loss
+
+  @staticmethod
+  def _fill_unused(opt_state, grads):
+    """Variables the loss does not depend on get a zero gradient (tf.gradients returns None and
+    Adam skips them; with zero m/v a zero gradient is the same no-op, e.g. the attention block's
+    theta/phi kernels while sigma == 0 still receive exact zeros through the graph)."""
+    out = []
+    for n, p, g in zip(opt_state.names, opt_state.params, grads):
+      if g is None:
+        if n not in opt_state.zero_grads:
+          opt_state.zero_grads[n] = torch.zeros_like(p, requires_grad=False)
+        g = opt_state.zero_grads[n]
+      out.append(g)
+    return out
 
   @staticmethod
   def _set_requires_grad(opt_state, flag):
@@ -418,6 +453,8 @@ class ModularGAN(AbstractGAN):
         self.train_step(self._static_images, self._static_labels)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    self.d_opt.reserve_tables(self._disc_iters)
+    self.g_opt.reserve_tables(1)
     self._graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(self._graph):
       self._graph_out = self.train_step(self._static_images, self._static_labels)

@@ -128,8 +128,40 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("CGAMD_TRACE"):
+        lib = _TracingLib(lib)
     _lib = lib
     return lib
+
+
+class _TracingLib(object):
+    """Debug aid (CGAMD_TRACE=1): prints every C-ABI call and synchronises after it, so that a
+    faulting kernel is the last name printed."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("cg_") or name in ("cg_last_error", "cg_abi_version"):
+            return fn
+
+        def traced(*args):
+            import sys
+            import torch
+            desc = []
+            for a in args:
+                if hasattr(a, "_obj") and isinstance(a._obj, ConvGeom):
+                    desc.append(str(a._obj.key()))
+                elif isinstance(a, (int, float)):
+                    desc.append(repr(a))
+            sys.stderr.write("[cgamd] %s %s\n" % (name, " ".join(desc)))
+            sys.stderr.flush()
+            rc = fn(*args)
+            if not name.endswith("_bytes"):
+                torch.cuda.synchronize()
+            return rc
+        return traced
 
 
 def check(rc, what):

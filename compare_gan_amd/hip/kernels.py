@@ -517,9 +517,10 @@ class AdamTable(object):
     The table lives at a stable device address; set_grads() re-points the gradient column (the
     autograd engine hands out fresh gradient tensors every step) and re-uploads it.  While a
     hipGraph is being captured no host-to-device copy may be recorded, so the upload is deferred:
-    the kernels only read the table when the graph is replayed -- call flush() after capture."""
+    the kernels only read the table when the graph is replayed -- call flush() after capture.  The
+    table buffer of a captured update must be allocated BEFORE the capture (`table=`)."""
 
-    def __init__(self, params, grads, ms, vs, emas=None):
+    def __init__(self, params, grads, ms, vs, emas=None, table=None):
         n = len(params)
         self.entries = (_lib.AdamEntry * n)()
         chunk = 0
@@ -541,13 +542,25 @@ class AdamTable(object):
         self.total_chunks = chunk
         self.total_elems = off
         self.device = params[0].device
-        self.table = torch.empty(ctypes.sizeof(self.entries), dtype=torch.uint8,
-                                 device=self.device)
+        if table is None:
+            if torch.cuda.is_current_stream_capturing():
+                # memory handed out during a capture is recycled among the captured kernels: an
+                # earlier temporary of the same graph may own these bytes, and replaying it would
+                # overwrite the (uploaded-once) table
+                raise RuntimeError("AdamTable: pass a table buffer allocated before the capture")
+            table = torch.empty(ctypes.sizeof(self.entries), dtype=torch.uint8, device=self.device)
+        if table.numel() < ctypes.sizeof(self.entries) or table.dtype != torch.uint8:
+            raise ValueError("AdamTable: table buffer too small")
+        self.table = table
         self._offsets = None
         self._keep = (params, ms, vs, emas)
         self._grad_ptrs = None
         self.dirty = False
         self.set_grads(grads)
+
+    @staticmethod
+    def table_bytes(n_entries):
+        return ctypes.sizeof(_lib.AdamEntry) * n_entries
 
     @property
     def offsets(self):

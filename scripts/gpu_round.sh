@@ -9,7 +9,7 @@ echo "pytest rc=$?" >> gpurun_out/tests_$TAG.log
 timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_$TAG.log 2>&1
 echo "bench rc=$?" >> gpurun_out/bench_$TAG.log
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
 echo "rocprof rc=$?" >> $R/gpurun_out/prof_$TAG.log
 cd $R
 find gpurun_out/prof_$TAG -name "*.db" -delete 2>/dev/null

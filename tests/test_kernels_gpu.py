@@ -57,6 +57,15 @@ CONV_CASES = [
     ("up_1x1", 2, 8, 8, 64, 32, 1, 1, 2),
     ("s2_5x5_rgb", 2, 32, 32, 3, 64, 5, 2, 1),
     ("odd_stride2", 2, 9, 9, 16, 24, 3, 2, 1),
+    # fast (LDS-DMA) path: multi-tile, ragged M / Co tiles, phases, strides
+    ("fast_ragged", 3, 10, 10, 128, 192, 3, 1, 1),
+    ("fast_big", 8, 32, 32, 128, 128, 3, 1, 1),
+    ("fast_up_big", 4, 16, 16, 256, 256, 3, 1, 2),
+    ("fast_up_1x1", 2, 8, 8, 128, 64, 1, 1, 2),
+    ("fast_s2_4x4", 2, 32, 32, 128, 256, 4, 2, 1),
+    ("fast_s2_5x5", 2, 16, 16, 128, 128, 5, 2, 1),
+    ("fast_s2_3x3", 4, 16, 16, 256, 256, 3, 2, 1),
+    ("fast_1x1_wide", 2, 16, 16, 192, 384, 1, 1, 1),
 ]
 
 
@@ -97,7 +106,7 @@ def test_gconv_forward_adjoint_wgrad(K, dev, case):
 def test_gconv_gates_residual(K, dev, slope):
     """out = d(gate_out) * (conv(lrelu(x)) + b) + residual and its wgrad with gated operands."""
     g = _gen(7)
-    N, H, W, Ci, Co, k = 2, 8, 8, 64, 64, 3
+    N, H, W, Ci, Co, k = 2, 8, 8, 128, 64, 3
     x64, xb = rand_bf16((N, H, W, Ci), g)
     w64, wb = rand_bf16((k, k, Ci, Co), g, 0.05)
     go64, gob = rand_bf16((N, H, W, Co), g)
@@ -122,6 +131,13 @@ def test_gconv_gates_residual(K, dev, slope):
                      slope_dy=slope)
     assert_close_f32(dw, wr.grad, "gated wgrad", rtol=1e-4 if slope == 0 else 1e-2,
                      abs_rms=1e-4 if slope == 0 else 1e-2)
+    if slope == 0:
+        # ReLU self-gate only (the transposed-read LDS-DMA weight-gradient path), with bias grads
+        wr2 = w64.clone().requires_grad_(True)
+        (oops.conv2d_same(xr, wr2, 1) * dy64).sum().backward()
+        dw2, db2 = K.gwgrad(geom, xd, dyb.to(dev), gate_in=xd, slope_in=0.0, want_dbias=True)
+        assert_close_f32(dw2, wr2.grad, "relu-gated wgrad", rtol=1e-4, abs_rms=1e-4)
+        assert_close_f32(db2, dy64.sum(dim=(0, 1, 2)), "relu-gated dbias", rtol=2e-4, abs_rms=2e-4)
 
 
 DECONV_CASES = [("dcgan_5x5", 2, 4, 4, 64, 32, 5, 2), ("sndcgan_4x4", 2, 8, 8, 32, 16, 4, 2),
