@@ -42,15 +42,22 @@ def parse_args():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-budget-s", type=float, default=20.0)
+    p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
 
 
-def cpu_baseline(config, batch, steps):
-    """The oracle's train step on the host cores (bounded sample)."""
+def cpu_baseline(config, batch, budget_s=20.0):
+    """The oracle's train step on the host cores, bounded: whole unrolled steps are timed until
+    `budget_s` seconds of CPU work have been spent (at least one step)."""
     from oracle import arch_ops as oops
     from tests import gan_util as U
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
     vs = oops.VarStore(dtype=torch.float32, seed=1)
     ora = U.build_oracle(config, vs)
     nsub = ora.disc_iters + 1
@@ -58,20 +65,45 @@ def cpu_baseline(config, batch, steps):
     gen = torch.Generator().manual_seed(547)
     subs = [{"images": torch.rand(batch, h, w, c, generator=gen),
              "z": torch.rand(batch, 128, generator=gen) * 2 - 1} for _ in range(nsub)]
-    ora.train_step(subs)  # builds variables / warms the allocator
-    t0 = time.time()
-    for _ in range(steps):
+    steps, t0 = 0, time.time()
+    while True:
         ora.train_step(subs)
-    dt = time.time() - t0
+        steps += 1
+        dt = time.time() - t0
+        if dt >= budget_s or steps >= 8:
+            break
     return {"value": round(batch * nsub * steps / dt, 2), "unit": "img/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full unrolled steps (%d D + 1 G sub-steps) of %s at batch %d, fp32 "
-                      "PyTorch-CPU restatement of the reference (oracle/)" % (
-                          steps, ora.disc_iters, config, batch)}
+            "cores": cores, "kind": "port",
+            "sample": "%d full unrolled step(s) (%d D + 1 G sub-steps each) of %s at batch %d in "
+                      "%.1f s, fp32 PyTorch-CPU restatement of the reference (oracle/); the first "
+                      "step includes variable creation" % (steps, ora.disc_iters, config, batch, dt)}
+
+
+def cpu_baseline_guarded(config, batch, budget_s):
+    """Runs cpu_baseline in a child process under a hard timeout so that a slow or oversubscribed
+    host can never stall the benchmark line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", config,
+           "--batch-per-gpu", str(batch), "--cpu-budget-s", str(budget_s)]
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(120.0, 8 * budget_s),
+                           env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        note = "cpu baseline child failed: rc=%d %s" % (r.returncode, r.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        note = "cpu baseline exceeded its hard timeout"
+    return {"value": None, "unit": "img/s", "cores": 0, "kind": "port", "sample": note}
 
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.config, args.batch_per_gpu, args.cpu_budget_s)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,7 +209,7 @@ def main():
                          for k, v in fam.items()},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.config, bsz, args.cpu_steps)
+        result["cpu_baseline"] = cpu_baseline_guarded(args.config, bsz, args.cpu_budget_s)
 
     if rank == 0:
         print(json.dumps(result))

@@ -334,18 +334,16 @@ def deconv2d(inputs, output_shape, k_h, k_w, d_h, d_w, stddev=0.02, name="deconv
 # ------------------------------------------------------------------------------------------------
 # batch norm family (arch_ops.py:66-445)
 # ------------------------------------------------------------------------------------------------
-def _moments_for_inference(mean, variance, is_training, decay, use_moving_averages, num_channels):
-  """Returns (mean, var) to normalise with; creates / updates the inference statistics.
+def _moments_for_inference(is_training, use_moving_averages, num_channels):
+  """Creates the inference statistics; returns them.
 
-  arch_ops.py:66-119 (moving averages, zero_debias=False) and :122-191 (accumulators)."""
+  arch_ops.py:66-119 (moving averages, zero_debias=False): (moving_mean, moving_variance);
+  arch_ops.py:122-191 (accumulators): (accu_mean, accu_variance, accu_counter, update_accus)."""
+  del is_training
   c = [num_channels]
   if use_moving_averages:
     mm = get_variable("moving_mean", c, constant(0.0), trainable=False)
     mv = get_variable("moving_variance", c, constant(1.0), trainable=False)
-    if is_training:
-      if mean is not None:
-        K.bn_update_moving(mm, mv, mean, variance, decay)
-      return None, None
     return mm, mv
   with variable_scope("accu"):
     accu_mean = get_variable("accu_mean", c, constant(0.0), trainable=False)
@@ -353,8 +351,6 @@ def _moments_for_inference(mean, variance, is_training, decay, use_moving_averag
     accu_counter = get_variable("accu_counter", [], constant(1e-12), trainable=False)
     update_accus = get_variable("update_accus", [], constant(0), trainable=False,
                                 dtype=torch.int32)
-  if is_training:
-    return None, None
   return accu_mean, accu_var, accu_counter, update_accus
 
 
@@ -377,16 +373,15 @@ def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_forma
     use_cross_replica_mean = tpu_ops.in_replica_context()   # arch_ops.py:258-263
   num_channels = inputs.shape[-1]
   sync_fn = tpu_ops.SyncMoments() if use_cross_replica_mean else None
+  stats = _moments_for_inference(is_training, use_moving_averages, num_channels)
   if inputs.is_meta:
-    _moments_for_inference(None, None, is_training, decay, use_moving_averages, num_channels)
     return inputs
   inputs = _to_bf16(inputs)
   if is_training:
-    out, mean, var = Fn.batch_norm_act(inputs, gamma, beta, None, None, epsilon, per_sample, relu,
-                                       sync_fn)
-    _moments_for_inference(mean, var, True, decay, use_moving_averages, num_channels)
+    moving = (stats[0], stats[1], decay) if use_moving_averages else None
+    out, _, _ = Fn.batch_norm_act(inputs, gamma, beta, None, None, epsilon, per_sample, relu,
+                                  sync_fn, moving)
     return out
-  stats = _moments_for_inference(None, None, False, decay, use_moving_averages, num_channels)
   if use_moving_averages:
     mean, var = stats
   else:

@@ -85,19 +85,42 @@ __global__ __launch_bounds__(256) void bn_stats_part_scalar_kernel(const bf16_t*
     p[C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
   }
 }
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int splits, int C,
-                                      float inv_rows, float* __restrict__ mean,
-                                      float* __restrict__ var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one block per 32 channels: 8 split-lanes per channel sum the partials, LDS combines them.
+// Optionally folds the moving-average update m <- m - (1-decay)(m - batch) (arch_ops.py:105-114).
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part,
+                                                             int splits, int C, float inv_rows,
+                                                             float* __restrict__ mean,
+                                                             float* __restrict__ var,
+                                                             float* __restrict__ mm,
+                                                             float* __restrict__ mv, float decay) {
+  __shared__ float sm[2][8][33];
+  const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f, q = 0.f;
-  for (int z = 0; z < splits; ++z) {
-    s += part[(int64_t)z * 2 * C + c];
-    q += part[(int64_t)z * 2 * C + C + c];
+  if (c < C)
+    for (int z = zl; z < splits; z += 8) {
+      s += part[(int64_t)z * 2 * C + c];
+      q += part[(int64_t)z * 2 * C + C + c];
+    }
+  sm[0][zl][cl] = s;
+  sm[1][zl][cl] = q;
+  __syncthreads();
+  if (zl == 0 && c < C) {
+    float ss = 0.f, qq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      ss += sm[0][r][cl];
+      qq += sm[1][r][cl];
+    }
+    const float m = ss * inv_rows;
+    const float v = qq * inv_rows - m * m;  // tf.nn.normalize_moments(shift=None)
+    mean[c] = m;
+    var[c] = v;
+    if (mm) {
+      mm[c] -= (1.f - decay) * (mm[c] - m);
+      mv[c] -= (1.f - decay) * (mv[c] - v);
+    }
   }
-  const float m = s * inv_rows;
-  mean[c] = m;
-  var[c] = q * inv_rows - m * m;  // tf.nn.normalize_moments(shift=None)
 }
 inline int stats_splits(int64_t rows, int C) {
   const int ct = (C % 8 == 0) ? cdiv(C / 8, 32) : cdiv(C, 64);
@@ -105,52 +128,130 @@ inline int stats_splits(int64_t rows, int C) {
   const int64_t maxs = rows / 32 > 0 ? rows / 32 : 1;
   if (s > maxs) s = (int)maxs;
   if (s < 1) s = 1;
-  if (s > 256) s = 256;
+  if (s > 64) s = 64;
   return s;
 }
 
 // ---- apply -----------------------------------------------------------------------------------
-template <bool VEC>
-__global__ void bn_apply_kernel(const bf16_t* __restrict__ x, int HW, int C, int64_t total_units,
-                                const float* __restrict__ mean, const float* __restrict__ var,
-                                float eps, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, int per_sample, int relu,
-                                bf16_t* __restrict__ y) {
-  const int CV = VEC ? C / 8 : C;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_units; i += stride) {
-    const int cv = (int)(i % CV);
-    const int64_t row = i / CV;
-    const int64_t n = row / HW;
-    const int c0 = VEC ? cv * 8 : cv;
-    const int64_t pidx = per_sample ? n * C + c0 : c0;
-    if (VEC) {
-      V8 v, o;
-      v.q = *reinterpret_cast<const uint4*>(x + row * C + c0);
+// grid (ceil(CV/32), hw chunks, N); thread (cvl = tid & 31, rl = tid >> 5) owns 8 channels and
+// walks the rows rl, rl+8, ... of its chunk: the affine (scale, shift) is computed once.
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(
+    const bf16_t* __restrict__ x, int HW, int C, int hw_per_chunk, const float* __restrict__ mean,
+    const float* __restrict__ var, float eps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int per_sample, int relu, bf16_t* __restrict__ y) {
+  const int cv = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (cv * 8 >= C) return;
+  const int rl = threadIdx.x >> 5;
+  const int n = blockIdx.z;
+  const int c0 = cv * 8;
+  // the reference's operation order (x - mean) * rstd [* gamma] [+ beta] is kept: folding it into
+  // one multiply-add cancels catastrophically where x ~ mean (tiny batches, arch_ops.py:306-312)
+  float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float rstd = rsqrtf(var[c0 + e] + eps);
-        float t = (bf2f(v.h[e]) - mean[c0 + e]) * rstd;
-        if (gamma) t *= gamma[pidx + e];
-        if (beta) t += beta[pidx + e];
-        if (relu) t = fmaxf(t, 0.f);
-        o.h[e] = f2bf(t);
-      }
-      *reinterpret_cast<uint4*>(y + row * C + c0) = o.q;
-    } else {
-      const float rstd = rsqrtf(var[c0] + eps);
-      float t = (bf2f(x[row * C + c0]) - mean[c0]) * rstd;
-      if (gamma) t *= gamma[pidx];
-      if (beta) t += beta[pidx];
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[c0 + e];
+    rs[e] = rsqrtf(var[c0 + e] + eps);
+    const int64_t pidx = per_sample ? (int64_t)n * C + c0 + e : c0 + e;
+    gm[e] = gamma ? gamma[pidx] : 1.f;
+    bt[e] = beta ? beta[pidx] : 0.f;
+  }
+  const int h0 = blockIdx.y * hw_per_chunk, h1 = min(HW, h0 + hw_per_chunk);
+  const bf16_t* xp = x + (int64_t)n * HW * C + c0;
+  bf16_t* yp = y + (int64_t)n * HW * C + c0;
+  for (int p = h0 + rl; p < h1; p += 8) {
+    V8 v, o;
+    v.q = *reinterpret_cast<const uint4*>(xp + (int64_t)p * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (bf2f(v.h[e]) - mu[e]) * rs[e];
+      t = t * gm[e] + bt[e];
       if (relu) t = fmaxf(t, 0.f);
-      y[row * C + c0] = f2bf(t);
+      o.h[e] = f2bf(t);
     }
+    *reinterpret_cast<uint4*>(yp + (int64_t)p * C) = o.q;
+  }
+}
+// scalar fallback (C % 8 != 0)
+__global__ void bn_apply_scalar_kernel(const bf16_t* __restrict__ x, int HW, int C,
+                                       int64_t total, const float* __restrict__ mean,
+                                       const float* __restrict__ var, float eps,
+                                       const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, int per_sample, int relu,
+                                       bf16_t* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const int64_t n = i / ((int64_t)HW * C);
+    const int64_t pidx = per_sample ? n * C + c : c;
+    const float rstd = rsqrtf(var[c] + eps);
+    float t = (bf2f(x[i]) - mean[c]) * rstd;
+    if (gamma) t *= gamma[pidx];
+    if (beta) t += beta[pidx];
+    if (relu) t = fmaxf(t, 0.f);
+    y[i] = f2bf(t);
   }
 }
 
 // ---- backward --------------------------------------------------------------------------------
 // pass 1: S1[n,c] = sum_hw dz, S2[n,c] = sum_hw dz*xhat, dz = dy * (y>0 if relu).
-// grid (ceil(C/64), N, hsplits): 4 waves split hw; partial [hs][2][N][C].
+// vector form: grid (ceil(CV/32), hsplits, N); partial [hs][2][N][C].
+__global__ __launch_bounds__(256) void bn_bwd_sums_vec_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
+    int HW, int C, int hw_per_split, const float* __restrict__ mean,
+    const float* __restrict__ var, float eps, int relu, float* __restrict__ part) {
+  __shared__ float sm[8][32][17];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int cv = blockIdx.x * 32 + cg;
+  const int n = blockIdx.z, N = gridDim.z;
+  const int h0 = blockIdx.y * hw_per_split, h1 = min(HW, h0 + hw_per_split);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  if (cv * 8 < C) {
+    const int c0 = cv * 8;
+    float mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = mean[c0 + e];
+      rs[e] = rsqrtf(var[c0 + e] + eps);
+    }
+    const int64_t base = (int64_t)n * HW * C + c0;
+    for (int p = h0 + rl; p < h1; p += 8) {
+      const int64_t o = base + (int64_t)p * C;
+      V8 vx, vy, vg;
+      vx.q = *reinterpret_cast<const uint4*>(x + o);
+      vg.q = *reinterpret_cast<const uint4*>(dy + o);
+      if (relu) vy.q = *reinterpret_cast<const uint4*>(y + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g = bf2f(vg.h[e]);
+        if (relu && !(bf2f(vy.h[e]) > 0.f)) g = 0.f;
+        s1[e] += g;
+        s2[e] += g * (bf2f(vx.h[e]) - mu[e]) * rs[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sm[rl][cg][e] = s1[e];
+    sm[rl][cg][8 + e] = s2[e];
+  }
+  __syncthreads();
+  const int cg2 = threadIdx.x >> 3, e2 = threadIdx.x & 7;
+  const int cv2 = blockIdx.x * 32 + cg2;
+  if (cv2 * 8 < C) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      a += sm[r][cg2][e2];
+      b += sm[r][cg2][8 + e2];
+    }
+    float* p = part + (int64_t)blockIdx.y * 2 * N * C;
+    p[(int64_t)n * C + cv2 * 8 + e2] = a;
+    p[(int64_t)N * C + (int64_t)n * C + cv2 * 8 + e2] = b;
+  }
+}
+// scalar form (C % 8 != 0): grid (ceil(C/64), N, hsplits): 4 waves split hw.
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
     int HW, int C, int hw_per_split, const float* __restrict__ mean,
@@ -180,43 +281,100 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(
     p[(int64_t)N * C + (int64_t)n * C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
   }
 }
-// finalize: one thread per channel
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int hsplits, int N, int C,
-                                    float inv_rows, const float* __restrict__ gamma,
-                                    int per_sample, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, float* __restrict__ m12) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float t1 = 0.f, t2 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int n = 0; n < N; ++n) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int z = 0; z < hsplits; ++z) {
-      const float* p = part + (int64_t)z * 2 * N * C;
-      s1 += p[(int64_t)n * C + c];
-      s2 += p[(int64_t)N * C + (int64_t)n * C + c];
-    }
-    if (per_sample) {
-      const float g = gamma ? gamma[(int64_t)n * C + c] : 1.f;
-      if (dgamma) dgamma[(int64_t)n * C + c] = s2;
-      if (dbeta) dbeta[(int64_t)n * C + c] = s1;
-      a1 += g * s1;
-      a2 += g * s2;
-    } else {
-      t1 += s1;
-      t2 += s2;
+// finalize: block = 32 channels x 8 lanes.  per-sample: lanes split the samples (each sample's
+// dgamma/dbeta is complete after the hw-split sum); otherwise lanes split (n, z) jointly.
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(
+    const float* __restrict__ part, int hsplits, int N, int C, float inv_rows,
+    const float* __restrict__ gamma, int per_sample, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ m12) {
+  __shared__ float sm[2][8][33];
+  const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C) {
+    for (int n = zl; n < N; n += 8) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int z = 0; z < hsplits; ++z) {
+        const float* p = part + (int64_t)z * 2 * N * C;
+        s1 += p[(int64_t)n * C + c];
+        s2 += p[(int64_t)N * C + (int64_t)n * C + c];
+      }
+      if (per_sample) {
+        const float g = gamma ? gamma[(int64_t)n * C + c] : 1.f;
+        if (dgamma) dgamma[(int64_t)n * C + c] = s2;
+        if (dbeta) dbeta[(int64_t)n * C + c] = s1;
+        a1 += g * s1;
+        a2 += g * s2;
+      } else {
+        a1 += s1;
+        a2 += s2;
+      }
     }
   }
-  if (!per_sample) {
-    const float g = gamma ? gamma[c] : 1.f;
-    if (dgamma) dgamma[c] = t2;
-    if (dbeta) dbeta[c] = t1;
-    a1 = g * t1;
-    a2 = g * t2;
+  sm[0][zl][cl] = a1;
+  sm[1][zl][cl] = a2;
+  __syncthreads();
+  if (zl == 0 && c < C) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      t1 += sm[0][r][cl];
+      t2 += sm[1][r][cl];
+    }
+    if (!per_sample) {
+      const float g = gamma ? gamma[c] : 1.f;
+      if (dgamma) dgamma[c] = t2;
+      if (dbeta) dbeta[c] = t1;
+      t1 *= g;
+      t2 *= g;
+    }
+    m12[c] = t1 * inv_rows;
+    m12[C + c] = t2 * inv_rows;
   }
-  m12[c] = a1 * inv_rows;
-  m12[C + c] = a2 * inv_rows;
 }
-// pass 2
+// pass 2, vector form: grid (ceil(CV/32), hw chunks, N)
+__global__ __launch_bounds__(256) void bn_bwd_dx_vec_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
+    int HW, int C, int hw_per_chunk, const float* __restrict__ mean,
+    const float* __restrict__ var, float eps, const float* __restrict__ gamma, int per_sample,
+    int relu, int batch_stats, const float* __restrict__ m12, bf16_t* __restrict__ dx) {
+  const int cv = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (cv * 8 >= C) return;
+  const int rl = threadIdx.x >> 5;
+  const int n = blockIdx.z;
+  const int c0 = cv * 8;
+  float mu[8], rs[8], gm[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[c0 + e];
+    rs[e] = rsqrtf(var[c0 + e] + eps);
+    gm[e] = gamma ? gamma[per_sample ? (int64_t)n * C + c0 + e : c0 + e] : 1.f;
+    k1[e] = batch_stats ? m12[c0 + e] : 0.f;
+    k2[e] = batch_stats ? m12[C + c0 + e] : 0.f;
+  }
+  const int h0 = blockIdx.y * hw_per_chunk, h1 = min(HW, h0 + hw_per_chunk);
+  const int64_t base = (int64_t)n * HW * C + c0;
+  for (int p = h0 + rl; p < h1; p += 8) {
+    const int64_t o = base + (int64_t)p * C;
+    V8 vx, vy, vg, vo;
+    vg.q = *reinterpret_cast<const uint4*>(dy + o);
+    if (batch_stats) vx.q = *reinterpret_cast<const uint4*>(x + o);
+    if (relu) vy.q = *reinterpret_cast<const uint4*>(y + o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g = bf2f(vg.h[e]);
+      if (relu && !(bf2f(vy.h[e]) > 0.f)) g = 0.f;
+      float d = gm[e] * g;
+      if (batch_stats) {
+        const float xhat = (bf2f(vx.h[e]) - mu[e]) * rs[e];
+        d = d - k1[e] - xhat * k2[e];
+      }
+      vo.h[e] = f2bf(d * rs[e]);
+    }
+    *reinterpret_cast<uint4*>(dx + o) = vo.q;
+  }
+}
+// pass 2, scalar form
 __global__ void bn_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                  const bf16_t* __restrict__ dy, int HW, int C, int64_t total,
                                  const float* __restrict__ mean, const float* __restrict__ var,
@@ -265,12 +423,21 @@ __global__ void bn_moments_convert_kernel(float* __restrict__ mean, float* __res
 }
 
 inline int bwd_hsplits(int N, int HW, int C) {
-  const int blocks = cdiv(C, 64) * N;
+  const int blocks = ((C % 8 == 0) ? cdiv(C / 8, 32) : cdiv(C, 64)) * N;
   int s = cdiv(1024, blocks);
   const int maxs = HW / 16 > 0 ? HW / 16 : 1;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
   return s;
+}
+// hw chunks so that (channel blocks) x chunks x N ~ 2048 blocks, >= 32 rows per chunk
+inline int hw_chunks(int N, int HW, int C) {
+  const int64_t blocks = (int64_t)cdiv(C / 8, 32) * N;
+  int64_t ch = (2048 + blocks - 1) / blocks;
+  const int maxc = HW / 32 > 0 ? HW / 32 : 1;
+  if (ch > maxc) ch = maxc;
+  if (ch < 1) ch = 1;
+  return (int)ch;
 }
 inline int grid_cap(int64_t work) {
   int64_t b = (work + 255) / 256;
@@ -286,9 +453,10 @@ extern "C" size_t cg_bn_stats_workspace_bytes(int64_t rows, int C) {
   return align_up((size_t)stats_splits(rows, C) * 2 * C * sizeof(float), 256);
 }
 
-extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var, void* ws,
+extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var,
+                           float* moving_mean, float* moving_var, float decay, void* ws,
                            size_t ws_bytes, cgStream stream) {
-  if (!x || !mean || !var || rows <= 0 || C <= 0)
+  if (!x || !mean || !var || rows <= 0 || C <= 0 || ((moving_mean == nullptr) != (moving_var == nullptr)))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_stats: bad argument");
   if (!ws || ws_bytes < cg_bn_stats_workspace_bytes(rows, C))
     CG_FAIL(CG_ERR_WORKSPACE, "cg_bn_stats: workspace too small");
@@ -303,8 +471,9 @@ extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, floa
     bn_stats_part_scalar_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, C, rps, (float*)ws);
   }
   CG_CHECK_LAUNCH("cg_bn_stats(part)");
-  bn_stats_final_kernel<<<cdiv(C, 256), 256, 0, st>>>((const float*)ws, splits, C,
-                                                      1.0f / (float)rows, mean, var);
+  bn_stats_final_kernel<<<cdiv(C, 32), 256, 0, st>>>((const float*)ws, splits, C,
+                                                     1.0f / (float)rows, mean, var, moving_mean,
+                                                     moving_var, decay);
   CG_CHECK_LAUNCH("cg_bn_stats(final)");
   return CG_OK;
 }
@@ -316,13 +485,13 @@ extern "C" int cg_bn_apply(const void* x, int N, int HW, int C, const float* mea
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_apply: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (C % 8 == 0) {
-    const int64_t units = (int64_t)N * HW * (C / 8);
-    bn_apply_kernel<true><<<grid_cap(units), 256, 0, st>>>((const bf16_t*)x, HW, C, units, mean,
-                                                           var, eps, gamma, beta, per_sample,
-                                                           relu, (bf16_t*)y);
+    const int ch = hw_chunks(N, HW, C);
+    dim3 grid(cdiv(C / 8, 32), ch, N);
+    bn_apply_vec_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, HW, C, cdiv(HW, ch), mean, var,
+                                              eps, gamma, beta, per_sample, relu, (bf16_t*)y);
   } else {
     const int64_t units = (int64_t)N * HW * C;
-    bn_apply_kernel<false><<<grid_cap(units), 256, 0, st>>>((const bf16_t*)x, HW, C, units, mean,
+    bn_apply_scalar_kernel<<<grid_cap(units), 256, 0, st>>>((const bf16_t*)x, HW, C, units, mean,
                                                             var, eps, gamma, beta, per_sample,
                                                             relu, (bf16_t*)y);
   }
@@ -349,11 +518,19 @@ extern "C" int cg_bn_backward_reduce(const void* x, const void* y, const void* d
   const int hs = bwd_hsplits(N, HW, C);
   const int hps = (HW + hs - 1) / hs;
   float* part = (float*)ws;
-  dim3 grid(cdiv(C, 64), N, hs);
-  bn_bwd_sums_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
-                                           HW, C, hps, mean, var, eps, relu, part);
+  if (C % 8 == 0) {
+    dim3 grid(cdiv(C / 8, 32), hs, N);
+    bn_bwd_sums_vec_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y,
+                                                 (const bf16_t*)dy, HW, C, hps, mean, var, eps,
+                                                 relu, part);
+  } else {
+    dim3 grid(cdiv(C, 64), N, hs);
+    bn_bwd_sums_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y,
+                                             (const bf16_t*)dy, HW, C, hps, mean, var, eps, relu,
+                                             part);
+  }
   CG_CHECK_LAUNCH("cg_bn_backward_reduce(sums)");
-  bn_bwd_final_kernel<<<cdiv(C, 256), 256, 0, st>>>(part, hs, N, C,
+  bn_bwd_final_kernel<<<cdiv(C, 32), 256, 0, st>>>(part, hs, N, C,
                                                     1.0f / ((float)N * (float)HW), gamma,
                                                     per_sample, dgamma, dbeta, m12);
   CG_CHECK_LAUNCH("cg_bn_backward_reduce(final)");
@@ -367,10 +544,20 @@ extern "C" int cg_bn_backward_apply(const void* x, const void* y, const void* dy
   if (!x || !dy || !dx || !mean || !var || N <= 0 || HW <= 0 || C <= 0 || (relu && !y) ||
       (batch_stats && !m12))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_backward_apply: bad argument");
-  const int64_t total = (int64_t)N * HW * C;
-  bn_bwd_dx_kernel<<<grid_cap(total), 256, 0, (hipStream_t)stream>>>(
-      (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, HW, C, total, mean, var, eps, gamma,
-      per_sample, relu, batch_stats, m12, (bf16_t*)dx);
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 8 == 0) {
+    const int ch = hw_chunks(N, HW, C);
+    dim3 grid(cdiv(C / 8, 32), ch, N);
+    bn_bwd_dx_vec_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y,
+                                               (const bf16_t*)dy, HW, C, cdiv(HW, ch), mean, var,
+                                               eps, gamma, per_sample, relu, batch_stats, m12,
+                                               (bf16_t*)dx);
+  } else {
+    const int64_t total = (int64_t)N * HW * C;
+    bn_bwd_dx_kernel<<<grid_cap(total), 256, 0, st>>>(
+        (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, HW, C, total, mean, var, eps,
+        gamma, per_sample, relu, batch_stats, m12, (bf16_t*)dx);
+  }
   CG_CHECK_LAUNCH("cg_bn_backward_apply");
   return CG_OK;
 }

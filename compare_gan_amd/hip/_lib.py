@@ -48,7 +48,7 @@ SIGNATURES = {
     "cg_sn_backward": (c_int, [vp, vp, c_int, c_int, vp, vp, vp, vp, vp, c_sz, vp]),
     "cg_scale_f32": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
     "cg_bn_stats_workspace_bytes": (c_sz, [c_i64, c_int]),
-    "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, c_sz, vp]),
+    "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, vp, c_f32, vp, c_sz, vp]),
     "cg_bn_apply": (c_int, [vp, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, c_int, c_int, vp, vp]),
     "cg_bn_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "cg_bn_backward_reduce": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_f32, vp, c_int,

@@ -215,15 +215,21 @@ class BatchNormActFn(torch.autograd.Function):
   bookkeeping); eval: the given moments are used as constants."""
 
   @staticmethod
-  def forward(ctx, x, gamma, beta, mean_in, var_in, eps, per_sample, relu, sync_fn):
+  def forward(ctx, x, gamma, beta, mean_in, var_in, eps, per_sample, relu, sync_fn, moving):
     shape = x.shape
     N, C = shape[0], shape[-1]
     x3 = x.contiguous().reshape(N, -1, C)
     batch_stats = mean_in is None
     if batch_stats:
-      mean, var = K.bn_stats(x3)
-      if sync_fn is not None:
-        mean, var = sync_fn.forward_sync(mean, var)
+      if sync_fn is None and moving is not None:
+        # moving averages updated by the statistics kernel itself (arch_ops.py:105-114)
+        mean, var = K.bn_stats(x3, moving[0], moving[1], moving[2])
+      else:
+        mean, var = K.bn_stats(x3)
+        if sync_fn is not None:
+          mean, var = sync_fn.forward_sync(mean, var)
+        if moving is not None:
+          K.bn_update_moving(moving[0], moving[1], mean, var, moving[2])
     else:
       mean, var = mean_in, var_in
     y3 = K.bn_apply(x3, mean, var, eps, gamma, beta, per_sample, relu)
@@ -242,12 +248,13 @@ class BatchNormActFn(torch.autograd.Function):
         x3, y3, dy3, mean, var, eps, gamma, per_sample, relu, batch_stats,
         want_dgamma=ctx.needs_input_grad[1], want_dbeta=ctx.needs_input_grad[2],
         sync_fn=sync_fn.backward_sync if sync_fn is not None else None)
-    return dx.reshape(shape), dgamma, dbeta, None, None, None, None, None, None
+    return dx.reshape(shape), dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, mean=None, var=None, eps=1e-5, per_sample=False, relu=False,
-                   sync_fn=None):
-  return BatchNormActFn.apply(x, gamma, beta, mean, var, eps, per_sample, relu, sync_fn)
+                   sync_fn=None, moving=None):
+  """moving = (moving_mean, moving_var, decay): updated in place from this batch's moments."""
+  return BatchNormActFn.apply(x, gamma, beta, mean, var, eps, per_sample, relu, sync_fn, moving)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -177,15 +177,17 @@ def scale_f32(x, scale_dev=None, scale_host=1.0):
 # ------------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------------
-def bn_stats(x3):
-    """x3 [N, HW, C] bf16 -> mean, var fp32 [C]."""
+def bn_stats(x3, moving_mean=None, moving_var=None, decay=0.0):
+    """x3 [N, HW, C] bf16 -> mean, var fp32 [C]; optionally updates the moving averages."""
     _req(x3, BF16, "x")
+    _req(moving_mean, F32, "moving_mean", True)
+    _req(moving_var, F32, "moving_var", True)
     N, HW, C = x3.shape
     mean = torch.empty((C,), dtype=F32, device=x3.device)
     var = torch.empty((C,), dtype=F32, device=x3.device)
     ws = _ws(lib().cg_bn_stats_workspace_bytes(N * HW, C), x3)
-    check(lib().cg_bn_stats(_p(x3), N * HW, C, _p(mean), _p(var), _p(ws), ws.numel(), _stream()),
-          "cg_bn_stats")
+    check(lib().cg_bn_stats(_p(x3), N * HW, C, _p(mean), _p(var), _p(moving_mean), _p(moving_var),
+                            float(decay), _p(ws), ws.numel(), _stream()), "cg_bn_stats")
     return mean, var
 
 

@@ -141,10 +141,12 @@ int cg_scale_f32(const float* x, const float* scale_dev, float scale_host, float
  * :423-445 conditional_batch_norm).  x is [N, HW, C] bf16 (2-D inputs use HW=1).
  * ------------------------------------------------------------------------------------------ */
 /* mean[c] = sum x / n ; var[c] = sum x^2 / n - mean^2 (fp32, arch_ops.py:294-297).
+ * moving_mean / moving_var (both or neither, may be NULL): the moving-average update
+ * m <- m - (1-decay)(m - batch) of arch_ops.py:105-114 folded into the same launch.
  * ws >= cg_bn_stats_workspace_bytes(N*HW, C). */
 size_t cg_bn_stats_workspace_bytes(int64_t rows, int C);
-int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var, void* ws,
-                size_t ws_bytes, cgStream stream);
+int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var, float* moving_mean,
+                float* moving_var, float decay, void* ws, size_t ws_bytes, cgStream stream);
 /* y = act( (x - mean) * rsqrt(var + eps) * gamma + beta ), act = relu if relu != 0.
  * gamma/beta: fp32 [C] (per_sample == 0) or [N,C] (per_sample != 0, conditional BN), NULL = 1 / 0.
  * y bf16 same shape as x. */
