@@ -72,16 +72,19 @@ struct FastConvArgs {
   FastDiv dWp, dHp, dNt;
 };
 
-template <int BM, bool RELU>
+template <int BM, int BN, bool RELU>
 __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
-  constexpr int BN = 128;
-  constexpr int AJ = BM / 32;  // A staging instructions per wave (8 rows of 128 B each)
-  constexpr int TM = BM / 64;  // 32-pixel MFMA tiles per wave
+  constexpr int WN = BN >= 128 ? 2 : 1;   // waves along the channel dimension
+  constexpr int WM = 4 / WN;
+  constexpr int AJ = BM / 32;             // A staging instructions per wave (8 rows of 128 B each)
+  constexpr int BJ = BN / 32;             // B staging instructions per wave
+  constexpr int TM = BM / WM / 32;        // 32-pixel MFMA tiles per wave
+  constexpr int TN = BN / WN / 32;        // 32-channel MFMA tiles per wave
   constexpr int A_ELEMS = BM * 64, B_ELEMS = BN * 64;
   __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (A_ELEMS + B_ELEMS)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = (int)fdiv((uint32_t)wg, a.dNt);
   const int nt = wg - mt * a.ntiles;
@@ -123,11 +126,11 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     a_iw[j] = (a.U == 2) ? owp + bw : owp * a.S + bw;
     a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.Ci + c * 8;
   }
-  int b_off[4];
-  bool b_ok[4];
+  int b_off[BJ];
+  bool b_ok[BJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int g = wave * 4 + j;
+  for (int j = 0; j < BJ; ++j) {
+    const int g = wave * BJ + j;
     const int row = g * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     b_ok[j] = (n0 + row) < a.Co;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     const int tapoff = (st_ri * a.Win + st_si) * a.Ci + st_cb * 64;
     const int koff = ((r0 + a.U * st_ri) * a.kw + (s0 + a.U * st_si)) * a.Ci + st_cb * 64;
     bf16_t* Ab = Abuf(buf) + (wave * AJ) * 512;
-    bf16_t* Bb = Bbuf(buf) + (wave * 4) * 512;
+    bf16_t* Bb = Bbuf(buf) + (wave * BJ) * 512;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const bool ok = a_ok[j] && (unsigned)(a_ih[j] + st_ri) < (unsigned)a.Hin &&
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
       glds16(p, Ab + j * 512);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < BJ; ++j) {
       const bf16_t* p = b_ok[j] ? a.bt + (int64_t)(b_off[j] + koff) : zero;
       glds16(p, Bb + j * 512);
     }
@@ -166,11 +169,11 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     }
   };
 
-  f32x16_t acc[TM][2];
+  f32x16_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   int koffs[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) koffs[kk] = (((kk * 2 + (lane >> 5)) ^ swz) << 3);
-  const int arow0 = (wm * (BM / 2) + frow) * 64;
-  const int brow0 = (wn * 64 + frow) * 64;
+  const int arow0 = (wm * (BM / WM) + frow) * 64;
+  const int brow0 = (wn * (BN / WN) + frow) * 64;
 
   if (nk > 0) {
     stage(0);
@@ -196,19 +199,19 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     const bf16_t* Bb = Bbuf(buf);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t af[TM], bfr[2];
+      bf16x8_t af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
         if (RELU) af[i] = relu_bf16x8(af[i]);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN; ++j)
         bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -217,9 +220,10 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
 
   // ---- epilogue: lane owns pixel (lane & 31) of each M sub-tile and, per 8-channel group q, the
   // 4 consecutive channels 8*q + 4*(lane >> 5) + {0..3}
+  const bool vec4 = (a.Co & 3) == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 32 + frow;
+    const int m = m0 + wm * (BM / WM) + i * 32 + frow;
     if (m >= a.Mp) continue;
     const uint32_t t1 = fdiv((uint32_t)m, a.dWp);
     const int owp = m - (int)t1 * a.Wp;
@@ -228,40 +232,55 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     const int64_t opix =
         ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int co = n0 + wn * 64 + j * 32 + q * 8 + 4 * (lane >> 5);
+        const int co = n0 + wn * (BN / WN) + j * 32 + q * 8 + 4 * (lane >> 5);
         if (co >= a.Co) continue;
-        float v0 = acc[i][j][q * 4 + 0], v1 = acc[i][j][q * 4 + 1], v2 = acc[i][j][q * 4 + 2],
-              v3 = acc[i][j][q * 4 + 3];
-        if (a.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
-          v0 += b4.x; v1 += b4.y; v2 += b4.z; v3 += b4.w;
-        }
+        float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
+                      acc[i][j][q * 4 + 3]};
         const int64_t o = opix + co;
-        if (a.gate_out) {
-          const uint2 g2 = *reinterpret_cast<const uint2*>(a.gate_out + o);
-          if (!(bf2f((bf16_t)(g2.x & 0xffff)) > 0.f)) v0 *= a.slope_out;
-          if (!(bf2f((bf16_t)(g2.x >> 16)) > 0.f)) v1 *= a.slope_out;
-          if (!(bf2f((bf16_t)(g2.y & 0xffff)) > 0.f)) v2 *= a.slope_out;
-          if (!(bf2f((bf16_t)(g2.y >> 16)) > 0.f)) v3 *= a.slope_out;
-        }
-        if (a.residual) {
-          const uint2 r2 = *reinterpret_cast<const uint2*>(a.residual + o);
-          v0 += bf2f((bf16_t)(r2.x & 0xffff));
-          v1 += bf2f((bf16_t)(r2.x >> 16));
-          v2 += bf2f((bf16_t)(r2.y & 0xffff));
-          v3 += bf2f((bf16_t)(r2.y >> 16));
-        }
-        if (a.out_f32) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) =
-              make_float4(v0, v1, v2, v3);
+        if (vec4) {
+          if (a.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          }
+          if (a.gate_out) {
+            const uint2 g2 = *reinterpret_cast<const uint2*>(a.gate_out + o);
+            if (!(bf2f((bf16_t)(g2.x & 0xffff)) > 0.f)) v[0] *= a.slope_out;
+            if (!(bf2f((bf16_t)(g2.x >> 16)) > 0.f)) v[1] *= a.slope_out;
+            if (!(bf2f((bf16_t)(g2.y & 0xffff)) > 0.f)) v[2] *= a.slope_out;
+            if (!(bf2f((bf16_t)(g2.y >> 16)) > 0.f)) v[3] *= a.slope_out;
+          }
+          if (a.residual) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(a.residual + o);
+            v[0] += bf2f((bf16_t)(r2.x & 0xffff));
+            v[1] += bf2f((bf16_t)(r2.x >> 16));
+            v[2] += bf2f((bf16_t)(r2.y & 0xffff));
+            v[3] += bf2f((bf16_t)(r2.y >> 16));
+          }
+          if (a.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 w2;
+            w2.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            w2.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o) = w2;
+          }
         } else {
-          uint2 w2;
-          w2.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-          w2.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o) = w2;
+          // channel counts that are not a multiple of 4 (RGB outputs): element-wise tail
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (co + e >= a.Co) continue;
+            float val = v[e] + (a.bias ? a.bias[co + e] : 0.f);
+            if (a.gate_out && !(bf2f(a.gate_out[o + e]) > 0.f)) val *= a.slope_out;
+            if (a.residual) val += bf2f(a.residual[o + e]);
+            if (a.out_f32)
+              reinterpret_cast<float*>(a.out)[o + e] = val;
+            else
+              reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val);
+          }
         }
       }
     }
@@ -286,13 +305,18 @@ struct FastWgradArgs {
   FastDiv dWp, dHp, dCb, dNt;
 };
 
-// tile: 128 (k: one tap x 128 channels) x 128 (co), reduction over pixels in slices of 64 rows.
-// LDS rows are 256 B (128 channels); chunk c (16 B) of row r is stored at slot c ^ ((r & 3) << 1),
-// which spreads the 4 rows of every transpose-read block over 4 distinct 32-byte bank windows.
-template <bool RELU>
+// tile: TKC (k: one tap x TKC channels, TKC = 128 or 64) x 128 (co), reduction over pixels in
+// slices of 64 rows.  LDS rows are TKC*2 bytes (x) / 256 B (dy); chunk c (16 B) of row r is stored at
+// slot c ^ ((r & 3) << 1), which spreads the 4 rows of every transpose-read block over 4 distinct
+// 32-byte bank windows.
+template <int TKC, bool RELU>
 __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
   constexpr int MR = 64;
-  constexpr int X_ELEMS = MR * 128, Y_ELEMS = MR * 128;
+  constexpr int X_ELEMS = MR * TKC, Y_ELEMS = MR * 128;
+  constexpr int RX = 512 / TKC;        // x rows per 1 KiB staging instruction (4 or 8)
+  constexpr int XJ = MR / RX / 4;      // x staging instructions per wave (4 or 2)
+  constexpr int LPR = 64 / RX;         // lanes (16-byte chunks) per x row (16 or 8)
+  constexpr int FK = TKC / 64;         // 32-wide k tiles per wave (2 or 1)
   __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (X_ELEMS + Y_ELEMS)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,22 +343,25 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
   const int mend = min(a.Mp, mbeg + a.rows_per_split);
   const int nit = (mend - mbeg + MR - 1) / MR;
 
-  // staging: instruction group g = wave*4 + j covers rows g*4 .. g*4+3 (256 B each);
-  // lane -> row g*4 + (lane >> 4), LDS slot lane & 15 <- source chunk (lane & 15) ^ ((row & 3) << 1)
-  const int srow = lane >> 4;                       // row & 3
-  const int schunk = (lane & 15) ^ (srow << 1);
-  const bool y_ok = (c0 + schunk * 8) < a.Co;       // Co % 8 == 0
+  // staging.  dy: instruction group g = wave*4 + j covers rows g*4 .. g*4+3 (256 B each), lane ->
+  // row g*4 + (lane >> 4), slot lane & 15 <- source chunk (lane & 15) ^ ((row & 3) << 1).
+  // x: rows of TKC*2 bytes, RX rows per instruction, same swizzle rule.
+  const int yrow = lane >> 4;
+  const int ychunk = (lane & 15) ^ (yrow << 1);
+  const bool y_ok = (c0 + ychunk * 8) < a.Co;  // Co % 8 == 0
+  const int xrow = lane / LPR;
+  const int xchunk = (lane % LPR) ^ ((xrow & 3) << 1);
   auto Xbuf = [&](int buf) { return smem + buf * (X_ELEMS + Y_ELEMS); };
   auto Ybuf = [&](int buf) { return smem + buf * (X_ELEMS + Y_ELEMS) + X_ELEMS; };
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
 
   auto stage = [&](int buf, int it) {
     const int mb = mbeg + it * MR;
-    bf16_t* Xb = Xbuf(buf) + (wave * 4) * 512;
+    bf16_t* Xb = Xbuf(buf) + (wave * XJ) * 512;
     bf16_t* Yb = Ybuf(buf) + (wave * 4) * 512;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mb + (wave * 4 + j) * 4 + srow;
+    for (int j = 0; j < XJ; ++j) {
+      const int m = mb + (wave * XJ + j) * RX + xrow;
       const bool mok = m < mend;
       const uint32_t mm = mok ? (uint32_t)m : 0u;
       const uint32_t t1 = fdiv(mm, a.dWp);
@@ -345,18 +372,28 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
       const int iw = (a.U == 2) ? owp + bw : owp * a.S + bw;
       const bool xok = mok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const int64_t xoff =
-          ((int64_t)((int)n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * 128 + schunk * 8;
+          ((int64_t)((int)n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * TKC + xchunk * 8;
       glds16(xok ? a.in + xoff : zero, Xb + j * 512);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + (wave * 4 + j) * 4 + yrow;
+      const bool mok = m < mend;
+      const uint32_t mm = mok ? (uint32_t)m : 0u;
+      const uint32_t t1 = fdiv(mm, a.dWp);
+      const int owp = (int)(mm - t1 * a.Wp);
+      const uint32_t n = fdiv(t1, a.dHp);
+      const int ohp = (int)(t1 - n * a.Hp);
       const int64_t yoff =
           ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + c0 +
-          schunk * 8;
+          ychunk * 8;
       glds16((mok && y_ok) ? a.dy + yoff : zero, Yb + j * 512);
     }
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[FK][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FK; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -371,10 +408,10 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
   const int trow = l16 >> 2;                                 // row within the 4-row block
   const int tcol = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;   // element column within a 32-col tile
   const int mrow0 = (lane >> 5) * 8 + trow;                  // + mm*16 (+4 for the second read)
-  auto tr_addr = [&](const bf16_t* base, int row, int col) {
-    // row-major [64][128] image with the 16-byte chunk swizzle
+  auto tr_addr = [&](const bf16_t* base, int ld, int row, int col) {
+    // row-major [64][ld] image with the 16-byte chunk swizzle
     const int chunk = (col >> 3) ^ ((row & 3) << 1);
-    return base + row * 128 + chunk * 8 + (col & 7);
+    return base + row * ld + chunk * 8 + (col & 7);
   };
 
   if (nit > 0) {
@@ -390,15 +427,15 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
     const bf16_t* Yb = Ybuf(buf);
 #pragma unroll
     for (int mm = 0; mm < MR / 16; ++mm) {
-      bf16x8_t xf[2], yf[2];
+      bf16x8_t xf[FK], yf[2];
       const int row = mm * 16 + mrow0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int col = wk * 64 + i * 32 + tcol;
+      for (int i = 0; i < FK; ++i) {
+        const int col = wk * (TKC / 2) + i * 32 + tcol;
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Xb, row, col));
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Xb, TKC, row, col));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Xb, row + 4, col));
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Xb, TKC, row + 4, col));
         s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         xf[i] = __builtin_bit_cast(bf16x8_t, v);
         if (RELU) xf[i] = relu_bf16x8(xf[i]);
@@ -407,14 +444,14 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
       for (int j = 0; j < 2; ++j) {
         const int col = wn * 64 + j * 32 + tcol;
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Yb, row, col));
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Yb, 128, row, col));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Yb, row + 4, col));
+            (__attribute__((address_space(3))) s16x4_t*)tr_addr(Yb, 128, row + 4, col));
         s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         yf[j] = __builtin_bit_cast(bf16x8_t, v);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < FK; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
@@ -433,16 +470,16 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
 
   const bool direct = (gridDim.y == 1);
   float* outp = a.out + (direct ? 0 : (int64_t)blockIdx.y * a.K * a.Co);
-  const int kbase = tap * a.Ci + cb * 128;
+  const int kbase = tap * a.Ci + cb * TKC;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < FK; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int co = c0 + wn * 64 + j * 32 + (lane & 31);
       if (co >= a.Co) continue;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int k = kbase + wk * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        const int k = kbase + wk * (TKC / 2) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
         const int64_t o = (int64_t)k * a.Co + co;
         if (direct && a.accumulate)
           outp[o] += acc[i][j][v];
@@ -458,6 +495,298 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
     else
       bp[c0 + tid] = bias_acc;
   }
+}
+
+// -------------------------------------------------------------------------------------------
+// "stem" convolutions: image-like inputs (Ci <= 4, K = kh*kw*Ci <= 128).  Almost no FLOPs, HBM-bound
+// on the activation they write (forward) / read (weight gradient).  The im2col tile is built in LDS
+// by a scalar gather of the tiny, cache-resident input; the contraction still runs on MFMA.
+// -------------------------------------------------------------------------------------------
+struct StemArgs {
+  const bf16_t* in;
+  const bf16_t* bt;   // forward: [Co][Kp] bf16
+  const bf16_t* dy;   // weight gradient: [M][Co] bf16
+  void* out;          // forward: [M][Co] bf16/f32;  weight gradient: partials [splits][K*Co + Co]
+  const float* bias;
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, pt, pl;
+  int M, K, Kp, KS;   // KS = K rounded up to 32
+  int relu_in, out_f32, want_bias;
+  int rows_per_split;
+  int adjoint_out;   // weight gradient computed on the adjoint geometry: store as [kh,kw,Co,Ci]
+                     // with flipped taps, i.e. directly in the forward conv's HWIO layout
+  FastDiv dWo, dHo, dCi, dKw;
+};
+
+// per-k decode table (built once per block): r | s << 8 | valid << 16, element offset of the tap
+struct StemTap {
+  int rs;
+  int off;
+};
+__device__ __forceinline__ void stem_build_taps(const StemArgs& a, StemTap* taps, int KS) {
+  for (int k = threadIdx.x; k < KS; k += blockDim.x) {
+    StemTap t;
+    t.rs = 0;
+    t.off = 0;
+    if (k < a.K) {
+      const uint32_t tap = fdiv((uint32_t)k, a.dCi);
+      const int ci = k - (int)tap * a.Ci;
+      const int r = (int)fdiv(tap, a.dKw);
+      const int s = (int)tap - r * a.kw;
+      t.rs = r | (s << 8) | (1 << 16);
+      t.off = (r * a.Win + s) * a.Ci + ci;
+    }
+    taps[k] = t;
+  }
+}
+// gathers element k of the im2col row whose tap (0,0) pixel is (ihb, iwb) at element offset base;
+// zero outside the image / beyond K
+__device__ __forceinline__ bf16_t stem_gather(const StemArgs& a, const StemTap* taps,
+                                              int64_t base, int ihb, int iwb, int k, bool row_ok) {
+  const StemTap t = taps[k];
+  const int ih = ihb + (t.rs & 0xff), iw = iwb + ((t.rs >> 8) & 0xff);
+  if (!row_ok || !(t.rs >> 16) || (unsigned)ih >= (unsigned)a.Hin ||
+      (unsigned)iw >= (unsigned)a.Win)
+    return 0;
+  bf16_t v = a.in[base + t.off];
+  if (a.relu_in && (v & 0x8000)) v = 0;
+  return v;
+}
+
+// forward: block = 128 pixels x all output channels.  LDS: A [128][KS], W [Co<=128][KS].
+template <int KS>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
+  constexpr int LDA = KS + 8;  // +16 B row padding: conflict-free ds_read_b128 fragments
+  __shared__ __attribute__((aligned(16))) bf16_t As[128 * LDA];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[128 * LDA];
+  __shared__ StemTap taps[KS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 128;
+  stem_build_taps(a, taps, KS);
+  __syncthreads();
+  // weights -> LDS (zero rows / columns beyond Co / K)
+  for (int i = tid; i < 128 * (KS / 8); i += 256) {
+    const int row = i / (KS / 8), ch = i % (KS / 8);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < a.Co && ch * 8 < a.Kp) v = *reinterpret_cast<const uint4*>(a.bt + (int64_t)row * a.Kp + ch * 8);
+    *reinterpret_cast<uint4*>(Ws + row * LDA + ch * 8) = v;
+  }
+  // im2col tile: thread -> pixel (tid & 127), k half (tid >> 7)
+  {
+    const int p = tid & 127, half = tid >> 7;
+    const int m = m0 + p;
+    const bool ok = m < a.M;
+    const uint32_t mm = ok ? (uint32_t)m : 0u;
+    const uint32_t t1 = fdiv(mm, a.dWo);
+    const int ow = (int)(mm - t1 * a.Wo);
+    const uint32_t n = fdiv(t1, a.dHo);
+    const int oh = (int)(t1 - n * a.Ho);
+    const int ihb = oh * a.S - a.pt, iwb = ow * a.S - a.pl;
+    const int64_t base = ((int64_t)((int)n * a.Hin + ihb) * a.Win + iwb) * a.Ci;
+#pragma unroll 8
+    for (int kk = 0; kk < KS / 2; kk += 2) {
+      const int k = half * (KS / 2) + kk;
+      const uint32_t lo = stem_gather(a, taps, base, ihb, iwb, k, ok);
+      const uint32_t hi = stem_gather(a, taps, base, ihb, iwb, k + 1, ok);
+      *reinterpret_cast<uint32_t*>(As + p * LDA + k) = lo | (hi << 16);
+    }
+  }
+  __syncthreads();
+  const int frow = lane & 31;
+  const int m = m0 + wave * 32 + frow;
+  const int64_t opix = (int64_t)m * a.Co;
+  const int nct = (a.Co + 31) / 32;
+  for (int ct = 0; ct < nct; ++ct) {
+    f32x16_t acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS / 16; ++kk) {
+      const int ko = kk * 16 + (lane >> 5) * 8;
+      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + (wave * 32 + frow) * LDA + ko);
+      const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(Ws + (ct * 32 + frow) * LDA + ko);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc, 0, 0, 0);
+    }
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = ct * 32 + q * 8 + 4 * (lane >> 5);
+      if (co >= a.Co) continue;
+      if ((a.Co & 3) == 0) {
+        float v[4] = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+        if (a.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (a.out_f32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + opix + co) =
+              make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 w2;
+          w2.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          w2.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + opix + co) = w2;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (co + e >= a.Co) continue;
+        const float val = acc[q * 4 + e] + (a.bias ? a.bias[co + e] : 0.f);
+        if (a.out_f32)
+          reinterpret_cast<float*>(a.out)[opix + co + e] = val;
+        else
+          reinterpret_cast<bf16_t*>(a.out)[opix + co + e] = f2bf(val);
+      }
+    }
+  }
+}
+
+// weight gradient: grid (co tiles of 128, splits).  Per 64-pixel slice: im2col tile [64][KS] by
+// gather, dy tile [64][128] by LDS-DMA (same image and swizzle as fast_wgrad_kernel), operands by
+// transpose reads.  Waves split the 128 channels; every wave owns all KS/32 k tiles.
+template <int KS>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
+  constexpr int MR = 64;
+  constexpr int KT = KS / 32;
+  __shared__ __attribute__((aligned(1024))) bf16_t Ys[2 * MR * 128];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[2 * MR * KS];
+  __shared__ StemTap taps[KS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 128;
+  stem_build_taps(a, taps, KS);
+  __syncthreads();
+  const int mbeg = blockIdx.y * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+  const int nit = (mend - mbeg + MR - 1) / MR;
+  const int yrow = lane >> 4;
+  const int ychunk = (lane & 15) ^ (yrow << 1);
+  const bool y_ok = (c0 + ychunk * 8) < a.Co;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  auto stage = [&](int buf, int it) {
+    const int mb = mbeg + it * MR;
+    bf16_t* Yb = Ys + buf * MR * 128 + (wave * 4) * 512;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + (wave * 4 + j) * 4 + yrow;
+      const bool mok = m < mend;
+      const int64_t yoff = (int64_t)(mok ? m : 0) * a.Co + c0 + ychunk * 8;
+      glds16((mok && y_ok) ? a.dy + yoff : zero, Yb + j * 512);
+    }
+    // im2col gather: thread -> pixel (tid & 63), k quarter (tid >> 6)
+    const int p = tid & 63, quarter = tid >> 6;
+    const int m = mb + p;
+    const bool ok = m < mend;
+    const uint32_t mm = ok ? (uint32_t)m : 0u;
+    const uint32_t t1 = fdiv(mm, a.dWo);
+    const int ow = (int)(mm - t1 * a.Wo);
+    const uint32_t n = fdiv(t1, a.dHo);
+    const int oh = (int)(t1 - n * a.Ho);
+    const int ihb = oh * a.S - a.pt, iwb = ow * a.S - a.pl;
+    const int64_t base = ((int64_t)((int)n * a.Hin + ihb) * a.Win + iwb) * a.Ci;
+    bf16_t* Xb = Xs + buf * MR * KS;
+#pragma unroll
+    for (int kk = 0; kk < KS / 4; kk += 2) {
+      const int k = quarter * (KS / 4) + kk;
+      const uint32_t lo = stem_gather(a, taps, base, ihb, iwb, k, ok);
+      const uint32_t hi = stem_gather(a, taps, base, ihb, iwb, k + 1, ok);
+      *reinterpret_cast<uint32_t*>(Xb + p * KS + k) = lo | (hi << 16);
+    }
+  };
+
+  f32x16_t acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+  float bias_acc = 0.f;
+
+  const int l16 = lane & 15;
+  const int trow = l16 >> 2;
+  const int tcol = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+  const int mrow0 = (lane >> 5) * 8 + trow;
+
+  if (nit > 0) {
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) stage(buf ^ 1, it + 1);
+    const bf16_t* Xb = Xs + buf * MR * KS;
+    const bf16_t* Yb = Ys + buf * MR * 128;
+#pragma unroll
+    for (int mm = 0; mm < MR / 16; ++mm) {
+      const int row = mm * 16 + mrow0;
+      bf16x8_t yf;
+      {
+        const int col = wave * 32 + tcol;
+        const int ch0 = (col >> 3) ^ ((row & 3) << 1), ch1 = (col >> 3) ^ (((row + 4) & 3) << 1);
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(Yb + row * 128 + ch0 * 8 + (col & 7)));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(Yb + (row + 4) * 128 + ch1 * 8 + (col & 7)));
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        yf = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < KT; ++i) {
+        const int col = i * 32 + tcol;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(Xb + row * KS + col));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(Xb + (row + 4) * KS + col));
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v), yf,
+                                                         acc[i], 0, 0, 0);
+      }
+    }
+    if (a.want_bias && tid < 128) {
+#pragma unroll 8
+      for (int rr = 0; rr < MR; ++rr) {
+        const int chunk = (tid >> 3) ^ ((rr & 3) << 1);
+        bias_acc += bf2f(Yb[rr * 128 + chunk * 8 + (tid & 7)]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  float* outp = reinterpret_cast<float*>(a.out) + (int64_t)blockIdx.y * ((int64_t)a.K * a.Co + a.Co);
+  const int co = c0 + wave * 32 + (lane & 31);
+  if (co < a.Co) {
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (k >= a.K) continue;
+        if (!a.adjoint_out) {
+          outp[(int64_t)k * a.Co + co] = acc[i][v];
+        } else {
+          // k = (tap', c) of the adjoint conv (its Ci = the forward conv's Co); forward tap index
+          // = T-1-tap' (both axes flipped); forward layout [tap][Ci_f = a.Co][Co_f = a.Ci]
+          const uint32_t tapa = fdiv((uint32_t)k, a.dCi);
+          const int c = k - (int)tapa * a.Ci;
+          const int tapf = a.kh * a.kw - 1 - (int)tapa;
+          outp[((int64_t)tapf * a.Co + co) * a.Ci + c] = acc[i][v];
+        }
+      }
+  }
+  if (a.want_bias && tid < 128 && c0 + tid < a.Co) outp[(int64_t)a.K * a.Co + c0 + tid] = bias_acc;
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_z part[z * stride + i]
+__global__ __launch_bounds__(256) void split_reduce_strided_kernel(const float* __restrict__ part,
+                                                                   int splits, int64_t stride,
+                                                                   int64_t n,
+                                                                   float* __restrict__ out,
+                                                                   int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * stride + i];
+  out[i] = accumulate ? out[i] + s : s;
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i], 4 floats per thread
@@ -528,7 +857,7 @@ bool phase_ok(const cgConvGeom* g) {
 
 bool cg_fast_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                             float slope_in) {
-  if (g->Ci % 64 != 0 || g->Co % 4 != 0) return false;
+  if (g->Ci % 64 != 0) return false;
   if (!phase_ok(g)) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   if ((int64_t)g->N * g->Hin * g->Win * g->Ci >= (1ll << 31)) return false;
@@ -559,6 +888,30 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.slope_out = slope_out;
   a.dWp = make_fastdiv(a.Wp); a.dHp = make_fastdiv(a.Hp);
   const int phases = g->U * g->U;
+  if (g->Co <= 32) {
+    // narrow outputs (RGB images, logits): 32-channel tile, the pixel dimension carries the grid
+    a.ntiles = 1;
+    a.dNt = make_fastdiv(1);
+    a.mtiles = cdiv(a.Mp, 128);
+    dim3 grid(a.mtiles, phases);
+    if (a.relu_in)
+      fast_conv_kernel<128, 32, true><<<grid, 256, 0, st>>>(a);
+    else
+      fast_conv_kernel<128, 32, false><<<grid, 256, 0, st>>>(a);
+    return;
+  }
+  if (g->Co <= 64) {
+    // 64-channel tile: no MFMA work is spent on padding channels
+    a.ntiles = 1;
+    a.dNt = make_fastdiv(1);
+    a.mtiles = cdiv(a.Mp, 128);
+    dim3 grid(a.mtiles, phases);
+    if (a.relu_in)
+      fast_conv_kernel<128, 64, true><<<grid, 256, 0, st>>>(a);
+    else
+      fast_conv_kernel<128, 64, false><<<grid, 256, 0, st>>>(a);
+    return;
+  }
   a.ntiles = cdiv(g->Co, 128);
   a.dNt = make_fastdiv(a.ntiles);
   const int tiles128 = cdiv(a.Mp, 128) * a.ntiles * phases;
@@ -566,22 +919,154 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles * a.ntiles, phases);
     if (a.relu_in)
-      fast_conv_kernel<128, true><<<grid, 256, 0, st>>>(a);
+      fast_conv_kernel<128, 128, true><<<grid, 256, 0, st>>>(a);
     else
-      fast_conv_kernel<128, false><<<grid, 256, 0, st>>>(a);
+      fast_conv_kernel<128, 128, false><<<grid, 256, 0, st>>>(a);
   } else {
     a.mtiles = cdiv(a.Mp, 64);
     dim3 grid(a.mtiles * a.ntiles, phases);
     if (a.relu_in)
-      fast_conv_kernel<64, true><<<grid, 256, 0, st>>>(a);
+      fast_conv_kernel<64, 128, true><<<grid, 256, 0, st>>>(a);
     else
-      fast_conv_kernel<64, false><<<grid, 256, 0, st>>>(a);
+      fast_conv_kernel<64, 128, false><<<grid, 256, 0, st>>>(a);
   }
+}
+
+static bool stem_geom_ok(const cgConvGeom* g) {
+  return g->U == 1 && g->Ci <= 4 && g->kh * g->kw * g->Ci <= 128 &&
+         (int64_t)g->N * g->Ho * g->Wo < (1ll << 31);
+}
+
+static void stem_fill(const cgConvGeom* g, StemArgs* a) {
+  a->N = g->N; a->Hin = g->Hin; a->Win = g->Win; a->Ci = g->Ci;
+  a->Ho = g->Ho; a->Wo = g->Wo; a->Co = g->Co; a->kh = g->kh; a->kw = g->kw;
+  a->S = g->S; a->pt = g->pt; a->pl = g->pl;
+  a->M = g->N * g->Ho * g->Wo;
+  a->K = g->kh * g->kw * g->Ci;
+  a->Kp = (a->K + 7) & ~7;
+  a->KS = (a->K + 31) & ~31;
+  a->dWo = make_fastdiv(g->Wo); a->dHo = make_fastdiv(g->Ho);
+  a->dCi = make_fastdiv(g->Ci); a->dKw = make_fastdiv(g->kw);
+}
+
+bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                            float slope_in, const void* gate_out, const void* residual) {
+  if (!stem_geom_ok(g) || g->Co > 128 || gate_out || residual) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  return true;
+}
+
+void cg_stem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                         int out_is_f32, const float* bias, const void* gate_in, hipStream_t st) {
+  StemArgs a;
+  stem_fill(g, &a);
+  a.in = (const bf16_t*)in; a.bt = (const bf16_t*)bt; a.dy = nullptr; a.out = out; a.bias = bias;
+  a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.want_bias = 0; a.rows_per_split = 0;
+  a.adjoint_out = 0;
+  const int grid = cdiv(a.M, 128);
+  switch (a.KS) {
+    case 32: stem_fwd_kernel<32><<<grid, 256, 0, st>>>(a); break;
+    case 64: stem_fwd_kernel<64><<<grid, 256, 0, st>>>(a); break;
+    case 96: stem_fwd_kernel<96><<<grid, 256, 0, st>>>(a); break;
+    default: stem_fwd_kernel<128><<<grid, 256, 0, st>>>(a); break;
+  }
+}
+
+bool cg_stem_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                             float slope_in, const void* gate_dy) {
+  if (!stem_geom_ok(g) || gate_dy || g->Co % 8 != 0) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  return true;
+}
+
+static void stem_wgrad_plan(const cgConvGeom* g, int* splits, int* rps) {
+  const int M = g->N * g->Ho * g->Wo;
+  int s = M / 1024 > 0 ? M / 1024 : 1;
+  if (s > 512) s = 512;
+  int r = cdiv(M, s);
+  r = (r + 63) / 64 * 64;
+  *splits = cdiv(M, r);
+  *rps = r;
+}
+
+size_t cg_stem_wgrad_workspace_bytes(const cgConvGeom* g) {
+  int splits, rps;
+  stem_wgrad_plan(g, &splits, &rps);
+  const size_t K = (size_t)g->kh * g->kw * g->Ci;
+  return align_up((size_t)splits * (K * g->Co + g->Co) * sizeof(float), 256);
+}
+
+// geometry of the adjoint (data-gradient) convolution: input = g's output space
+static cgConvGeom adjoint_geom(const cgConvGeom* g) {
+  cgConvGeom t;
+  t.N = g->N; t.Hin = g->Ho; t.Win = g->Wo; t.Ci = g->Co;
+  t.Ho = g->Hin; t.Wo = g->Win; t.Co = g->Ci;
+  t.kh = g->kh; t.kw = g->kw; t.S = g->U; t.U = g->S;
+  t.pt = g->kh - 1 - g->pt; t.pl = g->kw - 1 - g->pl;
+  return t;
+}
+
+// narrow outputs (Co <= 4, e.g. the generator's RGB convolution): dw[k][co] = sum x[k] dy[co] is the
+// stem weight gradient of the ADJOINT convolution with the operands swapped
+bool cg_narrow_wgrad_supported(const cgConvGeom* g, const void* gate_in, const void* gate_dy) {
+  if (gate_in || gate_dy) return false;
+  if (g->S != 1 || g->U != 1 || g->Co > 4 || g->Ci % 8 != 0) return false;
+  const cgConvGeom t = adjoint_geom(g);
+  return stem_geom_ok(&t);
+}
+
+size_t cg_narrow_wgrad_workspace_bytes(const cgConvGeom* g) {
+  const cgConvGeom t = adjoint_geom(g);
+  return cg_stem_wgrad_workspace_bytes(&t);
+}
+
+static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, const void* dy,
+                           float* dw, int accumulate, float* dbias, void* ws, int adjoint_out,
+                           hipStream_t st);
+
+void cg_narrow_wgrad_launch(const cgConvGeom* g, const void* in, const void* dy, float* dw,
+                            int accumulate, void* ws, hipStream_t st) {
+  const cgConvGeom t = adjoint_geom(g);
+  // adjoint conv: "input" = dy (Co channels), "output gradient" = x
+  stem_wgrad_run(&t, dy, 0, in, dw, accumulate, nullptr, ws, 1, st);
+}
+
+void cg_stem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
+                          const void* dy, float* dw, int accumulate, float* dbias, void* ws,
+                          hipStream_t st) {
+  stem_wgrad_run(g, in, gate_in != nullptr, dy, dw, accumulate, dbias, ws, 0, st);
+}
+
+static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, const void* dy,
+                           float* dw, int accumulate, float* dbias, void* ws, int adjoint_out,
+                           hipStream_t st) {
+  StemArgs a;
+  stem_fill(g, &a);
+  int splits, rps;
+  stem_wgrad_plan(g, &splits, &rps);
+  a.in = (const bf16_t*)in; a.bt = nullptr; a.dy = (const bf16_t*)dy; a.out = ws; a.bias = nullptr;
+  a.relu_in = relu_in; a.out_f32 = 1; a.want_bias = dbias != nullptr;
+  a.adjoint_out = adjoint_out;
+  a.rows_per_split = rps;
+  dim3 grid(cdiv(g->Co, 128), splits);
+  switch (a.KS) {
+    case 32: stem_wgrad_kernel<32><<<grid, 256, 0, st>>>(a); break;
+    case 64: stem_wgrad_kernel<64><<<grid, 256, 0, st>>>(a); break;
+    case 96: stem_wgrad_kernel<96><<<grid, 256, 0, st>>>(a); break;
+    default: stem_wgrad_kernel<128><<<grid, 256, 0, st>>>(a); break;
+  }
+  const int64_t KC = (int64_t)a.K * g->Co, stride = KC + g->Co;
+  split_reduce_strided_kernel<<<cdiv(KC, 256), 256, 0, st>>>((const float*)ws, splits, stride, KC,
+                                                             dw, accumulate);
+  if (dbias)
+    split_reduce_strided_kernel<<<cdiv(g->Co, 256), 256, 0, st>>>((const float*)ws + KC, splits,
+                                                                  stride, g->Co, dbias,
+                                                                  accumulate);
 }
 
 bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                              float slope_in, const void* gate_dy) {
-  if (g->Ci % 128 != 0 || g->Co % 8 != 0) return false;
+  if (g->Ci % 64 != 0 || g->Co % 8 != 0) return false;
   if (!phase_ok(g)) return false;
   if (gate_dy) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
@@ -591,9 +1076,12 @@ bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* ga
 
 void cg_fast_wgrad_plan(const cgConvGeom* g, int* splits, int* rows_per_split) {
   const int Mp = g->N * (g->Ho / g->U) * (g->Wo / g->U);
-  const int tiles = g->kh * g->kw * (g->Ci / 128) * cdiv(g->Co, 128);
-  int s = cdiv(512, tiles);
-  const int max_by_rows = Mp / 128 > 0 ? Mp / 128 : 1;  // >= 2 slices of 64 rows per split
+  const int tkc = (g->Ci % 128 == 0) ? 128 : 64;
+  const int tiles = g->kh * g->kw * (g->Ci / tkc) * cdiv(g->Co, 128);
+  // each split costs one fp32 partial image of the whole weight (written, then re-read by the
+  // reduce): only split as far as filling the chip needs, and never below 8 row slices per split
+  int s = cdiv(384, tiles);
+  const int max_by_rows = Mp / 512 > 0 ? Mp / 512 : 1;
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
@@ -629,7 +1117,8 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
   a.Hp = g->Ho / g->U; a.Wp = g->Wo / g->U;
   a.Mp = g->N * a.Hp * a.Wp;
   a.K = g->kh * g->kw * g->Ci;
-  a.cblocks = g->Ci / 128;
+  const int tkc = (g->Ci % 128 == 0) ? 128 : 64;
+  a.cblocks = g->Ci / tkc;
   a.ktiles = g->kh * g->kw * a.cblocks;
   a.ntiles = cdiv(g->Co, 128);
   a.rows_per_split = rps;
@@ -650,13 +1139,20 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     a.bias_out = bias_in_kernel ? wsf + (size_t)splits * KC : nullptr;
   }
   dim3 grid(a.ktiles * a.ntiles, splits);
-  if (a.relu_in)
-    fast_wgrad_kernel<true><<<grid, 256, 0, st>>>(a);
-  else
-    fast_wgrad_kernel<false><<<grid, 256, 0, st>>>(a);
+  if (tkc == 128) {
+    if (a.relu_in)
+      fast_wgrad_kernel<128, true><<<grid, 256, 0, st>>>(a);
+    else
+      fast_wgrad_kernel<128, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (a.relu_in)
+      fast_wgrad_kernel<64, true><<<grid, 256, 0, st>>>(a);
+    else
+      fast_wgrad_kernel<64, false><<<grid, 256, 0, st>>>(a);
+  }
   const int64_t c4 = g->Co / 4;
   if (splits > 1) {
-    const int64_t n4 = (int64_t)(KC / 4);  // Ci % 128 == 0 and Co % 8 == 0 -> divisible
+    const int64_t n4 = (int64_t)(KC / 4);  // Ci % 64 == 0 and Co % 8 == 0 -> divisible
     split_reduce4_kernel<<<cdiv(n4, 256), 256, 0, st>>>(wsf, splits, n4, dw, accumulate);
     if (bias_in_kernel)
       split_reduce4_kernel<<<cdiv(c4, 256), 256, 0, st>>>(wsf + (size_t)splits * KC, splits, c4,

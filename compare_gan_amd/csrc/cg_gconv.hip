@@ -610,6 +610,18 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   int rc = check_geom(g, "cg_gconv");
   if (rc) return rc;
   if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
+  if (cg_stem_conv_supported(g, in, gate_in, slope_in, gate_out, residual)) {
+    hipStream_t fst = (hipStream_t)stream;
+    if (cg_prof_enabled()) {
+      double flops, bytes;
+      algorithmic_cost(g, &flops, &bytes);
+      cg_prof_begin(CG_PROF_GCONV_OTHER, flops, bytes, fst);
+    }
+    cg_stem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, fst);
+    cg_prof_end(CG_PROF_GCONV_OTHER, fst);
+    CG_CHECK_LAUNCH("cg_gconv(stem)");
+    return CG_OK;
+  }
   if (cg_fast_conv_supported(g, in, gate_in, slope_in)) {
     hipStream_t fst = (hipStream_t)stream;
     if (cg_prof_enabled()) {
@@ -687,6 +699,13 @@ extern "C" size_t cg_gwgrad_workspace_bytes(const cgConvGeom* g) {
   size_t fast = 0;
   if (cg_fast_wgrad_supported(g, nullptr, nullptr, 0.f, nullptr))
     fast = cg_fast_wgrad_workspace_bytes(g);
+  if (cg_stem_wgrad_supported(g, nullptr, nullptr, 0.f, nullptr))
+    fast = cg_stem_wgrad_workspace_bytes(g);
+  if (cg_narrow_wgrad_supported(g, nullptr, nullptr)) {
+    fast = cg_narrow_wgrad_workspace_bytes(g);
+    const size_t cs = cg_colsum_workspace_bytes((int64_t)g->N * g->Ho * g->Wo, g->Co);
+    if (cs > fast) fast = cs;
+  }
   const size_t slow = gwgrad_slow_workspace_bytes(g);
   return fast > slow ? fast : slow;
 }
@@ -709,6 +728,35 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
   if (!ws || ws_bytes < cg_gwgrad_workspace_bytes(g))
     CG_FAIL(CG_ERR_WORKSPACE, "cg_gwgrad: workspace too small (%zu < %zu)", ws_bytes,
             cg_gwgrad_workspace_bytes(g));
+  if (cg_stem_wgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
+    hipStream_t fst = (hipStream_t)stream;
+    if (cg_prof_enabled()) {
+      double flops, bytes;
+      algorithmic_cost(g, &flops, &bytes);
+      cg_prof_begin(CG_PROF_GWGRAD_OTHER, flops, bytes, fst);
+    }
+    cg_stem_wgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, ws, fst);
+    cg_prof_end(CG_PROF_GWGRAD_OTHER, fst);
+    CG_CHECK_LAUNCH("cg_gwgrad(stem)");
+    return CG_OK;
+  }
+  if (cg_narrow_wgrad_supported(g, gate_in, gate_dy)) {
+    hipStream_t fst = (hipStream_t)stream;
+    if (cg_prof_enabled()) {
+      double flops, bytes;
+      algorithmic_cost(g, &flops, &bytes);
+      cg_prof_begin(CG_PROF_GWGRAD_OTHER, flops, bytes, fst);
+    }
+    cg_narrow_wgrad_launch(g, in, dy, dw, accumulate, ws, fst);
+    CG_CHECK_LAUNCH("cg_gwgrad(narrow)");
+    int rc2 = CG_OK;
+    if (dbias) {
+      if (accumulate) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gwgrad: accumulate with dbias on a narrow conv");
+      rc2 = cg_colsum(dy, (int64_t)g->N * g->Ho * g->Wo, g->Co, dbias, ws, ws_bytes, stream);
+    }
+    cg_prof_end(CG_PROF_GWGRAD_OTHER, fst);
+    return rc2;
+  }
   if (cg_fast_wgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
     if (cg_prof_enabled()) {

@@ -105,9 +105,11 @@ __global__ void scale_f32_kernel(const float* __restrict__ x, const float* __res
 }
 
 inline int colred_splits(int K, int Co) {
+  // enough blocks to pull the matrix at full rate, few enough that the single-block finalisation
+  // (which re-reads every partial) stays short
   const int ct = cdiv(Co, 64);
-  int s = cdiv(512, ct);
-  const int maxs = K / 16 > 0 ? K / 16 : 1;
+  int s = cdiv(128, ct);
+  const int maxs = K / 64 > 0 ? K / 64 : 1;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
   return s;

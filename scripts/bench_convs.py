@@ -15,6 +15,7 @@ SHAPES = {
         (64, 16, 16, 256, 256, 3, 1, 2, 0), (64, 16, 16, 256, 256, 3, 1, 1, 0),
         (64, 8, 8, 256, 256, 3, 1, 2, 0), (64, 8, 8, 256, 256, 3, 1, 1, 0),
         (64, 4, 4, 256, 256, 3, 1, 2, 0), (64, 1, 1, 128, 4096, 1, 1, 1, 0),
+        (128, 32, 32, 3, 128, 3, 1, 1, 1), (64, 32, 32, 256, 3, 3, 1, 1, 0),
     ],
     "resnet128": [
         (128, 128, 128, 64, 64, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
@@ -22,6 +23,7 @@ SHAPES = {
         (128, 32, 32, 256, 256, 3, 1, 1, 1), (128, 16, 16, 256, 256, 3, 1, 1, 1),
         (128, 8, 8, 512, 512, 3, 1, 1, 1), (64, 64, 64, 128, 64, 3, 1, 2, 0),
         (64, 32, 32, 256, 128, 3, 1, 2, 0), (64, 128, 128, 64, 64, 3, 1, 1, 0),
+        (128, 128, 128, 3, 64, 3, 1, 1, 1), (64, 128, 128, 64, 3, 3, 1, 1, 0),
     ],
 }[which]
 R = 20

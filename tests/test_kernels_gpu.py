@@ -140,6 +140,28 @@ def test_gconv_gates_residual(K, dev, slope):
         assert_close_f32(db2, dy64.sum(dim=(0, 1, 2)), "relu-gated dbias", rtol=2e-4, abs_rms=2e-4)
 
 
+def test_stem_relu_gate(K, dev):
+    """Image-like input (Ci = 3) with the ReLU input gate of a D block's first convolution
+    (resnet_ops.py:165): forward, weight and bias gradients."""
+    g = _gen(21)
+    N, H, W, Ci, Co, k = 3, 12, 12, 3, 64, 3
+    x64, xb = rand_bf16((N, H, W, Ci), g)
+    w64, wb = rand_bf16((k, k, Ci, Co), g, 0.2)
+    bias = torch.randn(Co, generator=g, dtype=torch.float32)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, k, k, 1, 1)
+    bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev))
+    xd = xb.to(dev)
+    wr = w64.clone().requires_grad_(True)
+    ref = oops.conv2d_same(torch.relu(x64), wr, 1) + bias.to(torch.float64)
+    y = K.gconv(geom, xd, bt_f, bias=bias.to(dev), gate_in=xd, slope_in=0.0)
+    assert_close_bf16(y, ref.detach(), "stem relu fwd")
+    dy64, dyb = rand_bf16(tuple(ref.shape), g)
+    (ref * dy64).sum().backward()
+    dw, db = K.gwgrad(geom, xd, dyb.to(dev), gate_in=xd, slope_in=0.0, want_dbias=True)
+    assert_close_f32(dw, wr.grad, "stem relu wgrad", rtol=2e-4, abs_rms=2e-4)
+    assert_close_f32(db, dy64.sum(dim=(0, 1, 2)), "stem dbias", rtol=2e-4, abs_rms=2e-4)
+
+
 DECONV_CASES = [("dcgan_5x5", 2, 4, 4, 64, 32, 5, 2), ("sndcgan_4x4", 2, 8, 8, 32, 16, 4, 2),
                 ("sndcgan_3x3_s1", 2, 8, 8, 64, 3, 3, 1)]
 
