@@ -42,6 +42,7 @@ def parse_args():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-fid", action="store_true", help="skip the FID-10k wall-clock leg")
     p.add_argument("--cpu-budget-s", type=float, default=20.0)
     p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
@@ -208,6 +209,25 @@ def main():
                              "launches_per_step": v["launches"] / n_prof}
                          for k, v in fam.items()},
         }
+    if rank == 0 and world == 1 and not args.no_fid:
+        # second half of BASELINE.json's metric: FID-10k wall-clock (10,000 generated vs 10,000
+        # synthetic reference images, 157 batches of 64, Inception features, fp64 statistics)
+        from compare_gan_amd.metrics import fid_score as fid_lib
+        from compare_gan_amd.metrics import inception_score as is_lib
+        n_eval = dataset.eval_test_samples
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = eval_gan_lib.evaluate_gan(gan, [is_lib.InceptionScoreTask(), fid_lib.FIDScoreTask()],
+                                        num_averaging_runs=1)
+        torch.cuda.synchronize()
+        result["fid10k"] = {
+            "wall_s": round(time.perf_counter() - t0, 3), "num_examples": n_eval,
+            "split_s": {k: round(v, 3) for k, v in eval_gan_lib.LAST_TIMING.items()},
+            "fid": round(float(res["fid_score_mean"]), 4),
+            "inception_score": round(float(res["inception_score_mean"]), 4),
+            "note": "synthetic reference images; seeded (untrained) Inception weights, the trained "
+                    "graph is not available offline -- wall-clock is meaningful, the values are not "
+                    "comparable with published FIDs"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_guarded(args.config, bsz, args.cpu_budget_s)
 

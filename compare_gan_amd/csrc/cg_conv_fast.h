@@ -17,10 +17,12 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
                           float* dw, int accumulate, float* dbias, void* ws, hipStream_t st);
 
 // image-like inputs (Ci <= 4): im2col-in-LDS stem kernels
-bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
-                            float slope_in, const void* gate_out, const void* residual);
+bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
+                            const void* gate_in, float slope_in, const void* gate_out,
+                            const void* residual);
 void cg_stem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
-                         int out_is_f32, const float* bias, const void* gate_in, hipStream_t st);
+                         int out_is_f32, const float* bias, const void* gate_in,
+                         const void* gate_out, float slope_out, hipStream_t st);
 bool cg_stem_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                              float slope_in, const void* gate_dy);
 size_t cg_stem_wgrad_workspace_bytes(const cgConvGeom* g);

@@ -68,6 +68,7 @@ struct FastConvArgs {
   int cblocks;     // Ci / 64
   int mtiles, ntiles;
   int relu_in, out_f32;
+  int self_gate;  // gate_out == out: the output activation is applied to the value itself
   float slope_out;
   FastDiv dWp, dHp, dNt;
 };
@@ -245,7 +246,11 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
             const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
           }
-          if (a.gate_out) {
+          if (a.self_gate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+          } else if (a.gate_out) {
             const uint2 g2 = *reinterpret_cast<const uint2*>(a.gate_out + o);
             if (!(bf2f((bf16_t)(g2.x & 0xffff)) > 0.f)) v[0] *= a.slope_out;
             if (!(bf2f((bf16_t)(g2.x >> 16)) > 0.f)) v[1] *= a.slope_out;
@@ -274,7 +279,11 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
           for (int e = 0; e < 4; ++e) {
             if (co + e >= a.Co) continue;
             float val = v[e] + (a.bias ? a.bias[co + e] : 0.f);
-            if (a.gate_out && !(bf2f(a.gate_out[o + e]) > 0.f)) val *= a.slope_out;
+            if (a.self_gate) {
+              if (!(val > 0.f)) val *= a.slope_out;
+            } else if (a.gate_out && !(bf2f(a.gate_out[o + e]) > 0.f)) {
+              val *= a.slope_out;
+            }
             if (a.residual) val += bf2f(a.residual[o + e]);
             if (a.out_f32)
               reinterpret_cast<float*>(a.out)[o + e] = val;
@@ -511,6 +520,8 @@ struct StemArgs {
   int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, pt, pl;
   int M, K, Kp, KS;   // KS = K rounded up to 32
   int relu_in, out_f32, want_bias;
+  int self_gate;     // forward: y = lrelu_slope(conv + bias)
+  float slope_out;
   int rows_per_split;
   int adjoint_out;   // weight gradient computed on the adjoint geometry: store as [kh,kw,Co,Ci]
                      // with flipped taps, i.e. directly in the forward conv's HWIO layout
@@ -617,6 +628,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
           const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
           v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         }
+        if (a.self_gate) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+        }
         if (a.out_f32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + opix + co) =
               make_float4(v[0], v[1], v[2], v[3]);
@@ -631,7 +647,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (co + e >= a.Co) continue;
-        const float val = acc[q * 4 + e] + (a.bias ? a.bias[co + e] : 0.f);
+        float val = acc[q * 4 + e] + (a.bias ? a.bias[co + e] : 0.f);
+        if (a.self_gate && !(val > 0.f)) val *= a.slope_out;
         if (a.out_f32)
           reinterpret_cast<float*>(a.out)[opix + co + e] = val;
         else
@@ -874,7 +891,8 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.bt = (const bf16_t*)bt;
   a.out = out;
   a.bias = bias;
-  a.gate_out = (const bf16_t*)gate_out;
+  a.self_gate = (gate_out != nullptr && gate_out == out);
+  a.gate_out = a.self_gate ? nullptr : (const bf16_t*)gate_out;
   a.residual = (const bf16_t*)residual;
   a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
   a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;
@@ -949,17 +967,21 @@ static void stem_fill(const cgConvGeom* g, StemArgs* a) {
   a->dCi = make_fastdiv(g->Ci); a->dKw = make_fastdiv(g->kw);
 }
 
-bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
-                            float slope_in, const void* gate_out, const void* residual) {
-  if (!stem_geom_ok(g) || g->Co > 128 || gate_out || residual) return false;
+bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
+                            const void* gate_in, float slope_in, const void* gate_out,
+                            const void* residual) {
+  if (!stem_geom_ok(g) || g->Co > 128 || (gate_out && gate_out != out) || residual) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   return true;
 }
 
 void cg_stem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
-                         int out_is_f32, const float* bias, const void* gate_in, hipStream_t st) {
+                         int out_is_f32, const float* bias, const void* gate_in,
+                         const void* gate_out, float slope_out, hipStream_t st) {
   StemArgs a;
   stem_fill(g, &a);
+  a.self_gate = gate_out != nullptr;
+  a.slope_out = slope_out;
   a.in = (const bf16_t*)in; a.bt = (const bf16_t*)bt; a.dy = nullptr; a.out = out; a.bias = bias;
   a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.want_bias = 0; a.rows_per_split = 0;
   a.adjoint_out = 0;
@@ -1047,6 +1069,7 @@ static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, con
   a.in = (const bf16_t*)in; a.bt = nullptr; a.dy = (const bf16_t*)dy; a.out = ws; a.bias = nullptr;
   a.relu_in = relu_in; a.out_f32 = 1; a.want_bias = dbias != nullptr;
   a.adjoint_out = adjoint_out;
+  a.self_gate = 0; a.slope_out = 0.f;
   a.rows_per_split = rps;
   dim3 grid(cdiv(g->Co, 128), splits);
   switch (a.KS) {

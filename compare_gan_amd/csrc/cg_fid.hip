@@ -316,6 +316,25 @@ extern "C" int cg_gemm_f64(const double* a, const double* b, double* c, int m, i
   return CG_OK;
 }
 
+__global__ void rowscale_f64_kernel(const double* __restrict__ a, const double* __restrict__ sc,
+                                    double* __restrict__ out, int64_t total, int cols) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    out[i] = a[i] * sc[i / cols];
+}
+
+extern "C" int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
+                               int cols, cgStream stream) {
+  if (!a || !scale || !out || rows <= 0 || cols <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_rowscale_f64: bad argument");
+  const int64_t total = (int64_t)rows * cols;
+  int64_t b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  rowscale_f64_kernel<<<(int)b, 256, 0, (hipStream_t)stream>>>(a, scale, out, total, cols);
+  CG_CHECK_LAUNCH("cg_rowscale_f64");
+  return CG_OK;
+}
+
 extern "C" size_t cg_syevj_workspace_bytes(int d) { return d > 0 ? 256 : 0; }
 
 extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol,

@@ -27,6 +27,7 @@ struct GConvArgs {
   int HinU, WinU;
   float slope_in, slope_out;
   int out_f32;
+  int self_gate;  // gate_out == out
   FastDiv dWo, dHo, dCi, dKw;
 };
 
@@ -225,7 +226,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
         if (m >= a.M) continue;
         const int64_t o = (int64_t)m * a.Co + co;
         float val = acc[i][j][v] + bias;
-        if (a.gate_out) {
+        if (a.self_gate) {
+          if (!(val > 0.f)) val *= a.slope_out;
+        } else if (a.gate_out) {
           const float g = bf2f(a.gate_out[o]);
           if (!(g > 0.f)) val *= a.slope_out;
         }
@@ -610,14 +613,14 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   int rc = check_geom(g, "cg_gconv");
   if (rc) return rc;
   if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
-  if (cg_stem_conv_supported(g, in, gate_in, slope_in, gate_out, residual)) {
+  if (cg_stem_conv_supported(g, in, out, gate_in, slope_in, gate_out, residual)) {
     hipStream_t fst = (hipStream_t)stream;
     if (cg_prof_enabled()) {
       double flops, bytes;
       algorithmic_cost(g, &flops, &bytes);
       cg_prof_begin(CG_PROF_GCONV_OTHER, flops, bytes, fst);
     }
-    cg_stem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, fst);
+    cg_stem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, fst);
     cg_prof_end(CG_PROF_GCONV_OTHER, fst);
     CG_CHECK_LAUNCH("cg_gconv(stem)");
     return CG_OK;
@@ -641,7 +644,8 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   a.out = out;
   a.bias = bias;
   a.gate_in = (const bf16_t*)gate_in;
-  a.gate_out = (const bf16_t*)gate_out;
+  a.self_gate = (gate_out != nullptr && gate_out == out);
+  a.gate_out = a.self_gate ? nullptr : (const bf16_t*)gate_out;
   a.residual = (const bf16_t*)residual;
   a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
   a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;

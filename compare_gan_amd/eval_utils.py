@@ -1,0 +1,93 @@
+"""Data-related evaluation utilities (reference: compare_gan/eval_utils.py:41-206).
+
+EvalDataSample, NanFoundError, get_real_images, sample_fake_dataset and the batched Inception
+transform.  Image sets stay on the GPU as fp32 tensors in [0, 255] (the reference round-trips
+them through NumPy: SURVEY.md section 8a row a14)."""
+import numpy as np
+import torch
+
+from compare_gan_amd import inception as inception_lib
+
+_INCEPTION = {}
+
+
+class NanFoundError(Exception):
+  """Exception thrown, when the Nans are present in the output (eval_utils.py:52-53)."""
+
+
+class EvalDataSample(object):
+  """Images (in [0, 255]) and Inception features of one evaluation set (eval_utils.py:56-84)."""
+
+  def __init__(self, images):
+    self.images = images
+    self.activations = None
+    self.logits = None
+
+  def discard_images(self):
+    del self.images
+    self.images = None
+
+  def set_inception_features(self, activations, logits):
+    self.activations = activations
+    self.logits = logits
+
+  def set_num_examples(self, num_examples):
+    if self.images is not None:
+      assert self.images.shape[0] >= num_examples
+      self.images = self.images[:num_examples]
+    if self.activations is not None:
+      assert self.activations.shape[0] >= num_examples
+      self.activations = self.activations[:num_examples]
+    if self.logits is not None:
+      assert self.logits.shape[0] >= num_examples
+      self.logits = self.logits[:num_examples]
+
+
+def _to_three_channels(images):
+  if images.shape[-1] == 1:
+    return images.repeat(1, 1, 1, 3) if torch.is_tensor(images) else np.tile(images, [1, 1, 1, 3])
+  return images
+
+
+def get_real_images(dataset, num_examples, split=None, failure_on_insufficient_examples=True,
+                    device="cuda:0"):
+  """num_examples real images with values in [0, 255] (eval_utils.py:87-141).  Offline only the
+  synthetic eval split exists (datasets.eval_images)."""
+  del split, failure_on_insufficient_examples
+  images = torch.from_numpy(dataset.eval_images(num_examples)).to(device)
+  from compare_gan_amd.hip import kernels as K
+  return _to_three_channels(K.scale_f32(images.contiguous(), None, 255.0))
+
+
+def sample_fake_dataset(generate_fn, num_batches):
+  """Concatenates `num_batches` generator batches, x255; raises NanFoundError on NaNs
+  (eval_utils.py:144-162).  generate_fn() -> [B, H, W, C] fp32 device tensor in [0, 1]."""
+  samples = []
+  for _ in range(num_batches):
+    x = generate_fn()
+    samples.append(x)
+  fake_images = torch.cat(samples, dim=0)
+  if bool(torch.isnan(fake_images).any()):
+    raise NanFoundError("Detected NaN in fake images.")
+  from compare_gan_amd.hip import kernels as K
+  return _to_three_channels(K.scale_f32(fake_images.contiguous(), None, 255.0))
+
+
+def get_inception(device):
+  key = str(device)
+  if key not in _INCEPTION:
+    _INCEPTION[key] = inception_lib.InceptionV3(device)
+  return _INCEPTION[key]
+
+
+def inception_transform(inputs):
+  """[B, H, W, 3] in [0, 255] -> (pool_3 [B, 2048], logits [B, 1008]) (eval_utils.py:165-175)."""
+  if float(inputs.min()) < 0.0 or float(inputs.max()) > 255.0:
+    raise ValueError("inception_transform expects images in [0, 255]")
+  return get_inception(inputs.device).features(inputs)
+
+
+def inception_transform_np(inputs, batch_size, device="cuda:0"):
+  """Batched Inception features and logits for an image set (eval_utils.py:178-206)."""
+  dev = inputs.device if torch.is_tensor(inputs) and inputs.is_cuda else torch.device(device)
+  return get_inception(dev).transform(inputs, batch_size)

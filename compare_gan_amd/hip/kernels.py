@@ -85,7 +85,9 @@ def weight_prep(w, scale=None, want_fwd=True, want_bwd=False):
 
 
 def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slope_out=0.0,
-          residual=None, out_f32=False):
+          residual=None, out_f32=False, act_out=None):
+    """act_out: leaky-ReLU slope applied to (conv + bias) itself (0.0 = ReLU); exclusive with
+    gate_out."""
     _req(x, BF16, "x")
     _req(bt, BF16, "bt")
     _req(bias, F32, "bias", True)
@@ -106,6 +108,10 @@ def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slo
     if bias is not None and bias.numel() != geom.Co:
         raise ValueError("bias has the wrong number of elements")
     out = torch.empty(oshape, dtype=F32 if out_f32 else BF16, device=x.device)
+    if act_out is not None:
+        if gate_out is not None:
+            raise ValueError("act_out and gate_out are mutually exclusive")
+        gate_out, slope_out = out, act_out   # gate_out == out: the value itself is the gate
     check(lib().cg_gconv(ctypes.byref(geom), _p(x), _p(bt), _p(out), int(out_f32), _p(bias),
                          _p(gate_in), float(slope_in), _p(gate_out), float(slope_out),
                          _p(residual), _stream()), "cg_gconv")
@@ -653,6 +659,15 @@ def gemm_f64(a, b, ta=False, tb=False):
     check(lib().cg_gemm_f64(_p(a), _p(b), _p(c), m, n, k, int(ta), int(tb), _stream()),
           "cg_gemm_f64")
     return c
+
+
+def rowscale_f64(a, scale):
+    _req(a, F64, "a")
+    _req(scale, F64, "scale")
+    out = torch.empty_like(a)
+    check(lib().cg_rowscale_f64(_p(a), _p(scale), _p(out), a.shape[0], a.shape[1], _stream()),
+          "cg_rowscale_f64")
+    return out
 
 
 def syevj_f64(a, max_sweeps=30, tol=1e-15):

@@ -1,0 +1,212 @@
+"""Batched InceptionV3 feature extractor for FID / Inception score on the HIP kernels.
+
+Reference: compare_gan/eval_utils.py:41-49,165-206 -- the reference runs tfgan.eval.run_inception on
+the frozen 2015 Inception graph (`inceptionv1_for_inception_score.pb`, downloaded at run time) and
+reads `pool_3:0` ([B, 2048]) and `logits:0` ([B, 1008]) after tfgan.eval.preprocess_image
+(bilinear resize to 299x299, (x - 128) / 128).
+
+What is reproduced here: the preprocessing (cg_inception_preprocess, TF1 legacy bilinear) and the
+architecture of that graph (stem, mixed .. mixed_10, 8x8 average pool, 1008-way logits; batch norm
+folded into conv + bias + ReLU as in the frozen graph).  What cannot be reproduced offline: the
+trained weights (no network, no file on disk -- SURVEY.md section 8c).  Weights are therefore
+He-normal draws from a fixed seed: FID / IS values are self-consistent (same extractor for real and
+fake images) but not comparable with published numbers -- "parity unpinned" for real activations.
+`load_weights()` accepts a {name: array} dict in the layouts below, should a weight file exist.
+
+Every arithmetic op is a HIP kernel: cg_gconv (conv + bias + ReLU fused, act_out), cg_pool2d,
+cg_spatial_reduce (global average pool), cg_gconv as the logits GEMM.  torch.cat only moves bytes.
+"""
+import math
+
+import torch
+
+from compare_gan_amd.hip import kernels as K
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+# ---- architecture table ------------------------------------------------------------------------
+# op tuples: ("conv", name, cout, kh, kw, stride, padding) | ("max", k, s) | ("avg3",) and
+# ("mixed", name, [branches]) where every branch is a list of ops applied to the block input.
+
+
+def _c(name, cout, kh=1, kw=1, stride=1, padding="SAME"):
+  return ("conv", name, cout, kh, kw, stride, padding)
+
+
+def _mixed_35(name, pool_proj):
+  return ("mixed", name, [
+      [_c(name + "/b0_1x1", 64)],
+      [_c(name + "/b1_1x1", 48), _c(name + "/b1_5x5", 64, 5, 5)],
+      [_c(name + "/b2_1x1", 64), _c(name + "/b2_3x3a", 96, 3, 3), _c(name + "/b2_3x3b", 96, 3, 3)],
+      [("avg3",), _c(name + "/b3_pool_1x1", pool_proj)],
+  ])
+
+
+def _mixed_17(name, c7):
+  return ("mixed", name, [
+      [_c(name + "/b0_1x1", 192)],
+      [_c(name + "/b1_1x1", c7), _c(name + "/b1_1x7", c7, 1, 7), _c(name + "/b1_7x1", 192, 7, 1)],
+      [_c(name + "/b2_1x1", c7), _c(name + "/b2_7x1a", c7, 7, 1), _c(name + "/b2_1x7a", c7, 1, 7),
+       _c(name + "/b2_7x1b", c7, 7, 1), _c(name + "/b2_1x7b", 192, 1, 7)],
+      [("avg3",), _c(name + "/b3_pool_1x1", 192)],
+  ])
+
+
+def _mixed_8(name, pool):
+  return ("mixed", name, [
+      [_c(name + "/b0_1x1", 320)],
+      [_c(name + "/b1_1x1", 384), ("split", [[_c(name + "/b1_1x3", 384, 1, 3)],
+                                             [_c(name + "/b1_3x1", 384, 3, 1)]])],
+      [_c(name + "/b2_1x1", 448), _c(name + "/b2_3x3", 384, 3, 3),
+       ("split", [[_c(name + "/b2_1x3", 384, 1, 3)], [_c(name + "/b2_3x1", 384, 3, 1)]])],
+      [(pool,), _c(name + "/b3_pool_1x1", 192)],
+  ])
+
+
+SPEC = [
+    _c("conv", 32, 3, 3, 2, "VALID"), _c("conv_1", 32, 3, 3, 1, "VALID"), _c("conv_2", 64, 3, 3),
+    ("max", 3, 2),
+    _c("conv_3", 80), _c("conv_4", 192, 3, 3, 1, "VALID"),
+    ("max", 3, 2),
+    _mixed_35("mixed", 32), _mixed_35("mixed_1", 64), _mixed_35("mixed_2", 64),
+    ("mixed", "mixed_3", [
+        [_c("mixed_3/b0_3x3", 384, 3, 3, 2, "VALID")],
+        [_c("mixed_3/b1_1x1", 64), _c("mixed_3/b1_3x3a", 96, 3, 3),
+         _c("mixed_3/b1_3x3b", 96, 3, 3, 2, "VALID")],
+        [("max", 3, 2)],
+    ]),
+    _mixed_17("mixed_4", 128), _mixed_17("mixed_5", 160), _mixed_17("mixed_6", 160),
+    _mixed_17("mixed_7", 192),
+    ("mixed", "mixed_8", [
+        [_c("mixed_8/b0_1x1", 192), _c("mixed_8/b0_3x3", 320, 3, 3, 2, "VALID")],
+        [_c("mixed_8/b1_1x1", 192), _c("mixed_8/b1_1x7", 192, 1, 7), _c("mixed_8/b1_7x1", 192, 7, 1),
+         _c("mixed_8/b1_3x3", 192, 3, 3, 2, "VALID")],
+        [("max", 3, 2)],
+    ]),
+    _mixed_8("mixed_9", "avg3"), _mixed_8("mixed_10", "max3s1"),
+]
+POOL3_DIM = 2048
+NUM_LOGITS = 1008
+INPUT_SIZE = 299
+
+
+def conv_shapes(spec=None, cin=3):
+  """[(name, [kh, kw, cin, cout])] of every convolution in execution order, and the final width."""
+  out = []
+
+  def run(ops, c):
+    for op in ops:
+      if op[0] == "conv":
+        _, name, cout, kh, kw, _, _ = op
+        out.append((name, [kh, kw, c, cout]))
+        c = cout
+      elif op[0] == "mixed":
+        c = sum(run(b, c) for b in op[2])
+      elif op[0] == "split":
+        c = sum(run(b, c) for b in op[1])
+    return c
+  c_final = run(SPEC if spec is None else spec, cin)
+  return out, c_final
+
+
+def make_weights(seed=2015):
+  """Seeded He-normal conv kernels (HWIO fp32), small biases, and the logits layer."""
+  g = torch.Generator().manual_seed(seed)
+  w = {}
+  shapes, c_final = conv_shapes()
+  assert c_final == POOL3_DIM
+  for name, (kh, kw, ci, co) in shapes:
+    std = math.sqrt(2.0 / (kh * kw * ci))
+    w[name + "/kernel"] = torch.randn((kh, kw, ci, co), generator=g, dtype=F32) * std
+    w[name + "/bias"] = torch.randn((co,), generator=g, dtype=F32) * 0.05
+  w["logits/kernel"] = torch.randn((POOL3_DIM, NUM_LOGITS), generator=g, dtype=F32) * (
+      1.0 / math.sqrt(POOL3_DIM))
+  w["logits/bias"] = torch.zeros((NUM_LOGITS,), dtype=F32)
+  return w
+
+
+class InceptionV3(object):
+  """pool_3 / logits of [B, H, W, 3] images in [0, 255] (eval_utils.inception_transform)."""
+
+  def __init__(self, device, weights=None, seed=2015):
+    self.device = torch.device(device)
+    self.load_weights(weights if weights is not None else make_weights(seed))
+
+  def load_weights(self, weights):
+    self.weights = {k: v.to(F32).to(self.device).contiguous() for k, v in weights.items()}
+    # frozen weights: the MFMA operand images are built once
+    self._bt = {}
+    for name, v in self.weights.items():
+      if name.endswith("/kernel") and v.dim() == 4:
+        self._bt[name] = K.weight_prep(v, want_fwd=True, want_bwd=False)[0]
+    wl = self.weights["logits/kernel"]
+    self._bt["logits/kernel"] = K.weight_prep(wl.reshape(1, 1, *wl.shape), want_fwd=True)[0]
+
+  # -- ops -----------------------------------------------------------------------------------------
+  def _conv(self, x, op):
+    _, name, cout, kh, kw, stride, padding = op
+    n, h, w_, ci = x.shape
+    if padding == "SAME":
+      geom = K.geom_conv_same(n, h, w_, ci, cout, kh, kw, stride, 1)
+    else:
+      ho, wo = (h - kh) // stride + 1, (w_ - kw) // stride + 1
+      geom = K.make_geom(n, h, w_, ci, ho, wo, cout, kh, kw, stride, 1, 0, 0)
+    return K.gconv(geom, x, self._bt[name + "/kernel"], bias=self.weights[name + "/bias"],
+                   act_out=0.0)
+
+  @staticmethod
+  def _pool(x, kind, k, s, same):
+    n, h, w_, c = x.shape
+    if same:
+      p = (k - 1) // 2
+      ho, wo = -(-h // s), -(-w_ // s)
+    else:
+      p = 0
+      ho, wo = (h - k) // s + 1, (w_ - k) // s + 1
+    return K.pool2d(x, k, s, p, kind, ho, wo)
+
+  def _run(self, ops, x):
+    for op in ops:
+      if op[0] == "conv":
+        x = self._conv(x, op)
+      elif op[0] == "max":
+        x = self._pool(x, 0, op[1], op[2], False)
+      elif op[0] == "avg3":
+        x = self._pool(x, 1, 3, 1, True)
+      elif op[0] == "max3s1":
+        x = self._pool(x, 0, 3, 1, True)
+      elif op[0] == "mixed":
+        x = torch.cat([self._run(b, x) for b in op[2]], dim=3)
+      elif op[0] == "split":
+        x = torch.cat([self._run(b, x) for b in op[1]], dim=3)
+      else:
+        raise ValueError("unknown op %r" % (op,))
+    return x
+
+  def features(self, images_0_255):
+    """images [B, H, W, 3] fp32 in [0, 255] on the device -> (pool_3 [B, 2048], logits [B, 1008]),
+    both fp32."""
+    if images_0_255.shape[-1] != 3:
+      raise ValueError("Inception expects 3 colour channels, got %d" % images_0_255.shape[-1])
+    x = K.inception_preprocess(images_0_255.contiguous(), INPUT_SIZE, INPUT_SIZE)
+    x = self._run(SPEC, x)
+    n, h, w_, c = x.shape
+    pool3 = K.spatial_reduce(x, None, 1.0 / (h * w_))            # [B, 2048] bf16
+    geom = K.make_geom(n, 1, 1, c, 1, 1, NUM_LOGITS, 1, 1)
+    logits = K.gconv(geom, pool3.reshape(n, 1, 1, c), self._bt["logits/kernel"],
+                     bias=self.weights["logits/bias"], out_f32=True).reshape(n, NUM_LOGITS)
+    return K.cast_bf16_to_f32(pool3), logits
+
+  def transform(self, images_0_255, batch_size=64):
+    """eval_utils.inception_transform_np: batched over a [N, H, W, 3] array (host or device)."""
+    feats, logits = [], []
+    n = images_0_255.shape[0]
+    for i in range(0, n, batch_size):
+      batch = images_0_255[i:i + batch_size]
+      if not torch.is_tensor(batch):
+        batch = torch.from_numpy(batch)
+      f, l = self.features(batch.to(self.device, dtype=F32))
+      feats.append(f)
+      logits.append(l)
+    return torch.cat(feats, dim=0), torch.cat(logits, dim=0)

@@ -92,7 +92,9 @@ int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* 
  *   bt        [Co][kh*kw*Ci] bf16 (from cg_weight_prep)
  *   out       [N,Ho,Wo,Co] bf16, or fp32 when out_is_f32 != 0
  *   bias      [Co] fp32 or NULL;  gate_in like `in` (bf16) or NULL;  gate_out / residual like
- *             `out` (bf16) or NULL.
+ *             `out` (bf16) or NULL.  gate_out == out selects the value itself as the gate, i.e.
+ *             out = lrelu_{slope_out}(gconv + bias) + residual (conv + bias + ReLU of the
+ *             Inception graph, eval_utils.py:165-175).
  */
 int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, int out_is_f32,
              const float* bias, const void* gate_in, float slope_in, const void* gate_out,
@@ -328,6 +330,10 @@ int cg_mean_cov_f64(const float* x, int64_t n, int d, double* mean, double* cov,
 /* C = op(A) * op(B), fp64 row-major, A [m,k] (or [k,m] if ta), B [k,n] (or [n,k] if tb). */
 int cg_gemm_f64(const double* a, const double* b, double* c, int m, int n, int k, int ta, int tb,
                 cgStream stream);
+/* out[r, :] = a[r, :] * scale[r] (fp64): diag(f(w)) V when rebuilding a matrix function from its
+ * eigen-decomposition (the symmetric square roots of the FID, metrics/fid_score.py:49-51). */
+int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows, int cols,
+                    cgStream stream);
 /* Symmetric eigen-decomposition by parallel cyclic one-sided Jacobi: a [d,d] fp64 symmetric
  * (destroyed), eigenvalues -> w [d] (unsorted), eigenvectors -> ROWS of v [d,d]
  * (a = v^T diag(w) v).  max_sweeps bounds the work; rotation threshold tol (e.g. 1e-14).

@@ -12,7 +12,7 @@ else
 fi
 timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_$TAG.log
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-fid > $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
 rm -f gpurun_out/prof_$TAG/*kernel_trace.csv
 tail -4 gpurun_out/tests_$TAG.log; cut -c1-900 gpurun_out/bench_$TAG.log
