@@ -62,6 +62,7 @@ class AbstractGenerator(_Module):
 
   def __call__(self, z, y, is_training, reuse=None):
     del reuse  # AUTO_REUSE semantics: the store creates on first use and reuses afterwards
+    ops.prepare_module(self.name)
     with ops.variable_scope(self.name):
       return self.apply(z=z, y=y, is_training=is_training)
 
@@ -85,6 +86,7 @@ class AbstractDiscriminator(_Module):
 
   def __call__(self, x, y, is_training, reuse=None):
     del reuse
+    ops.prepare_module(self.name)
     with ops.variable_scope(self.name):
       return self.apply(x=x, y=y, is_training=is_training)
 

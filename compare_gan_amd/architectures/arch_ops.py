@@ -39,6 +39,11 @@ class VariableStore(object):
     self.initializers = {}    # name -> kind (for the initializer tests)
     self._gen = torch.Generator().manual_seed(seed)
     self._scope = []
+    # per top-level module ("generator" / "discriminator"), in call order:
+    self.sn_registry = {}     # module -> {weight name: (u_var name, mode, eps)}
+    self.conv_registry = {}   # module -> {weight name: None}
+    self.sn_ready = {}        # weight name -> w / sigma of the current module call
+    self.bt_ready = {}        # weight name -> (bt_fwd, bt_bwd) of the current module call
 
   # -- scopes --
   @contextlib.contextmanager
@@ -243,20 +248,59 @@ def spectral_norm(inputs, epsilon=1e-12, singular_value="left", var_name=None, b
   mode = 0 if singular_value == "left" else 1
   u_shape = (k, 1) if mode == 0 else (1, co)
   u_var = get_variable((var_name or "kernel") + "/u_var", u_shape, _normal(1.0), trainable=False)
+  store = current_store()
+  wname = store.full_name(var_name or "kernel")
+  module = wname.split("/", 1)[0]
+  store.sn_registry.setdefault(module, {})[wname] = (wname + "/u_var", mode, epsilon)
   if inputs.is_meta or build_only:
     return inputs   # graph construction only: variables exist, no power iteration is run
+  ready = store.sn_ready.pop(wname, None)
+  if ready is not None:
+    return ready     # computed by prepare_module() together with the module's other weights
   return Fn.spectral_norm(inputs, u_var, mode, epsilon)
+
+
+def prepare_module(module):
+  """Batched per-call weight bookkeeping of one network ("generator" / "discriminator"), run at the
+  start of its __call__ once its variables are known (any earlier call, including the shape-only
+  build pass, registers them): one multi-tensor power iteration for every spectrally-normalised
+  weight (the reference runs one per weight per call, arch_ops.py:479-535 -- same arithmetic, u is
+  still updated on every call) and one multi-tensor fp32 -> bf16 operand preparation."""
+  store = current_store()
+  store.sn_ready, store.bt_ready = {}, {}
+  if store.device.type == "meta":
+    return
+  sn = store.sn_registry.get(module, {})
+  names = [n for n in sn if n in store.vars]
+  if names:
+    weights = [store.vars[n] for n in names]
+    u_vars = [store.vars[sn[n][0]] for n in names]
+    modes = [sn[n][1] for n in names]
+    wbars = Fn.spectral_norm_batch(weights, u_vars, modes, sn[names[0]][2])
+    for n, wb in zip(names, wbars):
+      store.sn_ready[n] = wb
+  conv = [n for n in store.conv_registry.get(module, {}) if n in store.vars]
+  if conv:
+    eff = [store.sn_ready.get(n, store.vars[n]).detach() for n in conv]
+    w4 = [w if w.dim() == 4 else w.reshape(1, 1, w.shape[0], w.shape[1]) for w in eff]
+    bt_f, bt_b = K.weight_prep_multi(w4, want_fwd=True, want_bwd=torch.is_grad_enabled())
+    for n, f, b in zip(conv, bt_f, bt_b):
+      store.bt_ready[n] = (f, b)
 
 
 # ------------------------------------------------------------------------------------------------
 # linear / conv2d / deconv2d (arch_ops.py:538-592)
 # ------------------------------------------------------------------------------------------------
 def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32):
+  """Runs inside the weight's variable scope: the kernel variable is <scope>/kernel."""
   spec = Fn.ConvSpec(spec_geom, transpose=transpose, slope_in=slope, out_f32=out_f32)
+  store = current_store()
+  wname = store.full_name("kernel")
+  store.conv_registry.setdefault(wname.split("/", 1)[0], {})[wname] = None
   if x.is_meta:
     return torch.empty(spec.out_shape, dtype=F32 if out_f32 else BF16, device="meta")
   gate = x.detach() if slope is not None else None
-  return Fn.gconv(x, w, bias, residual, gate, None, spec, dx_f32)
+  return Fn.gconv(x, w, bias, residual, gate, None, spec, dx_f32, store.bt_ready.pop(wname, None))
 
 
 def linear(inputs, output_size, scope=None, stddev=0.02, bias_start=0.0, use_sn=False,

@@ -86,14 +86,39 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm4) {
   return sm4[0] + sm4[1] + sm4[2] + sm4[3];
 }
 
-// ---- optional HIP-event timing of the dominant kernel families (cg_error.hip) -----------------
-#define CG_PROF_GCONV_MAIN 0   /* gconv_kernel<128,128,64,2,2,true>: fwd / dgrad / deconv / linear */
-#define CG_PROF_GCONV_OTHER 1  /* narrow-N and scalar-gather instantiations */
-#define CG_PROF_GWGRAD_MAIN 2  /* gwgrad_kernel<128,128,true,true> (+ split reduce) */
-#define CG_PROF_GWGRAD_OTHER 3
+// ---- optional HIP-event timing of the convolution kernels (cg_error.hip) -------------------------
+// one family per kernel symbol, so that the numbers line up with `rocprofv3 --kernel-trace --stats`
+enum {
+  CG_PROF_FAST_CONV_128x128 = 0,  // fast_conv_kernel<128, 128, *>
+  CG_PROF_FAST_CONV_64x128,       // fast_conv_kernel<64, 128, *>
+  CG_PROF_FAST_CONV_128x64,       // fast_conv_kernel<128, 64, *>
+  CG_PROF_FAST_CONV_128x32,       // fast_conv_kernel<128, 32, *>
+  CG_PROF_STEM_FWD,               // stem_fwd_kernel<*>
+  CG_PROF_GCONV_GENERIC,          // gconv_kernel<...> (channel counts not a multiple of 64, leaky gates)
+  CG_PROF_FAST_WGRAD_128,         // fast_wgrad_kernel<128, *> (+ split reduce)
+  CG_PROF_FAST_WGRAD_64,          // fast_wgrad_kernel<64, *> (+ split reduce)
+  CG_PROF_STEM_WGRAD,             // stem_wgrad_kernel<*> incl. the narrow-output (adjoint) form
+  CG_PROF_GWGRAD_GENERIC,         // gwgrad_kernel<...>
+  CG_PROF_COUNT
+};
 void cg_prof_begin(int family, double flops, double bytes, hipStream_t st);
 void cg_prof_end(int family, hipStream_t st);
 bool cg_prof_enabled();
+// useful MACs x 2 (structural zeros of a zero-inserted input are not counted) and the minimum bf16
+// HBM traffic 2 * (in + out + weights) bytes of one launch
+void cg_conv_algorithmic_cost(const cgConvGeom* g, double* flops, double* bytes);
+struct CgProfScope {
+  int fam;
+  hipStream_t st;
+  CgProfScope(int family, const cgConvGeom* g, hipStream_t s) : fam(family), st(s) {
+    if (cg_prof_enabled()) {
+      double f, b;
+      cg_conv_algorithmic_cost(g, &f, &b);
+      cg_prof_begin(fam, f, b, st);
+    }
+  }
+  ~CgProfScope() { cg_prof_end(fam, st); }
+};
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

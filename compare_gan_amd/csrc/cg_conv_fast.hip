@@ -912,6 +912,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     a.dNt = make_fastdiv(1);
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles, phases);
+    CgProfScope prof(CG_PROF_FAST_CONV_128x32, g, st);
     if (a.relu_in)
       fast_conv_kernel<128, 32, true><<<grid, 256, 0, st>>>(a);
     else
@@ -924,6 +925,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     a.dNt = make_fastdiv(1);
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles, phases);
+    CgProfScope prof(CG_PROF_FAST_CONV_128x64, g, st);
     if (a.relu_in)
       fast_conv_kernel<128, 64, true><<<grid, 256, 0, st>>>(a);
     else
@@ -936,6 +938,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   if (tiles128 >= 256) {
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles * a.ntiles, phases);
+    CgProfScope prof(CG_PROF_FAST_CONV_128x128, g, st);
     if (a.relu_in)
       fast_conv_kernel<128, 128, true><<<grid, 256, 0, st>>>(a);
     else
@@ -943,6 +946,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   } else {
     a.mtiles = cdiv(a.Mp, 64);
     dim3 grid(a.mtiles * a.ntiles, phases);
+    CgProfScope prof(CG_PROF_FAST_CONV_64x128, g, st);
     if (a.relu_in)
       fast_conv_kernel<64, 128, true><<<grid, 256, 0, st>>>(a);
     else
@@ -986,6 +990,7 @@ void cg_stem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.want_bias = 0; a.rows_per_split = 0;
   a.adjoint_out = 0;
   const int grid = cdiv(a.M, 128);
+  CgProfScope prof(CG_PROF_STEM_FWD, g, st);
   switch (a.KS) {
     case 32: stem_fwd_kernel<32><<<grid, 256, 0, st>>>(a); break;
     case 64: stem_fwd_kernel<64><<<grid, 256, 0, st>>>(a); break;
@@ -1072,6 +1077,7 @@ static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, con
   a.self_gate = 0; a.slope_out = 0.f;
   a.rows_per_split = rps;
   dim3 grid(cdiv(g->Co, 128), splits);
+  CgProfScope prof(CG_PROF_STEM_WGRAD, g, st);
   switch (a.KS) {
     case 32: stem_wgrad_kernel<32><<<grid, 256, 0, st>>>(a); break;
     case 64: stem_wgrad_kernel<64><<<grid, 256, 0, st>>>(a); break;
@@ -1162,6 +1168,7 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     a.bias_out = bias_in_kernel ? wsf + (size_t)splits * KC : nullptr;
   }
   dim3 grid(a.ktiles * a.ntiles, splits);
+  CgProfScope prof(tkc == 128 ? CG_PROF_FAST_WGRAD_128 : CG_PROF_FAST_WGRAD_64, g, st);
   if (tkc == 128) {
     if (a.relu_in)
       fast_wgrad_kernel<128, true><<<grid, 256, 0, st>>>(a);

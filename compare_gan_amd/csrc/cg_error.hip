@@ -24,13 +24,18 @@ struct ProfSlot {
   int64_t launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[CG_PROF_FAMILIES];
+ProfSlot g_prof[CG_PROF_COUNT];
+const char* const g_prof_names[CG_PROF_COUNT] = {
+    "fast_conv_kernel<128, 128, *>", "fast_conv_kernel<64, 128, *>", "fast_conv_kernel<128, 64, *>",
+    "fast_conv_kernel<128, 32, *>",  "stem_fwd_kernel<*>",           "gconv_kernel<...>",
+    "fast_wgrad_kernel<128, *>",     "fast_wgrad_kernel<64, *>",     "stem_wgrad_kernel<*>",
+    "gwgrad_kernel<...>"};
 }  // namespace
 
 bool cg_prof_enabled() { return g_prof_on; }
 
 void cg_prof_begin(int family, double flops, double bytes, hipStream_t st) {
-  if (!g_prof_on || family < 0 || family >= CG_PROF_FAMILIES) return;
+  if (!g_prof_on || family < 0 || family >= CG_PROF_COUNT) return;
   ProfSlot& p = g_prof[family];
   hipEvent_t a, b;
   hipEventCreate(&a);
@@ -43,9 +48,14 @@ void cg_prof_begin(int family, double flops, double bytes, hipStream_t st) {
 }
 
 void cg_prof_end(int family, hipStream_t st) {
-  if (!g_prof_on || family < 0 || family >= CG_PROF_FAMILIES) return;
+  if (!g_prof_on || family < 0 || family >= CG_PROF_COUNT) return;
   ProfSlot& p = g_prof[family];
   if (p.ev.size() >= 2) hipEventRecord(p.ev.back(), st);
+}
+
+extern "C" int cg_prof_family_count(void) { return CG_PROF_COUNT; }
+extern "C" const char* cg_prof_family_name(int family) {
+  return (family >= 0 && family < CG_PROF_COUNT) ? g_prof_names[family] : "";
 }
 
 extern "C" int cg_prof_enable(int on) {
@@ -55,7 +65,7 @@ extern "C" int cg_prof_enable(int on) {
 
 extern "C" int cg_prof_collect(int family, double* total_ms, int64_t* launches, double* flops,
                                double* bytes) {
-  if (family < 0 || family >= CG_PROF_FAMILIES) CG_FAIL(CG_ERR_BAD_ARG, "cg_prof_collect: family");
+  if (family < 0 || family >= CG_PROF_COUNT) CG_FAIL(CG_ERR_BAD_ARG, "cg_prof_collect: family");
   ProfSlot& p = g_prof[family];
   for (size_t i = 0; i + 1 < p.ev.size(); i += 2) {
     hipEventSynchronize(p.ev[i + 1]);
@@ -80,7 +90,7 @@ extern "C" int cg_prof_collect(int family, double* total_ms, int64_t* launches, 
 }
 
 extern "C" int cg_prof_reset(void) {
-  for (int f = 0; f < CG_PROF_FAMILIES; ++f) {
+  for (int f = 0; f < CG_PROF_COUNT; ++f) {
     cg_prof_collect(f, nullptr, nullptr, nullptr, nullptr);
     g_prof[f].total_ms = g_prof[f].total_flops = g_prof[f].total_bytes = 0;
     g_prof[f].launches = 0;

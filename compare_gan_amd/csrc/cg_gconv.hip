@@ -561,9 +561,8 @@ int check_geom(const cgConvGeom* g, const char* who) {
   return CG_OK;
 }
 
-// Useful MACs (structural zeros of the zero-inserted input are not counted) and the minimum
-// bf16 HBM traffic of one launch.
-void algorithmic_cost(const cgConvGeom* g, double* flops, double* bytes) {
+}  // namespace
+void cg_conv_algorithmic_cost(const cgConvGeom* g, double* flops, double* bytes) {
   const double m = (double)g->N * g->Ho * g->Wo;
   double taps = (double)g->kh * g->kw;
   if (g->U > 1) taps /= (double)g->U * g->U;
@@ -571,8 +570,6 @@ void algorithmic_cost(const cgConvGeom* g, double* flops, double* bytes) {
   *bytes = 2.0 * ((double)g->N * g->Hin * g->Win * g->Ci + m * g->Co +
                   (double)g->kh * g->kw * g->Ci * g->Co);
 }
-
-}  // namespace
 
 extern "C" int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,
                               void* bt_fwd, void* bt_bwd, cgStream stream) {
@@ -615,26 +612,14 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
   if (cg_stem_conv_supported(g, in, out, gate_in, slope_in, gate_out, residual)) {
     hipStream_t fst = (hipStream_t)stream;
-    if (cg_prof_enabled()) {
-      double flops, bytes;
-      algorithmic_cost(g, &flops, &bytes);
-      cg_prof_begin(CG_PROF_GCONV_OTHER, flops, bytes, fst);
-    }
     cg_stem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, fst);
-    cg_prof_end(CG_PROF_GCONV_OTHER, fst);
     CG_CHECK_LAUNCH("cg_gconv(stem)");
     return CG_OK;
   }
   if (cg_fast_conv_supported(g, in, gate_in, slope_in)) {
     hipStream_t fst = (hipStream_t)stream;
-    if (cg_prof_enabled()) {
-      double flops, bytes;
-      algorithmic_cost(g, &flops, &bytes);
-      cg_prof_begin(CG_PROF_GCONV_MAIN, flops, bytes, fst);
-    }
     cg_fast_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
                         fst);
-    cg_prof_end(CG_PROF_GCONV_MAIN, fst);
     CG_CHECK_LAUNCH("cg_gconv(fast)");
     return CG_OK;
   }
@@ -660,19 +645,13 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   a.dCi = make_fastdiv(g->Ci); a.dKw = make_fastdiv(g->kw);
   const bool vec = (g->Ci % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
-  const int fam = CG_PROF_GCONV_OTHER;
-  if (cg_prof_enabled()) {
-    double flops, bytes;
-    algorithmic_cost(g, &flops, &bytes);
-    cg_prof_begin(fam, flops, bytes, st);
-  }
+  CgProfScope prof(CG_PROF_GCONV_GENERIC, g, st);
   if (g->Co > 64)
     launch_gconv<128, 128, 2, 2>(a, vec, st);
   else if (g->Co > 32)
     launch_gconv<128, 64, 2, 2>(a, vec, st);
   else
     launch_gconv<128, 32, 4, 1>(a, vec, st);
-  cg_prof_end(fam, st);
   CG_CHECK_LAUNCH("cg_gconv");
   return CG_OK;
 }
@@ -734,23 +713,12 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
             cg_gwgrad_workspace_bytes(g));
   if (cg_stem_wgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
-    if (cg_prof_enabled()) {
-      double flops, bytes;
-      algorithmic_cost(g, &flops, &bytes);
-      cg_prof_begin(CG_PROF_GWGRAD_OTHER, flops, bytes, fst);
-    }
     cg_stem_wgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, ws, fst);
-    cg_prof_end(CG_PROF_GWGRAD_OTHER, fst);
     CG_CHECK_LAUNCH("cg_gwgrad(stem)");
     return CG_OK;
   }
   if (cg_narrow_wgrad_supported(g, gate_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
-    if (cg_prof_enabled()) {
-      double flops, bytes;
-      algorithmic_cost(g, &flops, &bytes);
-      cg_prof_begin(CG_PROF_GWGRAD_OTHER, flops, bytes, fst);
-    }
     cg_narrow_wgrad_launch(g, in, dy, dw, accumulate, ws, fst);
     CG_CHECK_LAUNCH("cg_gwgrad(narrow)");
     int rc2 = CG_OK;
@@ -758,18 +726,11 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
       if (accumulate) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gwgrad: accumulate with dbias on a narrow conv");
       rc2 = cg_colsum(dy, (int64_t)g->N * g->Ho * g->Wo, g->Co, dbias, ws, ws_bytes, stream);
     }
-    cg_prof_end(CG_PROF_GWGRAD_OTHER, fst);
     return rc2;
   }
   if (cg_fast_wgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
-    if (cg_prof_enabled()) {
-      double flops, bytes;
-      algorithmic_cost(g, &flops, &bytes);
-      cg_prof_begin(CG_PROF_GWGRAD_MAIN, flops, bytes, fst);
-    }
     cg_fast_wgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, ws, fst);
-    cg_prof_end(CG_PROF_GWGRAD_MAIN, fst);
     CG_CHECK_LAUNCH("cg_gwgrad(fast)");
     return CG_OK;
   }
@@ -799,12 +760,7 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(K, tk), cdiv(g->Co, tn), splits);
-  const int fam = CG_PROF_GWGRAD_OTHER;
-  if (cg_prof_enabled()) {
-    double flops, bytes;
-    algorithmic_cost(g, &flops, &bytes);
-    cg_prof_begin(fam, flops, bytes, st);
-  }
+  CgProfScope prof(CG_PROF_GWGRAD_GENERIC, g, st);
   const bool vx = (g->Ci % 8) == 0, vy = (g->Co % 8) == 0;
 #define CG_WG(TK_, TN_)                                                        \
   do {                                                                         \
@@ -829,6 +785,5 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
       CG_CHECK_LAUNCH("cg_gwgrad(reduce bias)");
     }
   }
-  cg_prof_end(fam, st);
   return CG_OK;
 }

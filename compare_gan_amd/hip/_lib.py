@@ -28,6 +28,24 @@ class AdamEntry(ctypes.Structure):
                 ("n", c_i64), ("chunk_begin", c_i64)]
 
 
+class SNItem(ctypes.Structure):
+    """Mirror of cgSNItem."""
+    _fields_ = [("w", vp), ("u", vp), ("u_out", vp), ("v_out", vp), ("sigma", vp), ("wbar", vp),
+                ("ws", vp), ("K", ctypes.c_int32), ("Co", ctypes.c_int32), ("mode", ctypes.c_int32)]
+
+
+class SNBwdItem(ctypes.Structure):
+    """Mirror of cgSNBwdItem."""
+    _fields_ = [("dwbar", vp), ("w", vp), ("a_k", vp), ("b_co", vp), ("sigma", vp), ("dw", vp),
+                ("ws", vp), ("K", ctypes.c_int32), ("Co", ctypes.c_int32)]
+
+
+class PrepItem(ctypes.Structure):
+    """Mirror of cgPrepItem."""
+    _fields_ = [("w", vp), ("bt_fwd", vp), ("bt_bwd", vp), ("T", ctypes.c_int32),
+                ("Ci", ctypes.c_int32), ("Co", ctypes.c_int32)]
+
+
 ADAM_CHUNK = 16384
 GP = ctypes.POINTER(ConvGeom)
 
@@ -35,6 +53,8 @@ GP = ctypes.POINTER(ConvGeom)
 SIGNATURES = {
     "cg_abi_version": (c_int, []),
     "cg_last_error": (ctypes.c_char_p, []),
+    "cg_prof_family_count": (c_int, []),
+    "cg_prof_family_name": (ctypes.c_char_p, [c_int]),
     "cg_prof_enable": (c_int, [c_int]),
     "cg_prof_reset": (c_int, []),
     "cg_prof_collect": (c_int, [c_int, vp, vp, vp, vp]),
@@ -46,6 +66,11 @@ SIGNATURES = {
     "cg_spectral_norm": (c_int, [vp, c_int, c_int, c_int, c_f32, vp, vp, vp, vp, vp, vp, c_sz, vp]),
     "cg_sn_backward_workspace_bytes": (c_sz, [c_int, c_int]),
     "cg_sn_backward": (c_int, [vp, vp, c_int, c_int, vp, vp, vp, vp, vp, c_sz, vp]),
+    "cg_spectral_norm_multi_workspace_floats": (c_sz, [c_int, c_int]),
+    "cg_spectral_norm_multi": (c_int, [vp, c_int, c_f32, vp]),
+    "cg_sn_backward_multi_workspace_floats": (c_sz, [c_int, c_int]),
+    "cg_sn_backward_multi": (c_int, [vp, c_int, vp]),
+    "cg_weight_prep_multi": (c_int, [vp, c_int, vp]),
     "cg_scale_f32": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
     "cg_bn_stats_workspace_bytes": (c_sz, [c_i64, c_int]),
     "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, vp, c_f32, vp, c_sz, vp]),
@@ -144,7 +169,8 @@ class _TracingLib(object):
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if not name.startswith("cg_") or name in ("cg_last_error", "cg_abi_version"):
+        if not name.startswith("cg_") or name in ("cg_last_error", "cg_abi_version",
+                                                  "cg_prof_family_name", "cg_prof_family_count"):
             return fn
 
         def traced(*args):

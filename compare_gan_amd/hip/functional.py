@@ -50,13 +50,18 @@ class ConvSpec(object):
     return (g.N, g.Hin, g.Win, g.Ci) if self.transpose else (g.N, g.Ho, g.Wo, g.Co)
 
 
-def _run_gconv(spec, x, w, bias, gate_in, gate_out, residual):
+def _run_gconv(spec, x, w, bias, gate_in, gate_out, residual, bt_pair=None):
+  """bt_pair: (bt_fwd, bt_bwd) operand images prepared by the module-level batch, or None."""
   g = spec.geom
   if spec.transpose:
-    _, bt = K.weight_prep(w, want_fwd=False, want_bwd=True)
+    bt = bt_pair[1] if bt_pair is not None else None
+    if bt is None:
+      _, bt = K.weight_prep(w, want_fwd=False, want_bwd=True)
     geom = K.geom_adjoint(g)
   else:
-    bt, _ = K.weight_prep(w, want_fwd=True, want_bwd=False)
+    bt = bt_pair[0] if bt_pair is not None else None
+    if bt is None:
+      bt, _ = K.weight_prep(w, want_fwd=True, want_bwd=False)
     geom = g
   return K.gconv(geom, x, bt, bias=bias,
                  gate_in=gate_in if spec.slope_in is not None else None,
@@ -87,11 +92,14 @@ class GConvFn(torch.autograd.Function):
   piecewise constant); gate_in may be x itself (y = conv(lrelu(x)))."""
 
   @staticmethod
-  def forward(ctx, x, w, bias, residual, gate_in, gate_out, spec, dx_f32):
+  def forward(ctx, x, w, bias, residual, gate_in, gate_out, spec, dx_f32, bt_pair=None):
     x = x.contiguous()
-    y = _run_gconv(spec, x, w, bias, gate_in, gate_out, residual)
+    y = _run_gconv(spec, x, w, bias, gate_in, gate_out, residual, bt_pair)
     ctx.spec, ctx.dx_f32 = spec, dx_f32
     ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+    # the operand images of THIS call travel with the node: a later call of the same module
+    # (gradient penalty, next sub-step) prepares new ones
+    ctx.bt_pair = bt_pair
     ctx.save_for_backward(x, w, gate_in, gate_out)
     return y
 
@@ -108,7 +116,7 @@ class GConvFn(torch.autograd.Function):
       dr = dy16
     if need_x:
       aspec = spec.adjoint(out_f32=ctx.dx_f32)
-      dx = GConvFn.apply(dy16, w, None, None, gate_out, gate_in, aspec, False)
+      dx = GConvFn.apply(dy16, w, None, None, gate_out, gate_in, aspec, False, ctx.bt_pair)
     if need_w or (need_b and ctx.has_bias):
       want_b = bool(need_b and ctx.has_bias)
       if torch.is_grad_enabled():
@@ -117,7 +125,7 @@ class GConvFn(torch.autograd.Function):
           db = K.colsum(_gated(dy16, gate_out, spec.slope_out).reshape(-1, dy16.shape[-1]))
       else:
         dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
-    return dx, dw, db, dr, None, None, None, None
+    return dx, dw, db, dr, None, None, None, None, None
 
 
 def _gated(t, gate, slope):
@@ -170,8 +178,9 @@ class GWgradFn(torch.autograd.Function):
     return dx, ddy, None, None, None
 
 
-def gconv(x, w, bias=None, residual=None, gate_in=None, gate_out=None, spec=None, dx_f32=False):
-  return GConvFn.apply(x, w, bias, residual, gate_in, gate_out, spec, dx_f32)
+def gconv(x, w, bias=None, residual=None, gate_in=None, gate_out=None, spec=None, dx_f32=False,
+          bt_pair=None):
+  return GConvFn.apply(x, w, bias, residual, gate_in, gate_out, spec, dx_f32, bt_pair)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -203,6 +212,41 @@ class SpectralNormFn(torch.autograd.Function):
 
 def spectral_norm(w, u_var, mode, eps):
   return SpectralNormFn.apply(w, u_var, mode, eps)
+
+
+class SpectralNormBatchFn(torch.autograd.Function):
+  """SpectralNormFn for ALL spectrally-normalised weights of a network call at once: five launches
+  forward (two mat-vec passes, their normalisations, the 1/sigma scaling), two backward."""
+
+  @staticmethod
+  def forward(ctx, u_vars, modes, eps, *weights):
+    w2 = [w.reshape(-1, w.shape[-1]) for w in weights]
+    u_news, vs, sigmas, wbars = K.spectral_norm_multi(w2, [u.view(-1) for u in u_vars], modes, eps)
+    ctx.modes = list(modes)
+    ctx.n = len(weights)
+    ctx.save_for_backward(*(w2 + u_news + vs + sigmas))
+    return tuple(wb.view(w.shape) for wb, w in zip(wbars, weights))
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, *dwbars):
+    n = ctx.n
+    saved = ctx.saved_tensors
+    w2, u_news, vs, sigmas = saved[:n], saved[n:2 * n], saved[2 * n:3 * n], saved[3 * n:4 * n]
+    idx = [i for i in range(n) if dwbars[i] is not None and ctx.needs_input_grad[3 + i]]
+    out = [None] * n
+    if idx:
+      a_ks = [u_news[i] if ctx.modes[i] == 0 else vs[i] for i in idx]
+      b_cos = [vs[i] if ctx.modes[i] == 0 else u_news[i] for i in idx]
+      dws = K.sn_backward_multi([dwbars[i].contiguous().reshape(w2[i].shape) for i in idx],
+                                [w2[i] for i in idx], a_ks, b_cos, [sigmas[i] for i in idx])
+      for i, dw in zip(idx, dws):
+        out[i] = dw.reshape(dwbars[i].shape)
+    return (None, None, None) + tuple(out)
+
+
+def spectral_norm_batch(weights, u_vars, modes, eps):
+  return SpectralNormBatchFn.apply(tuple(u_vars), tuple(modes), eps, *weights)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -172,6 +172,104 @@ def sn_backward(dwbar2d, w2d, a_k, b_co, sigma):
     return dw
 
 
+def _carve(flat, sizes):
+    """Views into one flat buffer (one allocation per network call instead of one per tensor)."""
+    out, off = [], 0
+    for n in sizes:
+        out.append(flat[off:off + n])
+        off += n
+    return out
+
+
+def spectral_norm_multi(weights2d, us, modes, eps=1e-12, want_wbar=True):
+    """One power-iteration round for a list of [K, Co] weights; every u is updated IN PLACE.
+    Returns (u_news, vs, sigmas [each a 2-vector: sigma, 1/sigma], wbars or None)."""
+    n = len(weights2d)
+    dev = weights2d[0].device
+    vec_sizes, ws_sizes, wb_sizes = [], [], []
+    for w, u, m in zip(weights2d, us, modes):
+        _req(w, F32, "w")
+        _req(u, F32, "u")
+        K, Co = w.shape
+        lu, lv = (K, Co) if m == 0 else (Co, K)
+        if u.numel() != lu:
+            raise ValueError("u has %d elements for mode %d of a [%d,%d] matrix" % (u.numel(), m, K, Co))
+        vec_sizes += [lu, lv, 2]
+        ws_sizes.append(int(lib().cg_spectral_norm_multi_workspace_floats(K, Co)))
+        wb_sizes.append(K * Co)
+    vecs = _carve(torch.empty(sum(vec_sizes), dtype=F32, device=dev), vec_sizes)
+    wss = _carve(torch.empty(sum(ws_sizes), dtype=F32, device=dev), ws_sizes)
+    wbars = _carve(torch.empty(sum(wb_sizes), dtype=F32, device=dev), wb_sizes) if want_wbar else None
+    items = (_lib.SNItem * n)()
+    u_news, vs, sigmas = [], [], []
+    for i, (w, u, m) in enumerate(zip(weights2d, us, modes)):
+        it = items[i]
+        u_new, v, sig = vecs[3 * i], vecs[3 * i + 1], vecs[3 * i + 2]
+        it.w, it.u, it.u_out, it.v_out, it.sigma = (w.data_ptr(), u.data_ptr(), u_new.data_ptr(),
+                                                    v.data_ptr(), sig.data_ptr())
+        it.wbar = wbars[i].data_ptr() if want_wbar else None
+        it.ws = wss[i].data_ptr()
+        it.K, it.Co, it.mode = w.shape[0], w.shape[1], m
+        u_news.append(u_new); vs.append(v); sigmas.append(sig)
+    check(lib().cg_spectral_norm_multi(ctypes.cast(items, ctypes.c_void_p), n, float(eps),
+                                       _stream()), "cg_spectral_norm_multi")
+    if want_wbar:
+        wbars = [wb.view(w.shape) for wb, w in zip(wbars, weights2d)]
+    return u_news, vs, sigmas, wbars
+
+
+def sn_backward_multi(dwbars, weights2d, a_ks, b_cos, sigmas):
+    """dw_i = (dwbar_i - <dwbar_i, w_i>/sigma_i a_i b_i^T) / sigma_i for a list of weights."""
+    n = len(dwbars)
+    dev = weights2d[0].device
+    sizes = [w.numel() for w in weights2d]
+    ws_sizes = [int(lib().cg_sn_backward_multi_workspace_floats(w.shape[0], w.shape[1]))
+                for w in weights2d]
+    dws = _carve(torch.empty(sum(sizes), dtype=F32, device=dev), sizes)
+    wss = _carve(torch.empty(sum(ws_sizes), dtype=F32, device=dev), ws_sizes)
+    items = (_lib.SNBwdItem * n)()
+    for i in range(n):
+        _req(dwbars[i], F32, "dwbar")
+        it = items[i]
+        it.dwbar, it.w, it.a_k, it.b_co = (dwbars[i].data_ptr(), weights2d[i].data_ptr(),
+                                           a_ks[i].data_ptr(), b_cos[i].data_ptr())
+        it.sigma, it.dw, it.ws = sigmas[i].data_ptr(), dws[i].data_ptr(), wss[i].data_ptr()
+        it.K, it.Co = weights2d[i].shape
+    check(lib().cg_sn_backward_multi(ctypes.cast(items, ctypes.c_void_p), n, _stream()),
+          "cg_sn_backward_multi")
+    return [d.view(w.shape) for d, w in zip(dws, weights2d)]
+
+
+def weight_prep_multi(weights4d, want_fwd=True, want_bwd=False):
+    """fp32 [kh,kw,Ci,Co] weights -> lists of (bt_fwd [Co,Kp], bt_bwd [Ci,Kbp]) bf16 images."""
+    n = len(weights4d)
+    dev = weights4d[0].device
+    f_sizes, b_sizes = [], []
+    for w in weights4d:
+        _req(w, F32, "w")
+        kh, kw, Ci, Co = w.shape
+        f_sizes.append(Co * ((kh * kw * Ci + 7) // 8 * 8) if want_fwd else 0)
+        b_sizes.append(Ci * ((kh * kw * Co + 7) // 8 * 8) if want_bwd else 0)
+    # every image starts 16-byte aligned (sizes are multiples of 8 bf16 elements)
+    fbuf = _carve(torch.empty(sum(f_sizes), dtype=BF16, device=dev), f_sizes)
+    bbuf = _carve(torch.empty(sum(b_sizes), dtype=BF16, device=dev), b_sizes)
+    items = (_lib.PrepItem * n)()
+    bt_f, bt_b = [], []
+    for i, w in enumerate(weights4d):
+        kh, kw, Ci, Co = w.shape
+        it = items[i]
+        it.w = w.data_ptr()
+        it.T, it.Ci, it.Co = kh * kw, Ci, Co
+        f = fbuf[i].view(Co, -1) if want_fwd else None
+        b = bbuf[i].view(Ci, -1) if want_bwd else None
+        it.bt_fwd = f.data_ptr() if f is not None else None
+        it.bt_bwd = b.data_ptr() if b is not None else None
+        bt_f.append(f); bt_b.append(b)
+    check(lib().cg_weight_prep_multi(ctypes.cast(items, ctypes.c_void_p), n, _stream()),
+          "cg_weight_prep_multi")
+    return bt_f, bt_b
+
+
 def scale_f32(x, scale_dev=None, scale_host=1.0):
     _req(x, F32, "x")
     out = torch.empty_like(x)
@@ -712,9 +810,6 @@ def pool2d(x, k, s, p, kind, Ho, Wo):
 # ------------------------------------------------------------------------------------------------
 # kernel-family timing (bench.py roofline leg)
 # ------------------------------------------------------------------------------------------------
-PROF_FAMILIES = ["gconv_main", "gconv_other", "gwgrad_main", "gwgrad_other"]
-
-
 def prof_enable(on):
     check(lib().cg_prof_enable(int(on)), "cg_prof_enable")
 
@@ -724,9 +819,10 @@ def prof_reset():
 
 
 def prof_collect():
-    """{family: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
+    """{kernel family: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
     out = {}
-    for i, name in enumerate(PROF_FAMILIES):
+    for i in range(lib().cg_prof_family_count()):
+        name = lib().cg_prof_family_name(i).decode()
         ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         n = ctypes.c_int64()
         check(lib().cg_prof_collect(i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl),

@@ -41,13 +41,14 @@ int cg_abi_version(void);
 /* Human-readable description of the last error on this thread ("" if none). */
 const char* cg_last_error(void);
 
-/* Optional timing of the convolution kernel families with HIP events recorded on the launch
- * stream (bench.py's roofline measurement).  Families: 0 gconv main tile (128x128, vector
- * gather), 1 other gconv tiles, 2 gwgrad main tile, 3 other gwgrad tiles.  While enabled every
- * launch of a family is bracketed by an event pair; cg_prof_collect synchronises on them and
- * returns the accumulated kernel time, launch count and ALGORITHMIC flops / bytes (useful MACs x 2;
- * minimum bf16 traffic 2*(in + out + weights) bytes).  Not capturable into a hipGraph. */
-#define CG_PROF_FAMILIES 4
+/* Optional timing of the convolution kernels with HIP events recorded on the launch stream
+ * (bench.py's roofline measurement).  One family per kernel symbol (cg_prof_family_name), so the
+ * figures line up with `rocprofv3 --kernel-trace --stats`.  While enabled every launch is bracketed
+ * by an event pair; cg_prof_collect synchronises on them and returns the accumulated kernel time,
+ * launch count and ALGORITHMIC flops / bytes (useful MACs x 2; minimum bf16 traffic
+ * 2*(in + out + weights) bytes).  Not capturable into a hipGraph. */
+int cg_prof_family_count(void);
+const char* cg_prof_family_name(int family);
 int cg_prof_enable(int on);
 int cg_prof_reset(void);
 int cg_prof_collect(int family, double* total_ms, int64_t* launches, double* flops, double* bytes);
@@ -132,6 +133,46 @@ size_t cg_sn_backward_workspace_bytes(int K, int Co);
 int cg_sn_backward(const float* dwbar, const float* w, int K, int Co, const float* a_k,
                    const float* b_co, const float* sigma, float* dw, void* ws, size_t ws_bytes,
                    cgStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-tensor forms: every spectrally-normalised weight of a network call in five launches
+ * (instead of five per weight), the backward of all of them in two, and the MFMA operand images of
+ * all convolution / linear weights in two.  `items` is a HOST array; the per-tensor device pointers
+ * travel by value in the kernel arguments (chunks of CG_MULTI_MAX), so nothing is uploaded and the
+ * launches stay hipGraph-capturable although gradient tensors move between calls.
+ * ------------------------------------------------------------------------------------------ */
+#define CG_MULTI_MAX 32
+typedef struct {
+  const float* w;   /* [K, Co] fp32 */
+  float* u;         /* persisted power-iteration vector, updated in place ([K] mode 0, [Co] mode 1) */
+  float* u_out;     /* per-call copy of the updated u (kept for the backward) */
+  float* v_out;     /* the other singular-vector estimate ([Co] mode 0, [K] mode 1) */
+  float* sigma;     /* [2]: sigma, 1 / sigma */
+  float* wbar;      /* [K, Co] w / sigma, or NULL */
+  float* ws;        /* >= cg_spectral_norm_multi_workspace_floats(K, Co) floats */
+  int32_t K, Co, mode;
+} cgSNItem;
+size_t cg_spectral_norm_multi_workspace_floats(int K, int Co);
+int cg_spectral_norm_multi(const cgSNItem* items_host, int n, float eps, cgStream stream);
+typedef struct {
+  const float* dwbar; /* gradient w.r.t. w / sigma */
+  const float* w;
+  const float* a_k;   /* [K]  (u' for mode 0, v for mode 1) */
+  const float* b_co;  /* [Co] (v for mode 0, u' for mode 1) */
+  const float* sigma; /* [2] */
+  float* dw;          /* may alias dwbar */
+  float* ws;          /* >= cg_sn_backward_multi_workspace_floats(K, Co) floats */
+  int32_t K, Co;
+} cgSNBwdItem;
+size_t cg_sn_backward_multi_workspace_floats(int K, int Co);
+int cg_sn_backward_multi(const cgSNBwdItem* items_host, int n, cgStream stream);
+typedef struct {
+  const float* w;  /* [T, Ci, Co] fp32 (T = kh*kw) */
+  void* bt_fwd;    /* [Co][Kp] bf16 or NULL  (layouts of cg_weight_prep) */
+  void* bt_bwd;    /* [Ci][Kbp] bf16 or NULL */
+  int32_t T, Ci, Co;
+} cgPrepItem;
+int cg_weight_prep_multi(const cgPrepItem* items_host, int n, cgStream stream);
 
 /* out = x * (*scale_dev) * scale_host on fp32 (w_bar = w * (1/sigma), arch_ops.py:531; also loss
  * gradient scaling).  scale_dev may be NULL (= 1). out may alias x. */
