@@ -128,7 +128,7 @@ inline int stats_splits(int64_t rows, int C) {
   const int64_t maxs = rows / 32 > 0 ? rows / 32 : 1;
   if (s > maxs) s = (int)maxs;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > 512) s = 512;
   return s;
 }
 

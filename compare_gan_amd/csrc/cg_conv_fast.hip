@@ -793,17 +793,26 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
   if (a.want_bias && tid < 128 && c0 + tid < a.Co) outp[(int64_t)a.K * a.Co + c0 + tid] = bias_acc;
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_z part[z * stride + i]
+// out[i] = (accumulate ? out[i] : 0) + sum_z part[z * stride + i]; block = 32 outputs x 8 split lanes
 __global__ __launch_bounds__(256) void split_reduce_strided_kernel(const float* __restrict__ part,
                                                                    int splits, int64_t stride,
                                                                    int64_t n,
                                                                    float* __restrict__ out,
                                                                    int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float sm[8][33];
+  const int il = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + il;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * stride + i];
-  out[i] = accumulate ? out[i] + s : s;
+  if (i < n)
+    for (int z = zl; z < splits; z += 8) s += part[(int64_t)z * stride + i];
+  sm[zl][il] = s;
+  __syncthreads();
+  if (zl == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += sm[r][il];
+    out[i] = accumulate ? out[i] + t : t;
+  }
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i], 4 floats per thread
@@ -1085,10 +1094,10 @@ static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, con
     default: stem_wgrad_kernel<128><<<grid, 256, 0, st>>>(a); break;
   }
   const int64_t KC = (int64_t)a.K * g->Co, stride = KC + g->Co;
-  split_reduce_strided_kernel<<<cdiv(KC, 256), 256, 0, st>>>((const float*)ws, splits, stride, KC,
-                                                             dw, accumulate);
+  split_reduce_strided_kernel<<<cdiv(KC, 32), 256, 0, st>>>((const float*)ws, splits, stride, KC,
+                                                            dw, accumulate);
   if (dbias)
-    split_reduce_strided_kernel<<<cdiv(g->Co, 256), 256, 0, st>>>((const float*)ws + KC, splits,
+    split_reduce_strided_kernel<<<cdiv(g->Co, 32), 256, 0, st>>>((const float*)ws + KC, splits,
                                                                   stride, g->Co, dbias,
                                                                   accumulate);
 }
