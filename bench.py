@@ -113,9 +113,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = os.environ.get("CGAMD_FORCE_DP", "") == "1"   # exercise the RCCL path on 1 GPU
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from compare_gan_amd import datasets, gin, runner_lib
@@ -138,8 +142,22 @@ def main():
         images, labels = next(batches)
         pool.append((torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev)))
 
-    use_graph = (not args.no_graph) and world == 1
-    step_fn = gan.capture_train_step() if use_graph else gan.train_step
+    use_graph = not args.no_graph
+    step_fn = gan.train_step
+    if use_graph:
+        # the whole step -- including the RCCL gradient all-reduces under data parallelism -- is
+        # replayed from one hipGraph; if the capture of the collective path is refused by the
+        # runtime, fall back to eager launches rather than lose the measurement
+        try:
+            step_fn = gan.capture_train_step()
+        except Exception as e:  # pylint: disable=broad-except
+            if world == 1 and not force_dp:
+                raise
+            sys.stderr.write("hipGraph capture failed under data parallelism (%r); running "
+                             "eagerly\n" % (e,))
+            torch.cuda.synchronize()
+            use_graph = False
+            step_fn = gan.train_step
 
     def sync_all():
         torch.cuda.synchronize()
@@ -237,11 +255,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_guarded(args.config, bsz, args.cpu_budget_s)
 
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_dp:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio; flush it so that the JSON line is the LAST
+    # line on stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # pylint: disable=broad-except
+        pass
+    if rank == 0:
+        sys.stdout.write(json.dumps(result) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -237,6 +237,23 @@ __global__ __launch_bounds__(256) void prep_bwd_multi_kernel(PrepChunk c) {
   }
 }
 
+struct FlatChunk {
+  const float* src[MAXT];
+  int64_t off[MAXT];   // element offset of the tensor inside the flat buffer
+  int64_t n[MAXT];
+  int blk[MAXT + 1];
+  int cnt;
+};
+
+__global__ __launch_bounds__(256) void flatten_multi_kernel(FlatChunk c, float* __restrict__ flat) {
+  const int it = find_item(c.blk, c.cnt, blockIdx.x);
+  const int64_t base = (int64_t)(blockIdx.x - c.blk[it]) * EW_CHUNK;
+  const int64_t end = min(c.n[it], base + EW_CHUNK);
+  const float* __restrict__ s = c.src[it];
+  float* __restrict__ d = flat + c.off[it];
+  for (int64_t i = base + threadIdx.x; i < end; i += 256) d[i] = s[i];
+}
+
 inline int sn_splits(int K, int Co) {
   const int ct = cdiv(Co, 64);
   int s = cdiv(128, ct);
@@ -353,6 +370,33 @@ extern "C" int cg_weight_prep_multi(const cgPrepItem* items, int n, cgStream str
     if (bf > 0) prep_fwd_multi_kernel<<<bf, 256, 0, st>>>(c);
     if (bb > 0) prep_bwd_multi_kernel<<<bb, 256, 0, st>>>(c);
     CG_CHECK_LAUNCH("cg_weight_prep_multi");
+  }
+  return CG_OK;
+}
+
+extern "C" int cg_flatten_multi(const float* const* srcs, const int64_t* sizes, int n, float* flat,
+                                cgStream stream) {
+  if (!srcs || !sizes || !flat || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_flatten_multi: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t off = 0;
+  for (int i0 = 0; i0 < n; i0 += MAXT) {
+    const int cnt = (n - i0) < MAXT ? (n - i0) : MAXT;
+    FlatChunk c;
+    c.cnt = cnt;
+    int blk = 0;
+    for (int i = 0; i < cnt; ++i) {
+      if (!srcs[i0 + i] || sizes[i0 + i] <= 0)
+        CG_FAIL(CG_ERR_BAD_ARG, "cg_flatten_multi: bad item %d", i0 + i);
+      c.src[i] = srcs[i0 + i];
+      c.off[i] = off;
+      c.n[i] = sizes[i0 + i];
+      off += sizes[i0 + i];
+      c.blk[i] = blk;
+      blk += cdiv(c.n[i], EW_CHUNK);
+    }
+    c.blk[cnt] = blk;
+    flatten_multi_kernel<<<blk, 256, 0, st>>>(c, flat);
+    CG_CHECK_LAUNCH("cg_flatten_multi");
   }
   return CG_OK;
 }

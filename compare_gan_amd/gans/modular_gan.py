@@ -110,7 +110,7 @@ class _OptimizerState(object):
       grads[i] = g.contiguous()
     world = tpu_ops.num_replicas()
     scale = 1.0
-    if world > 1:
+    if world > 1 or tpu_ops.force_data_parallel():
       if self.flat is None:
         self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32,
                                 device=self.device)
@@ -119,10 +119,7 @@ class _OptimizerState(object):
         for g in grads:
           self.flat_views.append(self.flat[off:off + g.numel()].view(g.shape))
           off += g.numel()
-        self.gather_table = K.AdamTable([p.detach() for p in self.params], grads, self.m, self.v,
-                                        self.ema)
-      self.gather_table.set_grads(grads)
-      self.gather_table.gather(self.flat)
+      K.flatten_multi(grads, self.flat)          # one bucket per network
       tpu_ops.cross_replica_sum_(self.flat)      # CrossShardOptimizer: gradient mean
       grads = self.flat_views
       scale = 1.0 / world
@@ -433,9 +430,6 @@ class ModularGAN(AbstractGAN):
     hipGraph: small configs are launch-bound, replay removes the per-launch
     host cost.  Inputs are copied into static device buffers before each replay.  Returns
     run(images, labels) -> same dict as train_step."""
-    if tpu_ops.num_replicas() > 1:
-      raise NotImplementedError("graph capture with RCCL collectives is not enabled; use "
-                                "train_step() under data parallelism")
     nsub = self._disc_iters + 1
     shape = (nsub * self.batch_size,) + tuple(self._dataset.image_shape)
     self._static_images = torch.zeros(shape, dtype=torch.float32, device=self.device)

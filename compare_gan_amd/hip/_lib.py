@@ -71,6 +71,7 @@ SIGNATURES = {
     "cg_sn_backward_multi_workspace_floats": (c_sz, [c_int, c_int]),
     "cg_sn_backward_multi": (c_int, [vp, c_int, vp]),
     "cg_weight_prep_multi": (c_int, [vp, c_int, vp]),
+    "cg_flatten_multi": (c_int, [vp, vp, c_int, vp, vp]),
     "cg_scale_f32": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
     "cg_bn_stats_workspace_bytes": (c_sz, [c_i64, c_int]),
     "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, vp, c_f32, vp, c_sz, vp]),

@@ -270,6 +270,26 @@ def weight_prep_multi(weights4d, want_fwd=True, want_bwd=False):
     return bt_f, bt_b
 
 
+def flatten_multi(tensors, flat):
+    """Copies a list of fp32 tensors back to back into `flat` (one launch per 32 tensors)."""
+    _req(flat, F32, "flat")
+    n = len(tensors)
+    ptrs = (ctypes.c_void_p * n)()
+    sizes = (ctypes.c_int64 * n)()
+    total = 0
+    for i, t in enumerate(tensors):
+        _req(t, F32, "tensor")
+        ptrs[i] = t.data_ptr()
+        sizes[i] = t.numel()
+        total += t.numel()
+    if total != flat.numel():
+        raise ValueError("flat has %d elements, the tensors %d" % (flat.numel(), total))
+    check(lib().cg_flatten_multi(ctypes.cast(ptrs, ctypes.c_void_p),
+                                 ctypes.cast(sizes, ctypes.c_void_p), n, _p(flat), _stream()),
+          "cg_flatten_multi")
+    return flat
+
+
 def scale_f32(x, scale_dev=None, scale_host=1.0):
     _req(x, F32, "x")
     out = torch.empty_like(x)

@@ -21,6 +21,13 @@ def replica_id():
   return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def force_data_parallel():
+  """Debug switch (CGAMD_FORCE_DP=1): run the bucket + all-reduce path even on one replica, so the
+  collective path can be exercised (and captured) on a single-GPU box."""
+  import os
+  return os.environ.get("CGAMD_FORCE_DP", "") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def enable_cross_replica(enabled=True):
   """The analogue of 'running inside a TPU context' (arch_ops.py:258-263)."""
   _STATE["enabled"] = bool(enabled)
@@ -51,7 +58,7 @@ def _group(group_size):
 
 def cross_replica_sum_(tensor, group_size=None):
   """In-place all-reduce SUM (the one primitive the reference builds everything from)."""
-  if num_replicas() == 1 or group_size == 1:
+  if (num_replicas() == 1 and not force_data_parallel()) or group_size == 1:
     return tensor, 1
   group, n = _group(group_size)
   dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)

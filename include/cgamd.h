@@ -174,6 +174,13 @@ typedef struct {
 } cgPrepItem;
 int cg_weight_prep_multi(const cgPrepItem* items_host, int n, cgStream stream);
 
+/* Gradient bucket for the data-parallel all-reduce (CrossShardOptimizer, modular_gan.py:606-616):
+ * copies n fp32 tensors (host arrays of device pointers / element counts) back to back into
+ * `flat`.  Pointers by value in the kernel arguments: capturable although the gradient tensors
+ * move from step to step. */
+int cg_flatten_multi(const float* const* srcs_host, const int64_t* sizes_host, int n, float* flat,
+                     cgStream stream);
+
 /* out = x * (*scale_dev) * scale_host on fp32 (w_bar = w * (1/sigma), arch_ops.py:531; also loss
  * gradient scaling).  scale_dev may be NULL (= 1). out may alias x. */
 int cg_scale_f32(const float* x, const float* scale_dev, float scale_host, float* out, int64_t n,
