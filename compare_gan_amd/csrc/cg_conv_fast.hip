@@ -24,6 +24,8 @@
 //    row-major LDS image, so the DMA staging is shared with the forward kernel.
 #include "cg_conv_fast.h"
 
+#include <stdlib.h>
+
 #define CG_FAST_BIAS_SPLITS 64
 
 namespace {
@@ -73,7 +75,15 @@ struct FastConvArgs {
   FastDiv dWp, dHp, dNt;
 };
 
-template <int BM, int BN, bool RELU>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS = LDS ring depth: NS - 1 K-slices are in flight while one is being consumed.  NS = 2 keeps two
+// workgroups per CU (the second hides the load latency); NS = 4 is for grids of about one workgroup
+// per CU, where only a deeper ring can hide it.
+template <int BM, int BN, bool RELU, int NS>
 __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   constexpr int WN = BN >= 128 ? 2 : 1;   // waves along the channel dimension
   constexpr int WM = 4 / WN;
@@ -82,7 +92,9 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   constexpr int TM = BM / WM / 32;        // 32-pixel MFMA tiles per wave
   constexpr int TN = BN / WN / 32;        // 32-channel MFMA tiles per wave
   constexpr int A_ELEMS = BM * 64, B_ELEMS = BN * 64;
-  __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (A_ELEMS + B_ELEMS)];
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[NS * (A_ELEMS + B_ELEMS)];
+  constexpr int LOADS = AJ + BJ;   // LDS-DMA instructions per thread per stage
+  constexpr int D = NS - 1;        // prefetch distance
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -187,15 +199,22 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   const int arow0 = (wm * (BM / WM) + frow) * 64;
   const int brow0 = (wn * (BN / WN) + frow) * 64;
 
-  if (nk > 0) {
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
+  int staged = 0;
+  for (; staged < D && staged < nk; ++staged) stage(staged % NS);
 
   for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk) stage(buf ^ 1);
+    // wait for slice `it` (the oldest in flight), then barrier: every wave's share of it has landed
+    // and every wave has finished reading the buffer that is restaged below (slice it - 1's)
+    const int ahead = staged - it - 1;
+    if (D >= 3 && ahead >= 2) wait_vmcnt<2 * LOADS>();
+    else if (D >= 2 && ahead == 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (staged < nk) {
+      stage(staged % NS);
+      ++staged;
+    }
+    const int buf = it % NS;
     const bf16_t* Ab = Abuf(buf);
     const bf16_t* Bb = Bbuf(buf);
 #pragma unroll
@@ -215,8 +234,84 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  }
+
+  // ---- epilogue, coalesced form (Co % 8 == 0): the accumulators (+ bias, self-activation) go
+  // through LDS in WM passes of BM/WM rows, then every thread finishes 8 consecutive channels of
+  // one pixel: gate / residual are read and the result is written as 16-byte (bf16) or 2 x 16-byte
+  // (fp32) pieces, whole rows contiguous across the lanes.  (The direct form below issues 8-byte
+  // stores 256 B apart; measured, the output write was ~20 us of a 67 us launch.)
+  if ((a.Co & 7) == 0) {
+    constexpr int RP = BM / WM;          // rows per pass
+    constexpr int LDC = BN + 4;          // floats per LDS row (+16 B: conflict-free b128 writes)
+    constexpr int C8 = BN / 8;           // 8-channel items per row
+    float* Cs = reinterpret_cast<float*>(smem);
+    for (int h = 0; h < WM; ++h) {
+      __syncthreads();
+      if (wm == h) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int col = wn * (BN / WN) + j * 32 + q * 8 + 4 * (lane >> 5);
+              float4 v = make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1],
+                                     acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+              if (a.bias && n0 + col < a.Co) {
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + col);
+                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+              }
+              if (a.self_gate) {
+                if (!(v.x > 0.f)) v.x *= a.slope_out;
+                if (!(v.y > 0.f)) v.y *= a.slope_out;
+                if (!(v.z > 0.f)) v.z *= a.slope_out;
+                if (!(v.w > 0.f)) v.w *= a.slope_out;
+              }
+              *reinterpret_cast<float4*>(Cs + (i * 32 + frow) * LDC + col) = v;
+            }
+      }
+      __syncthreads();
+      for (int t = tid; t < RP * C8; t += 256) {
+        const int row = t / C8, c8 = t - row * C8;
+        const int m = m0 + h * RP + row;
+        const int co = n0 + c8 * 8;
+        if (m >= a.Mp || co >= a.Co) continue;
+        const uint32_t t1 = fdiv((uint32_t)m, a.dWp);
+        const int owp = m - (int)t1 * a.Wp;
+        const uint32_t n = fdiv(t1, a.dHp);
+        const int ohp = (int)t1 - (int)n * a.Hp;
+        const int64_t o =
+            ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + co;
+        const float4 lo = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (a.gate_out) {
+          union { uint4 q; bf16_t h8[8]; } g;
+          g.q = *reinterpret_cast<const uint4*>(a.gate_out + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!(bf2f(g.h8[e]) > 0.f)) v[e] *= a.slope_out;
+        }
+        if (a.residual) {
+          union { uint4 q; bf16_t h8[8]; } r;
+          r.q = *reinterpret_cast<const uint4*>(a.residual + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(r.h8[e]);
+        }
+        if (a.out_f32) {
+          float* op = reinterpret_cast<float*>(a.out) + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          union { uint4 q; bf16_t h8[8]; } w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w.h8[e] = f2bf(v[e]);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = w.q;
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue: lane owns pixel (lane & 31) of each M sub-tile and, per 8-channel group q, the
@@ -275,6 +370,273 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
           }
         } else {
           // channel counts that are not a multiple of 4 (RGB outputs): element-wise tail
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (co + e >= a.Co) continue;
+            float val = v[e] + (a.bias ? a.bias[co + e] : 0.f);
+            if (a.self_gate) {
+              if (!(val > 0.f)) val *= a.slope_out;
+            } else if (a.gate_out && !(bf2f(a.gate_out[o + e]) > 0.f)) {
+              val *= a.slope_out;
+            }
+            if (a.residual) val += bf2f(a.residual[o + e]);
+            if (a.out_f32)
+              reinterpret_cast<float*>(a.out)[o + e] = val;
+            else
+              reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val);
+          }
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// "halo" convolution: stride-1 filters with several taps (3x3, and the 2x2 / 3x3 phase filters of
+// zero-inserted inputs).  The plain implicit GEMM above re-stages every input pixel once per tap; its
+// speed is set by the global -> LDS fill rate (measured: ~8 TB/s chip-wide at 64 FLOP per staged
+// byte).  Here a workgroup stages the input window of its output tile ONCE per 64-channel block --
+// TH x TW output pixels need (TH + nr - 1) x (TW + ns - 1) input pixels -- and every tap reads its
+// shifted view of that LDS image (fragment address = pixel row + tap shift), so only the weights
+// are staged per tap: ~1.8x fewer staged bytes per FLOP for a 128-pixel tile.
+// -------------------------------------------------------------------------------------------
+struct HaloArgs {
+  const bf16_t* in;
+  const bf16_t* bt;
+  void* out;
+  const float* bias;
+  const bf16_t* gate_out;
+  const bf16_t* residual;
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, U, pt, pl;
+  int Kp, cblocks;
+  int Hp, Wp;                 // per-phase output grid
+  int tw_log, th_log;         // tile = 2^th_log rows x 2^tw_log cols of NI images, 128 pixels
+  int NI;
+  int tiles_x, tiles_y, img_groups, ntiles;
+  int halo_groups;            // LDS-DMA instruction groups (8 rows) of the largest phase's halo
+  int relu_in, out_f32, self_gate;
+  float slope_out;
+  FastDiv dNt, dTx, dTy;
+};
+
+constexpr int HALO_SLOTS = 9;   // halo staging instructions per thread (covers 288 rows)
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void halo_conv_kernel(HaloArgs a) {
+  constexpr int BN = 128, B_ELEMS = BN * 64;
+  extern __shared__ __attribute__((aligned(1024))) bf16_t hsm[];
+  const int halo_elems = a.halo_groups * 512;          // per halo buffer
+  bf16_t* Hbuf0 = hsm;
+  bf16_t* Bbuf0 = hsm + 2 * halo_elems;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int st = (int)fdiv((uint32_t)wg, a.dNt);       // spatial tile
+  const int nt = wg - st * a.ntiles;
+  const int n0 = nt * BN;
+  const int t1 = (int)fdiv((uint32_t)st, a.dTx);
+  const int tx = st - t1 * a.tiles_x;
+  const int ig = (int)fdiv((uint32_t)t1, a.dTy);
+  const int ty = t1 - ig * a.tiles_y;
+  const int TW = 1 << a.tw_log, TH = 1 << a.th_log;
+
+  // ---- phase geometry (as fast_conv_kernel) ----
+  const int phase = blockIdx.y;
+  int r0 = 0, s0 = 0, nr = a.kh, ns = a.kw, bh = -a.pt, bw = -a.pl, ph = 0, pw = 0;
+  if (a.U == 2) {
+    ph = phase >> 1;
+    pw = phase & 1;
+    r0 = (a.pt + ph) & 1;
+    s0 = (a.pl + pw) & 1;
+    nr = (a.kh - r0 + 1) >> 1;
+    ns = (a.kw - s0 + 1) >> 1;
+    bh = (ph - a.pt + r0) >> 1;
+    bw = (pw - a.pl + s0) >> 1;
+  }
+  const int ntaps = nr * ns;
+  const int nk = ntaps * a.cblocks;
+  const int HH = TH + nr - 1, HW = TW + ns - 1;
+  const int hrows = a.NI * HH * HW;                    // halo pixels of this phase
+  const int groups = (hrows + 7) >> 3;                 // <= a.halo_groups
+  const int gpt = (groups + 3) >> 2;                   // staging slots per thread (<= HALO_SLOTS)
+  const int slice = ntaps > 0 ? (gpt + ntaps - 1) / ntaps : 0;   // slots issued per tap iteration
+
+  // ---- halo staging descriptors: slot j of this thread = group j*4 + wave, row g*8 + (lane>>3)
+  int h_off[HALO_SLOTS];
+  bool h_ok[HALO_SLOTS];
+  const int hhw = HH * HW;
+#pragma unroll
+  for (int j = 0; j < HALO_SLOTS; ++j) {
+    const int g = j * 4 + wave;
+    const int row = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int il = row / hhw;
+    const int rem = row - il * hhw;
+    const int hy = rem / HW, hx = rem - hy * HW;
+    const int n = ig * a.NI + il;
+    const int ih = ty * TH + bh + hy, iw = tx * TW + bw + hx;
+    h_ok[j] = (j < gpt) && row < hrows && n < a.N && (unsigned)ih < (unsigned)a.Hin &&
+              (unsigned)iw < (unsigned)a.Win;
+    h_off[j] = ((n * a.Hin + ih) * a.Win + iw) * a.Ci + c * 8;
+  }
+  int b_off[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = wave * 4 + j;
+    const int row = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    b_ok[j] = (n0 + row) < a.Co;
+    b_off[j] = (n0 + row) * a.Kp + c * 8;
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  auto stage_halo = [&](int hb, int cb, int j0, int j1) {
+    bf16_t* Hb = Hbuf0 + hb * halo_elems;
+#pragma unroll
+    for (int j = 0; j < HALO_SLOTS; ++j) {
+      if (j >= j0 && j < j1) {
+        const bf16_t* p = h_ok[j] ? a.in + (int64_t)(h_off[j] + cb * 64) : zero;
+        glds16(p, Hb + (j * 4 + wave) * 512);
+      }
+    }
+  };
+  auto stage_b = [&](int bb, int cb, int tap) {
+    const int ri = tap / ns, si = tap - ri * ns;
+    const int koff = ((r0 + a.U * ri) * a.kw + (s0 + a.U * si)) * a.Ci + cb * 64;
+    bf16_t* Bb = Bbuf0 + bb * B_ELEMS + (wave * 4) * 512;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t* p = b_ok[j] ? a.bt + (int64_t)(b_off[j] + koff) : zero;
+      glds16(p, Bb + j * 512);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // fragment rows: pixel p of the tile -> halo row of its tap-(0,0) input pixel
+  const int frow = lane & 31;
+  int hr0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = wm * 64 + i * 32 + frow;
+    const int il = p >> (a.tw_log + a.th_log);
+    const int y = (p >> a.tw_log) & (TH - 1), x = p & (TW - 1);
+    hr0[i] = il * hhw + y * HW + x;
+  }
+  const int half = lane >> 5;
+  const int bswz = (frow >> 1) & 7;
+  const int brow0 = (wn * 64 + frow) * 64;
+
+  if (nk > 0) {
+    stage_halo(0, 0, 0, gpt);
+    stage_b(0, 0, 0);
+  }
+  int cb = 0, tap = 0;
+  for (int it = 0; it < nk; ++it) {
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    // next iteration's weights, and this tap's share of the next channel block's halo
+    int ncb = cb, ntap = tap + 1;
+    if (ntap == ntaps) {
+      ntap = 0;
+      ncb = cb + 1;
+    }
+    if (it + 1 < nk) stage_b((it + 1) & 1, ncb, ntap);
+    if (cb + 1 < a.cblocks) stage_halo((cb + 1) & 1, cb + 1, tap * slice, min(gpt, (tap + 1) * slice));
+    const bf16_t* Hb = Hbuf0 + (cb & 1) * halo_elems;
+    const bf16_t* Bb = Bbuf0 + (it & 1) * B_ELEMS;
+    const int ri = tap / ns, si = tap - ri * ns;
+    const int tshift = ri * HW + si;
+    int arow[2], aswz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int hr = hr0[i] + tshift;
+      arow[i] = hr * 64;
+      aswz[i] = (hr >> 1) & 7;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = kk * 2 + half;
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(Hb + arow[i] + ((ch ^ aswz[i]) << 3));
+        if (RELU) af[i] = relu_bf16x8(af[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + ((ch ^ bswz) << 3));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    cb = ncb;
+    tap = ntap;
+  }
+
+  // ---- epilogue ----
+  const bool vec4 = (a.Co & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = wm * 64 + i * 32 + frow;
+    const int il = p >> (a.tw_log + a.th_log);
+    const int y = (p >> a.tw_log) & (TH - 1), x = p & (TW - 1);
+    const int n = ig * a.NI + il;
+    const int ohp = ty * TH + y, owp = tx * TW + x;
+    if (n >= a.N || ohp >= a.Hp || owp >= a.Wp) continue;
+    const int64_t opix = ((int64_t)(n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + wn * 64 + j * 32 + q * 8 + 4 * (lane >> 5);
+        if (co >= a.Co) continue;
+        float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
+                      acc[i][j][q * 4 + 3]};
+        const int64_t o = opix + co;
+        if (vec4) {
+          if (a.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          }
+          if (a.self_gate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+          } else if (a.gate_out) {
+            const uint2 g2 = *reinterpret_cast<const uint2*>(a.gate_out + o);
+            if (!(bf2f((bf16_t)(g2.x & 0xffff)) > 0.f)) v[0] *= a.slope_out;
+            if (!(bf2f((bf16_t)(g2.x >> 16)) > 0.f)) v[1] *= a.slope_out;
+            if (!(bf2f((bf16_t)(g2.y & 0xffff)) > 0.f)) v[2] *= a.slope_out;
+            if (!(bf2f((bf16_t)(g2.y >> 16)) > 0.f)) v[3] *= a.slope_out;
+          }
+          if (a.residual) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(a.residual + o);
+            v[0] += bf2f((bf16_t)(r2.x & 0xffff));
+            v[1] += bf2f((bf16_t)(r2.x >> 16));
+            v[2] += bf2f((bf16_t)(r2.y & 0xffff));
+            v[3] += bf2f((bf16_t)(r2.y >> 16));
+          }
+          if (a.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 w2;
+            w2.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            w2.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o) = w2;
+          }
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (co + e >= a.Co) continue;
@@ -868,11 +1230,6 @@ __global__ __launch_bounds__(256) void colsum_part8_kernel(const bf16_t* __restr
   }
 }
 
-int ilog2x(int x) {
-  int l = 0;
-  while ((1 << l) < x) ++l;
-  return ((1 << l) == x) ? l : -1;
-}
 
 bool phase_ok(const cgConvGeom* g) {
   if (g->U == 1) return true;
@@ -880,6 +1237,8 @@ bool phase_ok(const cgConvGeom* g) {
 }
 
 }  // namespace
+
+static int ilog2x(int x);
 
 bool cg_fast_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                             float slope_in) {
@@ -915,6 +1274,78 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.slope_out = slope_out;
   a.dWp = make_fastdiv(a.Wp); a.dHp = make_fastdiv(a.Hp);
   const int phases = g->U * g->U;
+  // several taps, unit stride, wide output: stage the input window once per channel block
+  // (experimental, CGAMD_HALO=1: measured on MI355X it only ties the plain kernel -- the staged bytes
+  // were not the limiter, the epilogue and the per-iteration issue overheads were)
+  static const int use_halo = [] {
+    const char* e = getenv("CGAMD_HALO");
+    return e ? atoi(e) : 0;
+  }();
+  if (use_halo && g->S == 1 && g->Co > 64 && g->kh * g->kw >= 4 && (a.Hp & (a.Hp - 1)) == 0 &&
+      (a.Wp & (a.Wp - 1)) == 0 && a.Hp >= 4 && a.Wp >= 4 && g->kh <= 5 && g->kw <= 5) {
+    HaloArgs h;
+    h.in = a.in; h.bt = a.bt; h.out = a.out; h.bias = a.bias;
+    h.gate_out = a.gate_out; h.residual = a.residual;
+    h.N = g->N; h.Hin = g->Hin; h.Win = g->Win; h.Ci = g->Ci; h.Ho = g->Ho; h.Wo = g->Wo;
+    h.Co = g->Co; h.kh = g->kh; h.kw = g->kw; h.U = g->U; h.pt = g->pt; h.pl = g->pl;
+    h.Kp = a.Kp; h.cblocks = a.cblocks; h.Hp = a.Hp; h.Wp = a.Wp;
+    const int TW = a.Wp < 16 ? a.Wp : 16;
+    int TH = 128 / TW;
+    if (TH > a.Hp) TH = a.Hp;
+    h.NI = 128 / (TW * TH);
+    h.tw_log = ilog2x(TW); h.th_log = ilog2x(TH);
+    h.tiles_x = a.Wp / TW; h.tiles_y = a.Hp / TH;
+    h.img_groups = cdiv(g->N, h.NI);
+    h.ntiles = cdiv(g->Co, 128);
+    // largest halo over the phases: nr <= ceil(kh / U) rows more than the tile
+    const int nr_max = (g->kh + g->U - 1) / g->U, ns_max = (g->kw + g->U - 1) / g->U;
+    const int hrows = h.NI * (TH + nr_max - 1) * (TW + ns_max - 1);
+    h.halo_groups = ((hrows + 7) / 8 + 3) / 4 * 4;
+    if (h.halo_groups <= 4 * HALO_SLOTS) {
+      h.relu_in = a.relu_in; h.out_f32 = a.out_f32; h.self_gate = a.self_gate;
+      h.slope_out = a.slope_out;
+      h.dNt = make_fastdiv(h.ntiles); h.dTx = make_fastdiv(h.tiles_x);
+      h.dTy = make_fastdiv(h.tiles_y);
+      const size_t lds = (size_t)(2 * h.halo_groups * 512 + 2 * 128 * 64) * sizeof(bf16_t);
+      static const bool attr_set = [] {
+        // more than 64 KiB of dynamic LDS needs the opt-in attribute
+        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)attr_set;
+      dim3 grid(h.img_groups * h.tiles_y * h.tiles_x * h.ntiles, phases);
+      CgProfScope prof(CG_PROF_HALO_CONV, g, st);
+      if (h.relu_in)
+        halo_conv_kernel<true><<<grid, 256, lds, st>>>(h);
+      else
+        halo_conv_kernel<false><<<grid, 256, lds, st>>>(h);
+      return;
+    }
+  }
+  // ring depth: a grid of <= ~1.5 workgroups per CU cannot rely on a co-resident workgroup to hide
+  // the load latency -> deep ring; larger grids keep two workgroups per CU (64 KiB of LDS each)
+  static const int ns_env = [] {
+    const char* e = getenv("CGAMD_CONV_NS");
+    return e ? atoi(e) : 0;
+  }();
+#define CG_LAUNCH_CONV(BM_, BN_, GRID_)                                                  \
+  do {                                                                                   \
+    const int blocks_ = (GRID_).x * (GRID_).y;                                           \
+    const int ns_ = ns_env ? ns_env : (blocks_ <= 384 ? 4 : 2);                          \
+    if (ns_ >= 4) {                                                                      \
+      if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 4><<<GRID_, 256, 0, st>>>(a);      \
+      else fast_conv_kernel<BM_, BN_, false, 4><<<GRID_, 256, 0, st>>>(a);               \
+    } else if (ns_ == 3) {                                                               \
+      if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 3><<<GRID_, 256, 0, st>>>(a);      \
+      else fast_conv_kernel<BM_, BN_, false, 3><<<GRID_, 256, 0, st>>>(a);               \
+    } else {                                                                             \
+      if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 2><<<GRID_, 256, 0, st>>>(a);      \
+      else fast_conv_kernel<BM_, BN_, false, 2><<<GRID_, 256, 0, st>>>(a);               \
+    }                                                                                    \
+  } while (0)
   if (g->Co <= 32) {
     // narrow outputs (RGB images, logits): 32-channel tile, the pixel dimension carries the grid
     a.ntiles = 1;
@@ -922,10 +1353,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_128x32, g, st);
-    if (a.relu_in)
-      fast_conv_kernel<128, 32, true><<<grid, 256, 0, st>>>(a);
-    else
-      fast_conv_kernel<128, 32, false><<<grid, 256, 0, st>>>(a);
+    CG_LAUNCH_CONV(128, 32, grid);
     return;
   }
   if (g->Co <= 64) {
@@ -935,10 +1363,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_128x64, g, st);
-    if (a.relu_in)
-      fast_conv_kernel<128, 64, true><<<grid, 256, 0, st>>>(a);
-    else
-      fast_conv_kernel<128, 64, false><<<grid, 256, 0, st>>>(a);
+    CG_LAUNCH_CONV(128, 64, grid);
     return;
   }
   a.ntiles = cdiv(g->Co, 128);
@@ -948,19 +1373,20 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles * a.ntiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_128x128, g, st);
-    if (a.relu_in)
-      fast_conv_kernel<128, 128, true><<<grid, 256, 0, st>>>(a);
-    else
-      fast_conv_kernel<128, 128, false><<<grid, 256, 0, st>>>(a);
+    CG_LAUNCH_CONV(128, 128, grid);
   } else {
     a.mtiles = cdiv(a.Mp, 64);
     dim3 grid(a.mtiles * a.ntiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_64x128, g, st);
-    if (a.relu_in)
-      fast_conv_kernel<64, 128, true><<<grid, 256, 0, st>>>(a);
-    else
-      fast_conv_kernel<64, 128, false><<<grid, 256, 0, st>>>(a);
+    CG_LAUNCH_CONV(64, 128, grid);
   }
+#undef CG_LAUNCH_CONV
+}
+
+static int ilog2x(int x) {
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return ((1 << l) == x) ? l : -1;
 }
 
 static bool stem_geom_ok(const cgConvGeom* g) {
@@ -1017,8 +1443,8 @@ bool cg_stem_wgrad_supported(const cgConvGeom* g, const void* in, const void* ga
 
 static void stem_wgrad_plan(const cgConvGeom* g, int* splits, int* rps) {
   const int M = g->N * g->Ho * g->Wo;
-  int s = M / 1024 > 0 ? M / 1024 : 1;
-  if (s > 512) s = 512;
+  int s = M / 256 > 0 ? M / 256 : 1;   // the partial image is tiny (K <= 128 rows): split finely
+  if (s > 1024) s = 1024;
   int r = cdiv(M, s);
   r = (r + 63) / 64 * 64;
   *splits = cdiv(M, r);

@@ -101,6 +101,7 @@ class _OptimizerState(object):
   def apply_gradients(self, step, ema_decay=0.0, ema_start=0, grads=None):
     """All-reduce (data parallel) + fused Adam(+EMA).  step: device int64 update counter.
     grads: one tensor per variable (defaults to the variables' .grad fields)."""
+    Fn.join_wgrad_stream()   # weight gradients may still be in flight on the side stream
     if grads is None:
       grads = [p.grad for p in self.params]
     grads = list(grads)
@@ -430,6 +431,9 @@ class ModularGAN(AbstractGAN):
     hipGraph: small configs are launch-bound, replay removes the per-launch
     host cost.  Inputs are copied into static device buffers before each replay.  Returns
     run(images, labels) -> same dict as train_step."""
+    import os
+    # weight gradients become a parallel branch of the graph (CGAMD_NO_WGRAD_STREAM=1: A/B switch)
+    Fn.enable_wgrad_stream(os.environ.get("CGAMD_NO_WGRAD_STREAM", "") != "1")
     nsub = self._disc_iters + 1
     shape = (nsub * self.batch_size,) + tuple(self._dataset.image_shape)
     self._static_images = torch.zeros(shape, dtype=torch.float32, device=self.device)

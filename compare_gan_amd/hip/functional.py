@@ -72,6 +72,34 @@ def _run_gconv(spec, x, w, bias, gate_in, gate_out, residual, bt_pair=None):
 
 _SKIP_PARAM_GRADS = [False]
 
+# ------------------------------------------------------------------------------------------------
+# weight gradients on a second HIP stream
+# ------------------------------------------------------------------------------------------------
+# In the backward pass of a convolution the data gradient (needed by the next layer down) and the
+# weight gradient (needed only by the optimiser) are independent.  The small layers of the GAN
+# discriminators / generators do not fill 256 CUs on their own, so the weight gradients run on a
+# side stream and overlap with the data-gradient chain; inside a captured step this becomes a
+# parallel branch of the hipGraph.  Consumers of weight gradients (spectral-norm backward, the
+# optimiser) call join_wgrad_stream() first.
+_WGRAD = {"enabled": False, "stream": None, "dirty": False}
+
+
+def enable_wgrad_stream(enabled=True):
+  _WGRAD["enabled"] = bool(enabled)
+
+
+def _wgrad_side_stream():
+  if _WGRAD["stream"] is None:
+    _WGRAD["stream"] = torch.cuda.Stream()
+  return _WGRAD["stream"]
+
+
+def join_wgrad_stream():
+  """Makes the current stream wait for every weight gradient launched on the side stream."""
+  if _WGRAD["dirty"]:
+    torch.cuda.current_stream().wait_stream(_WGRAD["stream"])
+    _WGRAD["dirty"] = False
+
 
 class only_input_grads(object):
   """Context for torch.autograd.grad(outputs, [network input], create_graph=True): the weight /
@@ -123,6 +151,18 @@ class GConvFn(torch.autograd.Function):
         dw = GWgradFn.apply(x, dy16, gate_in, gate_out, spec) if need_w else None
         if want_b:
           db = K.colsum(_gated(dy16, gate_out, spec.slope_out).reshape(-1, dy16.shape[-1]))
+      elif _WGRAD["enabled"] and x.is_cuda:
+        main, side = torch.cuda.current_stream(), _wgrad_side_stream()
+        side.wait_stream(main)     # x / dy16 / gates are ready on the main stream
+        with torch.cuda.stream(side):
+          dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
+        for t in (x, dy16, gate_in, gate_out):
+          if t is not None:
+            t.record_stream(side)    # keep their memory until the side stream has read it
+        for t in (dw, db):
+          if t is not None:
+            t.record_stream(main)    # allocated on the side stream, consumed on the main one
+        _WGRAD["dirty"] = True
       else:
         dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
     return dx, dw, db, dr, None, None, None, None, None
@@ -204,6 +244,7 @@ class SpectralNormFn(torch.autograd.Function):
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, dwbar):
+    join_wgrad_stream()
     w2, u_new, v, sigma = ctx.saved_tensors
     a_k, b_co = (u_new, v) if ctx.mode == 0 else (v, u_new)
     dw = K.sn_backward(dwbar.contiguous().reshape(w2.shape), w2, a_k, b_co, sigma)
@@ -230,6 +271,7 @@ class SpectralNormBatchFn(torch.autograd.Function):
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, *dwbars):
+    join_wgrad_stream()
     n = ctx.n
     saved = ctx.saved_tensors
     w2, u_news, vs, sigmas = saved[:n], saved[n:2 * n], saved[2 * n:3 * n], saved[3 * n:4 * n]
