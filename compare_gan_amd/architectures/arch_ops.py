@@ -65,7 +65,7 @@ class VariableStore(object):
       if self.device.type == "meta":
         t = torch.empty(tuple(shape), dtype=dtype, device="meta")
       else:
-        t = fn(tuple(shape), self._gen).to(dtype).to(self.device)
+        t = fn(tuple(shape), self._gen).to(dtype).contiguous().to(self.device)
       if trainable:
         t.requires_grad_(True)
         self.trainable.add(full)

@@ -226,6 +226,353 @@ __global__ __launch_bounds__(256) void attn_bwd_k_kernel(
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// v2: MFMA (v_mfma_f32_32x32x16_bf16) flash-style kernels for Lq % 128 == 0, Lk % 64 == 0,
+// Dk <= 64, Dv <= 128.  Score tiles are computed TRANSPOSED (S^T[key][query]) so that a lane owns one
+// query column and 16 keys of it: softmax statistics are per-lane (plus one lane^32 exchange), and
+// the probabilities feed the second MFMA straight from the accumulator registers -- the key order
+// inside a 16-wide MFMA K step is a permutation, which is harmless as long as the other operand
+// (V^T / K^T / dO^T / Q^T, staged transposed in LDS) uses the same one:
+//   element e of lane half h of K-step ks  <->  row 16*ks + 4*h + (e & 3) + 8*(e >> 2).
+// Dk / Dv are zero-padded to DKP / DVP in LDS.
+// -------------------------------------------------------------------------------------------
+constexpr int AT = 64;          // keys (fwd, bwd_q) / queries (bwd_k) per LDS stage
+constexpr int ATP = AT + 8;     // padded row of the transposed tiles
+
+__device__ __forceinline__ bf16x8_t pack_bf16x8(const float* v) {
+  s16x8_t r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (short)f2bf(v[e]);
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+// two 4-element (8-byte) pieces of a transposed LDS row: rows base + 4h + {0..3} and + 8
+__device__ __forceinline__ bf16x8_t read_perm(const bf16_t* row, int off) {
+  const uint2 lo = *reinterpret_cast<const uint2*>(row + off);
+  const uint2 hi = *reinterpret_cast<const uint2*>(row + off + 8);
+  uint4 q = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return __builtin_bit_cast(bf16x8_t, q);
+}
+// row-major [rows][D] global tile -> LDS row-major (ld = DP + 8) with zero padding, rows r0..r0+AT
+template <int DP>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int D, int64_t row0,
+                                           bf16_t* dst) {
+  for (int i = threadIdx.x; i < AT * DP; i += 256) {
+    const int r = i / DP, d = i - r * DP;
+    dst[r * (DP + 8) + d] = d < D ? src[(row0 + r) * D + d] : (bf16_t)0;
+  }
+}
+// same tile transposed: dst[d][r], D rows padded to DPT (multiple of 32) zero rows
+template <int DPT>
+__device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ src, int D, int64_t row0,
+                                           bf16_t* dst) {
+  for (int i = threadIdx.x; i < AT * DPT; i += 256) {
+    const int r = i / DPT, d = i - r * DPT;
+    dst[d * ATP + r] = d < D ? src[(row0 + r) * D + d] : (bf16_t)0;
+  }
+}
+// register fragment of a global row-major matrix: row = lane & 31, columns kd*16 + (lane>>5)*8 + e
+__device__ __forceinline__ bf16x8_t load_frag(const bf16_t* __restrict__ src, int D, int64_t row,
+                                              int kd, int half) {
+  s16x8_t r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int d = kd * 16 + half * 8 + e;
+    r[e] = d < D ? (short)src[row * D + d] : (short)0;
+  }
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// forward: grid (Lq/128, B); wave -> 32 queries.
+template <int DKP, int DVP>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(
+    const bf16_t* __restrict__ theta, const bf16_t* __restrict__ phi, const bf16_t* __restrict__ g,
+    int Lq, int Lk, int Dk, int Dv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+  constexpr int KD = DKP / 16, VT = DVP / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[AT * (DKP + 8)];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[DVP * ATP];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int64_t q = (int64_t)b * Lq + blockIdx.x * 128 + wave * 32 + col;
+  bf16x8_t qf[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd) qf[kd] = load_frag(theta, Dk, q, kd, half);
+  f32x16_t o[VT];
+#pragma unroll
+  for (int t = 0; t < VT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[t][v] = 0.f;
+  float m = -3.0e38f, l = 0.f;
+  for (int k0 = 0; k0 < Lk; k0 += AT) {
+    __syncthreads();
+    stage_rows<DKP>(phi, Dk, (int64_t)b * Lk + k0, Ks);
+    stage_cols<DVP>(g, Dv, (int64_t)b * Lk + k0, Vt);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < AT / 32; ++sub) {
+      f32x16_t s;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) s[v] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+            Ks + (sub * 32 + col) * (DKP + 8) + kd * 16 + half * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int v = 1; v < 16; ++v) mx = fmaxf(mx, s[v]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float corr = __expf(m - mn);
+      m = mn;
+      l *= corr;
+#pragma unroll
+      for (int t = 0; t < VT; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[t][v] *= corr;
+      float p[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        p[v] = __expf(s[v] - mn);
+        l += p[v];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t pf = pack_bf16x8(p + 8 * ks);
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+          const bf16x8_t vf = read_perm(Vt + (t * 32 + col) * ATP, sub * 32 + 16 * ks + 4 * half);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int t = 0; t < VT; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int dv = t * 32 + qd * 8 + 4 * half;
+      if (dv < Dv) {   // Dv % 4 == 0
+        uint2 w;
+        w.x = (uint32_t)f2bf(o[t][qd * 4 + 0] * inv) | ((uint32_t)f2bf(o[t][qd * 4 + 1] * inv) << 16);
+        w.y = (uint32_t)f2bf(o[t][qd * 4 + 2] * inv) | ((uint32_t)f2bf(o[t][qd * 4 + 3] * inv) << 16);
+        *reinterpret_cast<uint2*>(out + q * Dv + dv) = w;
+      }
+    }
+  if (half == 0) lse[q] = m + __logf(l);
+}
+
+// dtheta: grid (Lq/128, B); wave -> 32 queries, loops over the keys.
+template <int DKP, int DVP>
+__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(
+    const bf16_t* __restrict__ theta, const bf16_t* __restrict__ phi, const bf16_t* __restrict__ g,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, int Lq, int Lk, int Dk, int Dv,
+    bf16_t* __restrict__ dtheta) {
+  constexpr int KD = DKP / 16, VD = DVP / 16, KT = (DKP + 31) / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[AT * (DKP + 8)];
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[KT * 32 * ATP];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[AT * (DVP + 8)];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int64_t q = (int64_t)b * Lq + blockIdx.x * 128 + wave * 32 + col;
+  bf16x8_t qf[KD], dof[VD];
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd) qf[kd] = load_frag(theta, Dk, q, kd, half);
+#pragma unroll
+  for (int vd = 0; vd < VD; ++vd) dof[vd] = load_frag(dout, Dv, q, vd, half);
+  const float ls = lse[q], dl = delta[q];
+  f32x16_t dq[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dq[t][v] = 0.f;
+  for (int k0 = 0; k0 < Lk; k0 += AT) {
+    __syncthreads();
+    stage_rows<DKP>(phi, Dk, (int64_t)b * Lk + k0, Ks);
+    stage_cols<KT * 32>(phi, Dk, (int64_t)b * Lk + k0, Kt);
+    stage_rows<DVP>(g, Dv, (int64_t)b * Lk + k0, Vs);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < AT / 32; ++sub) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) s[v] = dp[v] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+            Ks + (sub * 32 + col) * (DKP + 8) + kd * 16 + half * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int vd = 0; vd < VD; ++vd) {
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(
+            Vs + (sub * 32 + col) * (DVP + 8) + vd * 16 + half * 8);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[vd], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) ds[v] = __expf(s[v] - ls) * (dp[v] - dl);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t dsf = pack_bf16x8(ds + 8 * ks);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const bf16x8_t kf = read_perm(Kt + (t * 32 + col) * ATP, sub * 32 + 16 * ks + 4 * half);
+          dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf, dq[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int d = t * 32 + qd * 8 + 4 * half;
+      if (d < Dk) {   // Dk % 4 == 0
+        uint2 w;
+        w.x = (uint32_t)f2bf(dq[t][qd * 4 + 0]) | ((uint32_t)f2bf(dq[t][qd * 4 + 1]) << 16);
+        w.y = (uint32_t)f2bf(dq[t][qd * 4 + 2]) | ((uint32_t)f2bf(dq[t][qd * 4 + 3]) << 16);
+        *reinterpret_cast<uint2*>(dtheta + q * Dk + d) = w;
+      }
+    }
+}
+
+// dphi, dg: grid (Lk/128, B); wave -> 32 keys, loops over the queries.
+template <int DKP, int DVP>
+__global__ __launch_bounds__(256) void attn_bwd_k_mfma_kernel(
+    const bf16_t* __restrict__ theta, const bf16_t* __restrict__ phi, const bf16_t* __restrict__ g,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, int Lq, int Lk, int Dk, int Dv, bf16_t* __restrict__ dphi,
+    bf16_t* __restrict__ dg) {
+  constexpr int KD = DKP / 16, VD = DVP / 16, KT = (DKP + 31) / 32, VT = DVP / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[AT * (DKP + 8)];
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[KT * 32 * ATP];
+  __shared__ __attribute__((aligned(16))) bf16_t Os[AT * (DVP + 8)];
+  __shared__ __attribute__((aligned(16))) bf16_t Ot[DVP * ATP];
+  __shared__ float sls[AT], sdl[AT];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int64_t k = (int64_t)b * Lk + blockIdx.x * 128 + wave * 32 + col;
+  bf16x8_t kf[KD], vf[VD];
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd) kf[kd] = load_frag(phi, Dk, k, kd, half);
+#pragma unroll
+  for (int vd = 0; vd < VD; ++vd) vf[vd] = load_frag(g, Dv, k, vd, half);
+  f32x16_t dk[KT], dv[VT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dk[t][v] = 0.f;
+#pragma unroll
+  for (int t = 0; t < VT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dv[t][v] = 0.f;
+  for (int q0 = 0; q0 < Lq; q0 += AT) {
+    __syncthreads();
+    stage_rows<DKP>(theta, Dk, (int64_t)b * Lq + q0, Qs);
+    stage_cols<KT * 32>(theta, Dk, (int64_t)b * Lq + q0, Qt);
+    stage_rows<DVP>(dout, Dv, (int64_t)b * Lq + q0, Os);
+    stage_cols<DVP>(dout, Dv, (int64_t)b * Lq + q0, Ot);
+    if (threadIdx.x < AT) {
+      sls[threadIdx.x] = lse[(int64_t)b * Lq + q0 + threadIdx.x];
+      sdl[threadIdx.x] = delta[(int64_t)b * Lq + q0 + threadIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < AT / 32; ++sub) {
+      // S[q][key], dP[q][key]: lane owns key `col`, queries 4*half + (v & 3) + 8*(v >> 2)
+      f32x16_t s, dp;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) s[v] = dp[v] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) {
+        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(
+            Qs + (sub * 32 + col) * (DKP + 8) + kd * 16 + half * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[kd], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int vd = 0; vd < VD; ++vd) {
+        const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(
+            Os + (sub * 32 + col) * (DVP + 8) + vd * 16 + half * 8);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[vd], dp, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int qi = sub * 32 + 4 * half + (v & 3) + 8 * (v >> 2);
+        p[v] = __expf(s[v] - sls[qi]);
+        ds[v] = p[v] * (dp[v] - sdl[qi]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t pf = pack_bf16x8(p + 8 * ks);
+        const bf16x8_t dsf = pack_bf16x8(ds + 8 * ks);
+        const int off = sub * 32 + 16 * ks + 4 * half;
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+          const bf16x8_t of = read_perm(Ot + (t * 32 + col) * ATP, off);
+          dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, pf, dv[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const bf16x8_t qf = read_perm(Qt + (t * 32 + col) * ATP, off);
+          dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dk[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int d = t * 32 + qd * 8 + 4 * half;
+      if (d < Dk) {
+        uint2 w;
+        w.x = (uint32_t)f2bf(dk[t][qd * 4 + 0]) | ((uint32_t)f2bf(dk[t][qd * 4 + 1]) << 16);
+        w.y = (uint32_t)f2bf(dk[t][qd * 4 + 2]) | ((uint32_t)f2bf(dk[t][qd * 4 + 3]) << 16);
+        *reinterpret_cast<uint2*>(dphi + k * Dk + d) = w;
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < VT; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int d = t * 32 + qd * 8 + 4 * half;
+      if (d < Dv) {
+        uint2 w;
+        w.x = (uint32_t)f2bf(dv[t][qd * 4 + 0]) | ((uint32_t)f2bf(dv[t][qd * 4 + 1]) << 16);
+        w.y = (uint32_t)f2bf(dv[t][qd * 4 + 2]) | ((uint32_t)f2bf(dv[t][qd * 4 + 3]) << 16);
+        *reinterpret_cast<uint2*>(dg + k * Dv + d) = w;
+      }
+    }
+}
+
+bool attn_mfma_ok(int Lq, int Lk, int Dk, int Dv) {
+  return (Lq % 128) == 0 && (Lk % 128) == 0 && Dk <= 64 && Dv <= 128 && (Dk % 4) == 0 &&
+         (Dv % 4) == 0;
+}
+// padded sizes: DKP in {16, 32, 64}; DVP in {32, 64, 96, 128}
+#define CG_ATTN_DISPATCH(KERNEL, GRID, ...)                                                   \
+  do {                                                                                        \
+    const int dkp_ = Dk <= 16 ? 16 : (Dk <= 32 ? 32 : 64);                                    \
+    const int dvp_ = (Dv + 31) / 32 * 32;                                                     \
+    if (dkp_ == 16 && dvp_ == 32) KERNEL<16, 32><<<GRID, 256, 0, st>>>(__VA_ARGS__);          \
+    else if (dkp_ == 16 && dvp_ == 64) KERNEL<16, 64><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 16 && dvp_ == 96) KERNEL<16, 96><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 16) KERNEL<16, 128><<<GRID, 256, 0, st>>>(__VA_ARGS__);                  \
+    else if (dkp_ == 32 && dvp_ == 32) KERNEL<32, 32><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 32 && dvp_ == 64) KERNEL<32, 64><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 32 && dvp_ == 96) KERNEL<32, 96><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 32) KERNEL<32, 128><<<GRID, 256, 0, st>>>(__VA_ARGS__);                  \
+    else if (dvp_ == 32) KERNEL<64, 32><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
+    else if (dvp_ == 64) KERNEL<64, 64><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
+    else if (dvp_ == 96) KERNEL<64, 96><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
+    else KERNEL<64, 128><<<GRID, 256, 0, st>>>(__VA_ARGS__);                                  \
+  } while (0)
+
 int check_attn(int B, int Lq, int Lk, int Dk, int Dv, const char* who) {
   if (B <= 0 || Lq <= 0 || Lk <= 0 || Dk <= 0 || Dv <= 0)
     CG_FAIL(CG_ERR_BAD_ARG, "%s: non-positive dimension", who);
@@ -242,10 +589,17 @@ extern "C" int cg_attention_fwd(const void* theta, const void* phi, const void* 
   int rc = check_attn(B, Lq, Lk, Dk, Dv, "cg_attention_fwd");
   if (rc) return rc;
   if (!theta || !phi || !g || !out || !lse) CG_FAIL(CG_ERR_BAD_ARG, "cg_attention_fwd: null");
+  hipStream_t st = (hipStream_t)stream;
+  if (attn_mfma_ok(Lq, Lk, Dk, Dv)) {
+    dim3 mgrid(Lq / 128, B);
+    CG_ATTN_DISPATCH(attn_fwd_mfma_kernel, mgrid, (const bf16_t*)theta, (const bf16_t*)phi,
+                     (const bf16_t*)g, Lq, Lk, Dk, Dv, (bf16_t*)out, lse);
+    CG_CHECK_LAUNCH("cg_attention_fwd(mfma)");
+    return CG_OK;
+  }
   dim3 grid(cdiv(Lq, 64), B);
-  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)theta, (const bf16_t*)phi,
-                                                        (const bf16_t*)g, Lq, Lk, Dk, Dv,
-                                                        (bf16_t*)out, lse);
+  attn_fwd_kernel<<<grid, 256, 0, st>>>((const bf16_t*)theta, (const bf16_t*)phi,
+                                        (const bf16_t*)g, Lq, Lk, Dk, Dv, (bf16_t*)out, lse);
   CG_CHECK_LAUNCH("cg_attention_fwd");
   return CG_OK;
 }
@@ -272,6 +626,17 @@ extern "C" int cg_attention_bwd(const void* theta, const void* phi, const void* 
   attn_delta_kernel<<<cdiv(rows, 64), 256, 0, st>>>((const bf16_t*)out, (const bf16_t*)dout, rows,
                                                     Dv, delta);
   CG_CHECK_LAUNCH("cg_attention_bwd(delta)");
+  if (attn_mfma_ok(Lq, Lk, Dk, Dv)) {
+    dim3 mq(Lq / 128, B), mk(Lk / 128, B);
+    CG_ATTN_DISPATCH(attn_bwd_q_mfma_kernel, mq, (const bf16_t*)theta, (const bf16_t*)phi,
+                     (const bf16_t*)g, (const bf16_t*)dout, lse, delta, Lq, Lk, Dk, Dv,
+                     (bf16_t*)dtheta);
+    CG_ATTN_DISPATCH(attn_bwd_k_mfma_kernel, mk, (const bf16_t*)theta, (const bf16_t*)phi,
+                     (const bf16_t*)g, (const bf16_t*)dout, lse, delta, Lq, Lk, Dk, Dv,
+                     (bf16_t*)dphi, (bf16_t*)dg);
+    CG_CHECK_LAUNCH("cg_attention_bwd(mfma)");
+    return CG_OK;
+  }
   dim3 gq(cdiv(Lq, 64), B);
   attn_bwd_q_kernel<<<gq, 256, 0, st>>>((const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g,
                                         (const bf16_t*)dout, lse, delta, Lq, Lk, Dk, Dv,
