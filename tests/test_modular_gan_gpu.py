@@ -224,3 +224,82 @@ def test_wgangp_step_resnet5(dev, emulate):
     w = _check_grads(gan.store.trainable_variables("discriminator"), grads_o, "wgangp D-step",
                      0.99 if emulate else 0.90, 0.15 if emulate else 0.45)
     print("wgangp worst grad cosine", w)
+
+
+def test_biggan_forward_and_gradients(dev):
+    """biggan_imagenet128.gin (class-conditional hinge, conditional BN on hierarchical z + embedded
+    labels, spectral norm "auto" in G and D, self-attention at 64x64, projection discriminator) at
+    128x128, batch 2, with the reference's own width binding ch = 32 to keep the fp64 oracle fast.
+    Generator forward, D sub-step and G sub-step losses and gradients against the bf16-storage
+    oracle."""
+    from compare_gan_amd.architectures import arch_ops as ops
+    from oracle import architectures as OA
+    from oracle import arch_ops as oops
+    config, bsz = "biggan_imagenet128.gin", 2
+    bind = ["resnet_biggan.Generator.ch = 32", "resnet_biggan.Discriminator.ch = 32"]
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED, bindings=bind)
+    vs = U.mirror_to_oracle(gan, emulate_bf16=True)
+    ora = U.build_oracle(
+        config, vs,
+        g_cfg=lambda: OA.ArchConfig(batch_norm_fn="conditional_batch_norm", spectral_norm=True,
+                                    bn_cfg=oops.BNConfig(0.9, 1e-5, use_moving_averages=False),
+                                    sn_cfg=oops.SNConfig(singular_value="auto"),
+                                    hierarchical_z=True, embed_y=True, ch=32),
+        d_cfg=lambda: OA.ArchConfig(spectral_norm=True, sn_cfg=oops.SNConfig(singular_value="auto"),
+                                    project_y=True, ch=32))
+    rng = np.random.RandomState(11)
+    images = torch.from_numpy(rng.uniform(size=(bsz,) + dataset.image_shape).astype(np.float32))
+    labels = torch.tensor([3, 977], dtype=torch.int32)
+    sampled = torch.tensor([5, 400], dtype=torch.int32)
+    z = U.host_normal((bsz, options["z_dim"]), "z/0", 0.0, 1.0, SEED, 0)
+    with ops.use_store(gan.store):
+        zd = gan.z_generator([bsz, options["z_dim"]], name="z/0")
+        assert float((zd.cpu() - z).abs().max()) <= 1e-5, "device z differs from the host stream"
+        sy = gan._get_one_hot_labels(sampled.to(dev))
+        with torch.no_grad():
+            gen = gan.generator(zd, y=sy, is_training=True)
+    with torch.no_grad():
+        gen_o = ora.G(z.double(), ora.one_hot(sampled))
+    diff = (gen.cpu().double() - gen_o).abs()
+    assert float(diff.max()) <= 0.05 and float(diff.mean()) <= 5e-3, (float(diff.max()), float(diff.mean()))
+
+    # the generator forward above ran one power iteration on G's u vectors on both sides; D next
+    gen_in = gen_o.float()
+    feats = {"images": images.to(dev), "generated": gen_in.to(dev), "sampled_labels": sampled.to(dev)}
+    gan._set_requires_grad(gan.g_opt, False)
+    gan._zero_grads(gan.d_opt)
+    with ops.use_store(gan.store):
+        gan.create_loss(feats, labels.to(dev))
+    gan.d_loss.backward()
+    d_loss_o, _, _ = ora.create_loss(images.double(), gen_in.double(), labels, sampled)
+    grads_o = torch.autograd.grad(d_loss_o, ora.d_vars())
+    print("biggan d_loss", float(gan.d_loss.detach()), float(d_loss_o.detach()))
+    assert abs(float(gan.d_loss.detach()) - float(d_loss_o.detach())) <= 3e-2 * max(
+        1.0, abs(float(d_loss_o.detach())))
+    w = _check_grads(gan.store.trainable_variables("discriminator"), grads_o, "biggan D-step",
+                     0.98, 0.2)
+    print("biggan D-step worst grad cosine", w)
+
+    gan._set_requires_grad(gan.d_opt, False)
+    gan._set_requires_grad(gan.g_opt, True)
+    gan._zero_grads(gan.g_opt)
+    with ops.use_store(gan.store):
+        feats = {"images": images.to(dev), "_generator_step": True, "sampled_labels": sampled.to(dev),
+                 "generated": gan.generator(zd, y=sy, is_training=True)}
+        gan.create_loss(feats, labels.to(dev))
+    gan.g_loss.backward()
+    gen_o2 = ora.G(z.double(), ora.one_hot(sampled))
+    _, g_loss_o, _ = ora.create_loss(images.double(), gen_o2, labels, sampled, with_penalty=False)
+    ggrads_o = torch.autograd.grad(g_loss_o, ora.g_vars(), allow_unused=True)
+    print("biggan g_loss", float(gan.g_loss.detach()), float(g_loss_o.detach()))
+    assert abs(float(gan.g_loss.detach()) - float(g_loss_o.detach())) <= 3e-2 * max(
+        1.0, abs(float(g_loss_o.detach())))
+    named = [(n, p) for (n, p), go in zip(gan.store.trainable_variables("generator"), ggrads_o)
+             if go is not None and p.grad is not None]
+    ggo = [go for go in ggrads_o if go is not None]
+    assert len(named) == len(ggo) >= 40
+    w = _check_grads(named, ggo, "biggan G-step", 0.97, 0.3)
+    print("biggan G-step worst grad cosine", w)
+    for name, v in gan.store.vars.items():
+        if name.endswith("u_var"):
+            assert U.rel_l2(v, vs.vars[name]) <= 3e-2, name
