@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   // ---- per-thread staging descriptors ----
   // instruction group g = wave*AJ + j stages rows g*8 .. g*8+7; lane -> row g*8 + (lane >> 3),
   // LDS slot (lane & 7) which must hold source chunk (lane & 7) ^ ((row >> 1) & 7)
-  int a_off[AJ], a_ih[AJ], a_iw[AJ];
+  int a_off[AJ], a_ih[AJ], a_iw[AJ], a_c8[AJ];
   bool a_ok[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int g = wave * AJ + j;
     const int row = g * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
+    a_c8[j] = c * 8;
     const int m = m0 + row;
     a_ok[j] = m < a.Mp;
     const uint32_t mm = a_ok[j] ? (uint32_t)m : 0u;
@@ -139,13 +140,14 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     a_iw[j] = (a.U == 2) ? owp + bw : owp * a.S + bw;
     a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.Ci + c * 8;
   }
-  int b_off[BJ];
+  int b_off[BJ], b_c8[BJ];
   bool b_ok[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int g = wave * BJ + j;
     const int row = g * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
+    b_c8[j] = c * 8;
     b_ok[j] = (n0 + row) < a.Co;
     b_off[j] = (n0 + row) * a.Kp + c * 8;
   }
@@ -161,16 +163,19 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
     const int koff = ((r0 + a.U * st_ri) * a.kw + (s0 + a.U * st_si)) * a.Ci + st_cb * 64;
     bf16_t* Ab = Abuf(buf) + (wave * AJ) * 512;
     bf16_t* Bb = Bbuf(buf) + (wave * BJ) * 512;
+    const int crem = a.Ci - st_cb * 64;   // channels left in this block (< 64 only for the last
+                                          // block of a channel count that is not a multiple of 64)
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const bool ok = a_ok[j] && (unsigned)(a_ih[j] + st_ri) < (unsigned)a.Hin &&
+      const bool ok = a_ok[j] && a_c8[j] < crem &&
+                      (unsigned)(a_ih[j] + st_ri) < (unsigned)a.Hin &&
                       (unsigned)(a_iw[j] + st_si) < (unsigned)a.Win;
       const bf16_t* p = ok ? a.in + (int64_t)(a_off[j] + tapoff) : zero;
       glds16(p, Ab + j * 512);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const bf16_t* p = b_ok[j] ? a.bt + (int64_t)(b_off[j] + koff) : zero;
+      const bf16_t* p = (b_ok[j] && b_c8[j] < crem) ? a.bt + (int64_t)(b_off[j] + koff) : zero;
       glds16(p, Bb + j * 512);
     }
     if (++st_cb == a.cblocks) {
@@ -741,7 +746,8 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
       const int ohp = (int)(t1 - n * a.Hp);
       const int ih = (a.U == 2) ? ohp + bh : ohp * a.S + bh;
       const int iw = (a.U == 2) ? owp + bw : owp * a.S + bw;
-      const bool xok = mok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const bool xok = mok && (cb * TKC + xchunk * 8) < a.Ci && (unsigned)ih < (unsigned)a.Hin &&
+                       (unsigned)iw < (unsigned)a.Win;
       const int64_t xoff =
           ((int64_t)((int)n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * TKC + xchunk * 8;
       glds16(xok ? a.in + xoff : zero, Xb + j * 512);
@@ -850,7 +856,9 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
       if (co >= a.Co) continue;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int k = kbase + wk * (TKC / 2) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        const int kl = wk * (TKC / 2) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (cb * TKC + kl >= a.Ci) continue;   // padding rows of a partial channel block
+        const int k = kbase + kl;
         const int64_t o = (int64_t)k * a.Co + co;
         if (direct && a.accumulate)
           outp[o] += acc[i][j][v];
@@ -1242,7 +1250,7 @@ static int ilog2x(int x);
 
 bool cg_fast_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                             float slope_in) {
-  if (g->Ci % 64 != 0) return false;
+  if (g->Ci % 32 != 0) return false;   // 64-channel K slices; the last one may be half empty
   if (!phase_ok(g)) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   if ((int64_t)g->N * g->Hin * g->Win * g->Ci >= (1ll << 31)) return false;
@@ -1268,7 +1276,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.Kp = (g->kh * g->kw * g->Ci + 7) & ~7;
   a.Hp = g->Ho / g->U; a.Wp = g->Wo / g->U;
   a.Mp = g->N * a.Hp * a.Wp;
-  a.cblocks = g->Ci / 64;
+  a.cblocks = (g->Ci + 63) / 64;
   a.relu_in = gate_in != nullptr;
   a.out_f32 = out_is_f32;
   a.slope_out = slope_out;
@@ -1281,7 +1289,7 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     const char* e = getenv("CGAMD_HALO");
     return e ? atoi(e) : 0;
   }();
-  if (use_halo && g->S == 1 && g->Co > 64 && g->kh * g->kw >= 4 && (a.Hp & (a.Hp - 1)) == 0 &&
+  if (use_halo && (g->Ci % 64) == 0 && g->S == 1 && g->Co > 64 && g->kh * g->kw >= 4 && (a.Hp & (a.Hp - 1)) == 0 &&
       (a.Wp & (a.Wp - 1)) == 0 && a.Hp >= 4 && a.Wp >= 4 && g->kh <= 5 && g->kw <= 5) {
     HaloArgs h;
     h.in = a.in; h.bt = a.bt; h.out = a.out; h.bias = a.bias;
@@ -1530,7 +1538,7 @@ static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, con
 
 bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                              float slope_in, const void* gate_dy) {
-  if (g->Ci % 64 != 0 || g->Co % 8 != 0) return false;
+  if (g->Ci % 32 != 0 || g->Co % 8 != 0) return false;
   if (!phase_ok(g)) return false;
   if (gate_dy) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
@@ -1541,7 +1549,7 @@ bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* ga
 void cg_fast_wgrad_plan(const cgConvGeom* g, int* splits, int* rows_per_split) {
   const int Mp = g->N * (g->Ho / g->U) * (g->Wo / g->U);
   const int tkc = (g->Ci % 128 == 0) ? 128 : 64;
-  const int tiles = g->kh * g->kw * (g->Ci / tkc) * cdiv(g->Co, 128);
+  const int tiles = g->kh * g->kw * cdiv(g->Ci, tkc) * cdiv(g->Co, 128);
   // each split costs one fp32 partial image of the whole weight (written, then re-read by the
   // reduce): only split as far as filling the chip needs, and never below 8 row slices per split
   int s = cdiv(384, tiles);
@@ -1582,7 +1590,7 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
   a.Mp = g->N * a.Hp * a.Wp;
   a.K = g->kh * g->kw * g->Ci;
   const int tkc = (g->Ci % 128 == 0) ? 128 : 64;
-  a.cblocks = g->Ci / tkc;
+  a.cblocks = cdiv(g->Ci, tkc);
   a.ktiles = g->kh * g->kw * a.cblocks;
   a.ntiles = cdiv(g->Co, 128);
   a.rows_per_split = rps;

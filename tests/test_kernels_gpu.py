@@ -66,6 +66,11 @@ CONV_CASES = [
     ("fast_s2_5x5", 2, 16, 16, 128, 128, 5, 2, 1),
     ("fast_s2_3x3", 4, 16, 16, 256, 256, 3, 2, 1),
     ("fast_1x1_wide", 2, 16, 16, 192, 384, 1, 1, 1),
+    # channel counts that are multiples of 32 but not 64 (BigGAN ch = 96): half-empty last K slice
+    ("c32", 2, 8, 8, 32, 64, 3, 1, 1),
+    ("c96_big", 4, 16, 16, 96, 96, 3, 1, 1),
+    ("c160_up", 2, 8, 8, 160, 96, 3, 1, 2),
+    ("c96_s2", 2, 16, 16, 96, 192, 4, 2, 1),
 ]
 
 
