@@ -96,6 +96,7 @@ enum {
   CG_PROF_FAST_CONV_128x32,       // fast_conv_kernel<128, 32, *>
   CG_PROF_STEM_FWD,               // stem_fwd_kernel<*>
   CG_PROF_GCONV_GENERIC,          // gconv_kernel<...> (channel counts not a multiple of 64, leaky gates)
+  CG_PROF_HALO_WGRAD,             // halo_wgrad_kernel<*> (+ split reduce)
   CG_PROF_FAST_WGRAD_128,         // fast_wgrad_kernel<128, *> (+ split reduce)
   CG_PROF_FAST_WGRAD_64,          // fast_wgrad_kernel<64, *> (+ split reduce)
   CG_PROF_STEM_WGRAD,             // stem_wgrad_kernel<*> incl. the narrow-output (adjoint) form

@@ -26,7 +26,7 @@
 
 #include <stdlib.h>
 
-#define CG_FAST_BIAS_SPLITS 64
+#define CG_FAST_BIAS_SPLITS 512
 
 namespace {
 
@@ -1163,6 +1163,216 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
   if (a.want_bias && tid < 128 && c0 + tid < a.Co) outp[(int64_t)a.K * a.Co + c0 + tid] = bias_acc;
 }
 
+// -------------------------------------------------------------------------------------------
+// weight gradient, "halo" form for unit-stride multi-tap filters (3x3): fast_wgrad_kernel handles one
+// tap per workgroup, so the activations and the output gradients are re-read once per tap (9x).
+// Here a workgroup owns a 64-channel x 64-out-channel block of ALL taps: per 64-pixel slice it
+// stages the input window (with its halo) and the dy slice once, and every tap's operand is a
+// shifted transpose-read of that window.  9 accumulator tiles per wave (144 registers).
+// -------------------------------------------------------------------------------------------
+struct HaloWgradArgs {
+  const bf16_t* in;
+  const bf16_t* dy;
+  float* out;   // dw (splits == 1) or partials [splits][K*Co]
+  float* bias;  // nullptr, dbias (splits == 1) or partials [splits][Co]
+  int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, pt, pl;
+  int K, cblocks, ntiles;
+  int tw_log, th_log, NI, tiles_x, tiles_y, nslices, slices_per_split;
+  int relu_in, accumulate, dbg;
+  FastDiv dNt, dTx, dTy;
+};
+constexpr int HW_GROUPS = 20;   // halo staging groups (8 rows each) per buffer: up to 160 pixels
+constexpr int HW_SLOTS = HW_GROUPS / 4;
+
+template <bool RELU, bool W4>
+__global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (HW_GROUPS * 512 + 64 * 64)];
+  auto Xh = [&](int buf) { return smem + buf * (HW_GROUPS * 512 + 64 * 64); };
+  auto Ys = [&](int buf) { return smem + buf * (HW_GROUPS * 512 + 64 * 64) + HW_GROUPS * 512; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int cb = (int)fdiv((uint32_t)blockIdx.x, a.dNt);
+  const int nt = blockIdx.x - cb * a.ntiles;
+  const int c0 = nt * 64;
+  const int TW = 1 << a.tw_log, TH = 1 << a.th_log;
+  constexpr int ntaps = 9;   // 3x3 only: the tap loops must unroll
+  const int HH = TH + 2, HW = TW + 2, hhw = HH * HW;
+  const int hrows = a.NI * hhw;
+  const int gpt = ((hrows + 7) / 8 + 3) / 4;   // <= HW_SLOTS
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  // LDS rows are 128 B (64 channels); 16-B chunk c of row r sits at chunk c ^ (((r >> 1) & 1) << 2),
+  // i.e. byte ^ ((r & 2) << 5): any 4 consecutive rows of a transpose read then hit distinct banks,
+  // whatever the parity of the first row (odd tap shifts), and rows r, r + 4 differ by 512 B exactly.
+  // halo staging slots: row (j*4 + wave)*8 + (lane >> 3); descriptor packed
+  // il | hy << 4 | hx << 10 | chunk << 16 | valid << 20
+  int hdesc[HW_SLOTS];
+#pragma unroll
+  for (int j = 0; j < HW_SLOTS; ++j) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (((row >> 1) & 1) << 2);
+    const int il = row / hhw;
+    const int rem = row - il * hhw;
+    const int hy = rem / HW, hx = rem - hy * HW;
+    const int ok = j < gpt && row < hrows && (cb * 64 + c * 8) < a.Ci;
+    hdesc[j] = il | (hy << 4) | (hx << 10) | (c << 16) | (ok << 20);
+  }
+  // dy staging: row (wave*2 + j)*8 + (lane >> 3) = pixel of the slice; il | y << 4 | x << 10 | chunk << 16
+  int ydesc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (wave * 2 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (((p >> 1) & 1) << 2);
+    ydesc[j] = (p >> (a.tw_log + a.th_log)) | (((p >> a.tw_log) & (TH - 1)) << 4) |
+               ((p & (TW - 1)) << 10) | (c << 16);
+  }
+  auto stage = [&](int buf, int sl) {
+    // slice -> (image group, tile row, tile col): wave-uniform
+    const int t1 = (int)fdiv((uint32_t)sl, a.dTx);
+    const int tx = sl - t1 * a.tiles_x;
+    const int ig = (int)fdiv((uint32_t)t1, a.dTy);
+    const int ty = t1 - ig * a.tiles_y;
+    bf16_t* Xb = Xh(buf);
+    bf16_t* Yb = Ys(buf) + (wave * 2) * 512;
+    const int n0 = ig * a.NI, ih0 = ty * TH - a.pt, iw0 = tx * TW - a.pl;
+#pragma unroll
+    for (int j = 0; j < HW_SLOTS; ++j) {
+      if (j < gpt) {
+        const int d = hdesc[j];
+        const int n = n0 + (d & 15);
+        const int ih = ih0 + ((d >> 4) & 63), iw = iw0 + ((d >> 10) & 63);
+        const bool ok = (d >> 20) && n < a.N && (unsigned)ih < (unsigned)a.Hin &&
+                        (unsigned)iw < (unsigned)a.Win;
+        const int64_t off =
+            ((int64_t)(n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * 64 + ((d >> 16) & 7) * 8;
+        glds16(ok ? a.in + off : zero, Xb + (j * 4 + wave) * 512);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int d = ydesc[j];
+      const int n = n0 + (d & 15);
+      const int oh = ty * TH + ((d >> 4) & 63), ow = tx * TW + ((d >> 10) & 63);
+      const int c8 = ((d >> 16) & 7) * 8;
+      const bool ok = n < a.N && (c0 + c8) < a.Co;
+      const int64_t off = ((int64_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co + c0 + c8;
+      glds16(ok ? a.dy + off : zero, Yb + j * 512);
+    }
+  };
+
+  f32x16_t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+  // bias gradient = column sums of dy: one more MFMA per k-step with an all-ones A operand, in the
+  // workgroups of channel block 0 only (wave-uniform)
+  const bool want_bias = a.bias != nullptr && cb == 0;
+  f32x16_t accb;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) accb[v] = 0.f;
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  // transpose-read addressing (see fast_wgrad_kernel): for k-step mm this lane supplies pixel
+  // p = mm*16 + (lane >> 5)*8 + (l16 >> 2) (lo read) and p + 4 (hi read: the same tile row, +512 B,
+  // when tiles are >= 8 pixels wide), 4 columns at tcol
+  const int l16 = lane & 15;
+  const int tcol = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+  const int xcolb = (wk * 32 + tcol) * 2, ycolb = (wn * 32 + tcol) * 2;   // byte column
+  int hr00[4];   // halo row of the tap-(0,0) input pixel of p
+  int yoff[4];   // byte offset of the dy read
+#pragma unroll
+  for (int mm = 0; mm < 4; ++mm) {
+    const int p = mm * 16 + (lane >> 5) * 8 + (l16 >> 2);
+    const int il = p >> (a.tw_log + a.th_log);
+    const int y = (p >> a.tw_log) & (TH - 1), x = p & (TW - 1);
+    hr00[mm] = il * hhw + y * HW + x;
+    yoff[mm] = ((p << 7) | ycolb) ^ ((p & 2) << 5);
+  }
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+  const int sbeg = blockIdx.y * a.slices_per_split;
+  const int send = min(a.nslices, sbeg + a.slices_per_split);
+  if (sbeg < send) {
+    stage(0, sbeg);
+    wait_vmcnt<0>();
+  }
+  __syncthreads();
+  for (int sl = sbeg; sl < send; ++sl) {
+    const int buf = (sl - sbeg) & 1;
+    if (sl + 1 < send && !(a.dbg & 2)) stage(buf ^ 1, sl + 1);
+    lds_char_ptr Xb = (lds_char_ptr)Xh(buf);
+    if (a.dbg & 4) { wait_vmcnt<0>(); __syncthreads(); continue; }
+    lds_char_ptr Yb = (lds_char_ptr)Ys(buf);
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+      bf16x8_t yf;
+      {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(Yb + yoff[mm]));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(Yb + yoff[mm] + 512));
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        yf = __builtin_bit_cast(bf16x8_t, v);
+      }
+      if (want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yf, accb, 0, 0, 0);
+      // keep the 9 x 4 tap addresses out of registers: recompute them from hr00 in every slice
+      int hq = hr00[mm];
+      asm volatile("" : "+v"(hq));
+      bf16x8_t xf[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int h = hq + (t / 3) * HW + (t % 3);
+        const int off = ((h << 7) | xcolb) ^ ((h & 2) << 5);
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(Xb + off));
+        s16x4_t hi;
+        if (W4) {
+          // 4-pixel-wide tiles: pixel p + 4 is the next tile row, HW (not 4) window rows further
+          const int h2 = h + HW;
+          const int off2 = ((h2 << 7) | xcolb) ^ ((h2 & 2) << 5);
+          hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(Xb + off2));
+        } else {
+          hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(Xb + off + 512));
+        }
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        xf[t] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (RELU) xf[t] = relu_bf16x8(xf[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[t], yf, acc[t], 0, 0, 0);
+      }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+  }
+
+  const bool direct = (gridDim.y == 1);
+  float* outp = a.out + (direct ? 0 : (int64_t)blockIdx.y * a.K * a.Co);
+  const int co = c0 + wn * 32 + (lane & 31);
+  if (co < a.Co) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int ch = cb * 64 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (ch >= a.Ci) continue;
+        if ((a.dbg & 1) && acc[t][v] == acc[t][v]) continue;
+        const int64_t o = ((int64_t)t * a.Ci + ch) * a.Co + co;
+        if (direct && a.accumulate)
+          outp[o] += acc[t][v];
+        else
+          outp[o] = acc[t][v];
+      }
+    }
+    // every row of accb holds the column sums; row 0 lives in accb[0] of lanes 0..31
+    if (want_bias && wk == 0 && lane < 32) {
+      float* bp = a.bias + (direct ? 0 : (int64_t)blockIdx.y * a.Co) + co;
+      *bp = (direct && a.accumulate) ? *bp + accb[0] : accb[0];
+    }
+  }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_z part[z * stride + i]; block = 32 outputs x 8 split lanes
 __global__ __launch_bounds__(256) void split_reduce_strided_kernel(const float* __restrict__ part,
                                                                    int splits, int64_t stride,
@@ -1205,6 +1415,49 @@ __global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restr
   *o = s;
 }
 
+// same sum, 8 split lanes per output float4: the serial loop over the partials is 8x shorter and 4
+// loads are in flight per thread (a single thread walking 128 partials is pure HBM latency)
+__global__ __launch_bounds__(256) void split_reduce4x8_kernel(const float* __restrict__ part,
+                                                              int splits, int64_t n4,
+                                                              float* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ float4 sm[8][32];
+  const int il = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + il;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p4 = reinterpret_cast<const float4*>(part) + i;
+#pragma unroll 4
+    for (int z = zl; z < splits; z += 8) {
+      const float4 p = p4[(int64_t)z * n4];
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+  }
+  sm[zl][il] = s;
+  __syncthreads();
+  if (zl == 0 && i < n4) {
+    float4 t = sm[0][il];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const float4 q = sm[r][il];
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out) + i;
+    if (accumulate) {
+      const float4 q = *o;
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    *o = t;
+  }
+}
+static void launch_split_reduce4(const float* part, int splits, int64_t n4, float* out,
+                                 int accumulate, hipStream_t st) {
+  if (splits >= 8)
+    split_reduce4x8_kernel<<<cdiv(n4, 32), 256, 0, st>>>(part, splits, n4, out, accumulate);
+  else
+    split_reduce4_kernel<<<cdiv(n4, 256), 256, 0, st>>>(part, splits, n4, out, accumulate);
+}
+
 // part[z][c] = sum over rows [z*rps, (z+1)*rps) of y[row][c]   (bias gradient when the weight
 // gradient itself only visits one output phase per tap); 8 channels per thread, 8 rows in flight
 __global__ __launch_bounds__(256) void colsum_part8_kernel(const bf16_t* __restrict__ y,
@@ -1218,6 +1471,7 @@ __global__ __launch_bounds__(256) void colsum_part8_kernel(const bf16_t* __restr
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = 0.f;
   if (cv * 8 < C) {
+#pragma unroll 4
     for (int64_t r = r0 + rl; r < r1; r += 8) {
       union { uint4 q; bf16_t h[8]; } v;
       v.q = *reinterpret_cast<const uint4*>(y + r * C + (int64_t)cv * 8);
@@ -1564,9 +1818,56 @@ void cg_fast_wgrad_plan(const cgConvGeom* g, int* splits, int* rows_per_split) {
   *rows_per_split = rps;
 }
 
+static bool halo_wgrad_ok(const cgConvGeom* g) {
+  static const int off = [] {
+    const char* e = getenv("CGAMD_NO_HALO_WGRAD");
+    return e ? atoi(e) : 0;
+  }();
+  return !off && g->S == 1 && g->U == 1 && g->kh == 3 && g->kw == 3 &&
+         (g->Ho & (g->Ho - 1)) == 0 && (g->Wo & (g->Wo - 1)) == 0 && g->Ho >= 4 && g->Wo >= 4 &&
+         g->Ho == g->Hin && g->Wo == g->Win;
+}
+
+struct HaloWgradPlan {
+  int TW, TH, NI, tiles_x, tiles_y, img_groups, nslices, splits, sps;
+};
+static HaloWgradPlan halo_wgrad_plan(const cgConvGeom* g) {
+  HaloWgradPlan p;
+  p.TW = g->Wo < 16 ? g->Wo : 16;
+  p.TH = 64 / p.TW;
+  if (p.TH > g->Ho) p.TH = g->Ho;
+  p.NI = 64 / (p.TW * p.TH);
+  p.tiles_x = g->Wo / p.TW;
+  p.tiles_y = g->Ho / p.TH;
+  p.img_groups = cdiv(g->N, p.NI);
+  p.nslices = p.img_groups * p.tiles_y * p.tiles_x;
+  const int tiles = cdiv(g->Ci, 64) * cdiv(g->Co, 64);
+  // two resident workgroups per CU hide the staging latency; every split costs a K x Co fp32 partial
+  static const int target = [] {
+    const char* e = getenv("CGAMD_HALO_BLOCKS");
+    return e ? atoi(e) : 512;
+  }();
+  int s = cdiv(target, tiles);
+  const int max_by = p.nslices / 4 > 0 ? p.nslices / 4 : 1;   // >= 4 slices per split
+  if (s > max_by) s = max_by;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  p.sps = cdiv(p.nslices, s);
+  p.splits = cdiv(p.nslices, p.sps);
+  return p;
+}
+
 size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g) {
   int splits, rps;
   cg_fast_wgrad_plan(g, &splits, &rps);
+  if (halo_wgrad_ok(g)) {
+    const HaloWgradPlan p = halo_wgrad_plan(g);
+    const size_t K = (size_t)g->kh * g->kw * g->Ci;
+    size_t need = p.splits > 1 ? (size_t)p.splits * (K + 1) * g->Co * sizeof(float) : 256;
+    const size_t bias_need = (size_t)CG_FAST_BIAS_SPLITS * g->Co * sizeof(float);
+    if (need < bias_need) need = bias_need;
+    return align_up(need, 256);
+  }
   const size_t K = (size_t)g->kh * g->kw * g->Ci;
   size_t need = 256;
   if (splits > 1) need = (size_t)splits * (K * g->Co + g->Co) * sizeof(float);
@@ -1578,6 +1879,47 @@ size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g) {
 void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
                           const void* dy, float* dw, int accumulate, float* dbias, void* ws,
                           hipStream_t st) {
+  if (halo_wgrad_ok(g)) {
+    const HaloWgradPlan p = halo_wgrad_plan(g);
+    HaloWgradArgs h;
+    h.in = (const bf16_t*)in; h.dy = (const bf16_t*)dy;
+    h.N = g->N; h.Hin = g->Hin; h.Win = g->Win; h.Ci = g->Ci; h.Ho = g->Ho; h.Wo = g->Wo;
+    h.Co = g->Co; h.kh = g->kh; h.kw = g->kw; h.pt = g->pt; h.pl = g->pl;
+    h.K = g->kh * g->kw * g->Ci;
+    h.cblocks = cdiv(g->Ci, 64); h.ntiles = cdiv(g->Co, 64);
+    h.tw_log = ilog2x(p.TW); h.th_log = ilog2x(p.TH); h.NI = p.NI;
+    h.tiles_x = p.tiles_x; h.tiles_y = p.tiles_y; h.nslices = p.nslices;
+    h.slices_per_split = p.sps;
+    h.relu_in = gate_in != nullptr; h.accumulate = accumulate;
+    static const int dbg = [] {
+      const char* e = getenv("CGAMD_HALO_DBG");
+      return e ? atoi(e) : 0;
+    }();
+    h.dbg = dbg;
+    h.dNt = make_fastdiv(h.ntiles); h.dTx = make_fastdiv(p.tiles_x);
+    h.dTy = make_fastdiv(p.tiles_y);
+    float* wsf = (float*)ws;
+    const size_t KC = (size_t)h.K * g->Co;
+    h.out = p.splits == 1 ? dw : wsf;
+    h.bias = !dbias ? nullptr : (p.splits == 1 ? dbias : wsf + (size_t)p.splits * KC);
+    dim3 grid(h.cblocks * h.ntiles, p.splits);
+    CgProfScope prof(CG_PROF_HALO_WGRAD, g, st);
+    const bool w4 = p.TW == 4;
+    if (h.relu_in) {
+      if (w4) halo_wgrad_kernel<true, true><<<grid, 256, 0, st>>>(h);
+      else halo_wgrad_kernel<true, false><<<grid, 256, 0, st>>>(h);
+    } else {
+      if (w4) halo_wgrad_kernel<false, true><<<grid, 256, 0, st>>>(h);
+      else halo_wgrad_kernel<false, false><<<grid, 256, 0, st>>>(h);
+    }
+    if (p.splits > 1) {
+      const int64_t n4 = (int64_t)(KC / 4);
+      launch_split_reduce4(wsf, p.splits, n4, dw, accumulate, st);
+      if (dbias)
+        launch_split_reduce4(wsf + (size_t)p.splits * KC, p.splits, g->Co / 4, dbias, accumulate, st);
+    }
+    return;
+  }
   int splits, rps;
   cg_fast_wgrad_plan(g, &splits, &rps);
   FastWgradArgs a;
@@ -1626,10 +1968,9 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
   const int64_t c4 = g->Co / 4;
   if (splits > 1) {
     const int64_t n4 = (int64_t)(KC / 4);  // Ci % 64 == 0 and Co % 8 == 0 -> divisible
-    split_reduce4_kernel<<<cdiv(n4, 256), 256, 0, st>>>(wsf, splits, n4, dw, accumulate);
+    launch_split_reduce4(wsf, splits, n4, dw, accumulate, st);
     if (bias_in_kernel)
-      split_reduce4_kernel<<<cdiv(c4, 256), 256, 0, st>>>(wsf + (size_t)splits * KC, splits, c4,
-                                                         dbias, accumulate);
+      launch_split_reduce4(wsf + (size_t)splits * KC, splits, c4, dbias, accumulate, st);
   }
   if (dbias && !bias_in_kernel) {
     // stream-ordered after the reduce above: the partial area of the workspace is free again
@@ -1640,6 +1981,6 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     bs = (int)((rows + rps - 1) / rps);
     dim3 bgrid(cdiv(g->Co / 8, 32), bs);
     colsum_part8_kernel<<<bgrid, 256, 0, st>>>((const bf16_t*)dy, rows, g->Co, rps, wsf);
-    split_reduce4_kernel<<<cdiv(c4, 256), 256, 0, st>>>(wsf, bs, c4, dbias, accumulate);
+    launch_split_reduce4(wsf, bs, c4, dbias, accumulate, st);
   }
 }

@@ -433,7 +433,7 @@ class ModularGAN(AbstractGAN):
     run(images, labels) -> same dict as train_step."""
     import os
     # weight gradients become a parallel branch of the graph (CGAMD_NO_WGRAD_STREAM=1: A/B switch)
-    Fn.enable_wgrad_stream(os.environ.get("CGAMD_NO_WGRAD_STREAM", "") != "1")
+    Fn.enable_wgrad_stream(os.environ.get("CGAMD_WGRAD_STREAM", "") == "1")
     nsub = self._disc_iters + 1
     shape = (nsub * self.batch_size,) + tuple(self._dataset.image_shape)
     self._static_images = torch.zeros(shape, dtype=torch.float32, device=self.device)

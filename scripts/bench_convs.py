@@ -17,6 +17,10 @@ SHAPES = {
         (64, 4, 4, 256, 256, 3, 1, 2, 0), (64, 1, 1, 128, 4096, 1, 1, 1, 0),
         (128, 32, 32, 3, 128, 3, 1, 1, 1), (64, 32, 32, 256, 3, 3, 1, 1, 0),
     ],
+    "halo": [
+        (128, 32, 32, 128, 128, 3, 1, 1, 1), (64, 32, 32, 256, 256, 3, 1, 1, 0),
+        (128, 16, 16, 128, 128, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
+    ],
     "probe": [
         (128, 32, 32, 64, 128, 1, 1, 1, 0), (128, 32, 32, 128, 128, 1, 1, 1, 0),
         (128, 32, 32, 256, 128, 1, 1, 1, 0), (128, 32, 32, 512, 128, 1, 1, 1, 0),

@@ -71,6 +71,14 @@ CONV_CASES = [
     ("c96_big", 4, 16, 16, 96, 96, 3, 1, 1),
     ("c160_up", 2, 8, 8, 160, 96, 3, 1, 2),
     ("c96_s2", 2, 16, 16, 96, 192, 4, 2, 1),
+    # all-taps (halo) weight gradient: 4-wide tiles with 4 images per slice (batch not a multiple
+    # of 4), 8x8 tiles, 16x4 tiles over several tile rows / columns, many splits
+    ("halo_4x4", 6, 4, 4, 128, 64, 3, 1, 1),
+    ("halo_4x4_c96", 5, 4, 4, 96, 160, 3, 1, 1),
+    ("halo_8x8", 3, 8, 8, 64, 128, 3, 1, 1),
+    ("halo_64x64", 2, 64, 64, 64, 64, 3, 1, 1),
+    ("halo_4x16", 3, 4, 16, 64, 72, 3, 1, 1),
+    ("halo_16x4", 3, 16, 4, 64, 64, 3, 1, 1),
 ]
 
 
