@@ -85,30 +85,34 @@ __global__ __launch_bounds__(256) void bn_stats_part_scalar_kernel(const bf16_t*
     p[C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
   }
 }
-// one block per 32 channels: 8 split-lanes per channel sum the partials, LDS combines them.
+// one block per 32 channels: BN_ZL split-lanes per channel sum the partials (4 loads in flight each:
+// a short serial walk, the finalize is pure load latency), LDS combines them.
 // Optionally folds the moving-average update m <- m - (1-decay)(m - batch) (arch_ops.py:105-114).
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part,
+constexpr int BN_ZL = 32;
+__global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_kernel(const float* __restrict__ part,
                                                              int splits, int C, float inv_rows,
                                                              float* __restrict__ mean,
                                                              float* __restrict__ var,
                                                              float* __restrict__ mm,
                                                              float* __restrict__ mv, float decay) {
-  __shared__ float sm[2][8][33];
+  __shared__ float sm[2][BN_ZL][33];
   const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f, q = 0.f;
-  if (c < C)
-    for (int z = zl; z < splits; z += 8) {
+  if (c < C) {
+#pragma unroll 4
+    for (int z = zl; z < splits; z += BN_ZL) {
       s += part[(int64_t)z * 2 * C + c];
       q += part[(int64_t)z * 2 * C + C + c];
     }
+  }
   sm[0][zl][cl] = s;
   sm[1][zl][cl] = q;
   __syncthreads();
   if (zl == 0 && c < C) {
     float ss = 0.f, qq = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < BN_ZL; ++r) {
       ss += sm[0][r][cl];
       qq += sm[1][r][cl];
     }
@@ -281,19 +285,20 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(
     p[(int64_t)N * C + (int64_t)n * C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
   }
 }
-// finalize: block = 32 channels x 8 lanes.  per-sample: lanes split the samples (each sample's
+// finalize: block = 32 channels x BN_ZL lanes.  per-sample: lanes split the samples (each sample's
 // dgamma/dbeta is complete after the hw-split sum); otherwise lanes split (n, z) jointly.
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(
+__global__ __launch_bounds__(32 * BN_ZL) void bn_bwd_final_kernel(
     const float* __restrict__ part, int hsplits, int N, int C, float inv_rows,
     const float* __restrict__ gamma, int per_sample, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ m12) {
-  __shared__ float sm[2][8][33];
+  __shared__ float sm[2][BN_ZL][33];
   const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float a1 = 0.f, a2 = 0.f;
   if (c < C) {
-    for (int n = zl; n < N; n += 8) {
+    for (int n = zl; n < N; n += BN_ZL) {
       float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
       for (int z = 0; z < hsplits; ++z) {
         const float* p = part + (int64_t)z * 2 * N * C;
         s1 += p[(int64_t)n * C + c];
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
   if (zl == 0 && c < C) {
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < BN_ZL; ++r) {
       t1 += sm[0][r][cl];
       t2 += sm[1][r][cl];
     }
@@ -471,7 +476,7 @@ extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, floa
     bn_stats_part_scalar_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, C, rps, (float*)ws);
   }
   CG_CHECK_LAUNCH("cg_bn_stats(part)");
-  bn_stats_final_kernel<<<cdiv(C, 32), 256, 0, st>>>((const float*)ws, splits, C,
+  bn_stats_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>((const float*)ws, splits, C,
                                                      1.0f / (float)rows, mean, var, moving_mean,
                                                      moving_var, decay);
   CG_CHECK_LAUNCH("cg_bn_stats(final)");
@@ -530,7 +535,7 @@ extern "C" int cg_bn_backward_reduce(const void* x, const void* y, const void* d
                                              part);
   }
   CG_CHECK_LAUNCH("cg_bn_backward_reduce(sums)");
-  bn_bwd_final_kernel<<<cdiv(C, 32), 256, 0, st>>>(part, hs, N, C,
+  bn_bwd_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(part, hs, N, C,
                                                     1.0f / ((float)N * (float)HW), gamma,
                                                     per_sample, dgamma, dbeta, m12);
   CG_CHECK_LAUNCH("cg_bn_backward_reduce(final)");

@@ -84,7 +84,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // workgroups per CU (the second hides the load latency); NS = 4 is for grids of about one workgroup
 // per CU, where only a deeper ring can hide it.
 template <int BM, int BN, bool RELU, int NS>
-__global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
+__global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastConvArgs a) {
   constexpr int WN = BN >= 128 ? 2 : 1;   // waves along the channel dimension
   constexpr int WM = 4 / WN;
   constexpr int AJ = BM / 32;             // A staging instructions per wave (8 rows of 128 B each)
@@ -92,7 +92,12 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   constexpr int TM = BM / WM / 32;        // 32-pixel MFMA tiles per wave
   constexpr int TN = BN / WN / 32;        // 32-channel MFMA tiles per wave
   constexpr int A_ELEMS = BM * 64, B_ELEMS = BN * 64;
-  __shared__ __attribute__((aligned(1024))) bf16_t smem[NS * (A_ELEMS + B_ELEMS)];
+  // NS = 1: one buffer, two barriers per K-slice, three workgroups per CU overlap each other;
+  // the staged epilogue needs (BM / WM) x (BN + 4) floats
+  constexpr int EPI_ELEMS = (BM / WM) * (BN + 4) * 2;
+  constexpr int RING_ELEMS = NS * (A_ELEMS + B_ELEMS);
+  __shared__ __attribute__((aligned(1024)))
+  bf16_t smem[RING_ELEMS > EPI_ELEMS || NS > 1 ? RING_ELEMS : EPI_ELEMS];
   constexpr int LOADS = AJ + BJ;   // LDS-DMA instructions per thread per stage
   constexpr int D = NS - 1;        // prefetch distance
 
@@ -207,6 +212,33 @@ __global__ __launch_bounds__(256) void fast_conv_kernel(FastConvArgs a) {
   int staged = 0;
   for (; staged < D && staged < nk; ++staged) stage(staged % NS);
 
+  if constexpr (NS == 1) {
+    for (int it = 0; it < nk; ++it) {
+      stage(0);
+      wait_vmcnt<0>();
+      __syncthreads();
+      const bf16_t* Ab = Abuf(0);
+      const bf16_t* Bb = Bbuf(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
+          if (RELU) af[i] = relu_bf16x8(af[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else
   for (int it = 0; it < nk; ++it) {
     // wait for slice `it` (the oldest in flight), then barrier: every wave's share of it has landed
     // and every wave has finished reading the buffer that is restaged below (slice it - 1's)
@@ -1178,7 +1210,7 @@ struct HaloWgradArgs {
   int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, pt, pl;
   int K, cblocks, ntiles;
   int tw_log, th_log, NI, tiles_x, tiles_y, nslices, slices_per_split;
-  int relu_in, accumulate, dbg;
+  int relu_in, accumulate;
   FastDiv dNt, dTx, dTy;
 };
 constexpr int HW_GROUPS = 20;   // halo staging groups (8 rows each) per buffer: up to 160 pixels
@@ -1302,9 +1334,8 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
   __syncthreads();
   for (int sl = sbeg; sl < send; ++sl) {
     const int buf = (sl - sbeg) & 1;
-    if (sl + 1 < send && !(a.dbg & 2)) stage(buf ^ 1, sl + 1);
+    if (sl + 1 < send) stage(buf ^ 1, sl + 1);
     lds_char_ptr Xb = (lds_char_ptr)Xh(buf);
-    if (a.dbg & 4) { wait_vmcnt<0>(); __syncthreads(); continue; }
     lds_char_ptr Yb = (lds_char_ptr)Ys(buf);
 #pragma unroll
     for (int mm = 0; mm < 4; ++mm) {
@@ -1357,7 +1388,6 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
       for (int v = 0; v < 16; ++v) {
         const int ch = cb * 64 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
         if (ch >= a.Ci) continue;
-        if ((a.dbg & 1) && acc[t][v] == acc[t][v]) continue;
         const int64_t o = ((int64_t)t * a.Ci + ch) * a.Co + co;
         if (direct && a.accumulate)
           outp[o] += acc[t][v];
@@ -1373,24 +1403,26 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
   }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_z part[z * stride + i]; block = 32 outputs x 8 split lanes
-__global__ __launch_bounds__(256) void split_reduce_strided_kernel(const float* __restrict__ part,
-                                                                   int splits, int64_t stride,
-                                                                   int64_t n,
-                                                                   float* __restrict__ out,
-                                                                   int accumulate) {
-  __shared__ float sm[8][33];
+// out[i] = (accumulate ? out[i] : 0) + sum_z part[z * stride + i]; block = 32 outputs x 32 split
+// lanes, 4 loads in flight per lane (the walk over the partials is pure load latency)
+constexpr int SR_ZL = 32;
+__global__ __launch_bounds__(32 * SR_ZL) void split_reduce_strided_kernel(
+    const float* __restrict__ part, int splits, int64_t stride, int64_t n, float* __restrict__ out,
+    int accumulate) {
+  __shared__ float sm[SR_ZL][33];
   const int il = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + il;
   float s = 0.f;
-  if (i < n)
-    for (int z = zl; z < splits; z += 8) s += part[(int64_t)z * stride + i];
+  if (i < n) {
+#pragma unroll 4
+    for (int z = zl; z < splits; z += SR_ZL) s += part[(int64_t)z * stride + i];
+  }
   sm[zl][il] = s;
   __syncthreads();
   if (zl == 0 && i < n) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += sm[r][il];
+    for (int r = 0; r < SR_ZL; ++r) t += sm[r][il];
     out[i] = accumulate ? out[i] + t : t;
   }
 }
@@ -1588,7 +1620,9 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     }
   }
   // ring depth: a grid of <= ~1.5 workgroups per CU cannot rely on a co-resident workgroup to hide
-  // the load latency -> deep ring; larger grids keep two workgroups per CU (64 KiB of LDS each)
+  // the load latency -> deep ring (NS = 4); grids of >= 3 workgroups per CU run single-buffered
+  // (NS = 1: 33 KiB of LDS, 3-4 co-resident workgroups overlap each other's loads, MFMA work and
+  // epilogues: +15-25 % on the 1024-workgroup shapes); in between, NS = 2 with two per CU
   static const int ns_env = [] {
     const char* e = getenv("CGAMD_CONV_NS");
     return e ? atoi(e) : 0;
@@ -1596,13 +1630,13 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
 #define CG_LAUNCH_CONV(BM_, BN_, GRID_)                                                  \
   do {                                                                                   \
     const int blocks_ = (GRID_).x * (GRID_).y;                                           \
-    const int ns_ = ns_env ? ns_env : (blocks_ <= 384 ? 4 : 2);                          \
+    const int ns_ = ns_env ? ns_env : (blocks_ <= 384 ? 4 : (blocks_ >= 768 ? 1 : 2));   \
     if (ns_ >= 4) {                                                                      \
       if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 4><<<GRID_, 256, 0, st>>>(a);      \
       else fast_conv_kernel<BM_, BN_, false, 4><<<GRID_, 256, 0, st>>>(a);               \
-    } else if (ns_ == 3) {                                                               \
-      if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 3><<<GRID_, 256, 0, st>>>(a);      \
-      else fast_conv_kernel<BM_, BN_, false, 3><<<GRID_, 256, 0, st>>>(a);               \
+    } else if (ns_ == 1) {                                                               \
+      if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 1><<<GRID_, 256, 0, st>>>(a);      \
+      else fast_conv_kernel<BM_, BN_, false, 1><<<GRID_, 256, 0, st>>>(a);               \
     } else {                                                                             \
       if (a.relu_in) fast_conv_kernel<BM_, BN_, true, 2><<<GRID_, 256, 0, st>>>(a);      \
       else fast_conv_kernel<BM_, BN_, false, 2><<<GRID_, 256, 0, st>>>(a);               \
@@ -1782,10 +1816,10 @@ static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, con
     default: stem_wgrad_kernel<128><<<grid, 256, 0, st>>>(a); break;
   }
   const int64_t KC = (int64_t)a.K * g->Co, stride = KC + g->Co;
-  split_reduce_strided_kernel<<<cdiv(KC, 32), 256, 0, st>>>((const float*)ws, splits, stride, KC,
+  split_reduce_strided_kernel<<<cdiv(KC, 32), 32 * SR_ZL, 0, st>>>((const float*)ws, splits, stride, KC,
                                                             dw, accumulate);
   if (dbias)
-    split_reduce_strided_kernel<<<cdiv(g->Co, 32), 256, 0, st>>>((const float*)ws + KC, splits,
+    split_reduce_strided_kernel<<<cdiv(g->Co, 32), 32 * SR_ZL, 0, st>>>((const float*)ws + KC, splits,
                                                                   stride, g->Co, dbias,
                                                                   accumulate);
 }
@@ -1891,11 +1925,6 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     h.tiles_x = p.tiles_x; h.tiles_y = p.tiles_y; h.nslices = p.nslices;
     h.slices_per_split = p.sps;
     h.relu_in = gate_in != nullptr; h.accumulate = accumulate;
-    static const int dbg = [] {
-      const char* e = getenv("CGAMD_HALO_DBG");
-      return e ? atoi(e) : 0;
-    }();
-    h.dbg = dbg;
     h.dNt = make_fastdiv(h.ntiles); h.dTx = make_fastdiv(p.tiles_x);
     h.dTy = make_fastdiv(p.tiles_y);
     float* wsf = (float*)ws;

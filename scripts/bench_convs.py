@@ -21,6 +21,11 @@ SHAPES = {
         (128, 32, 32, 128, 128, 3, 1, 1, 1), (64, 32, 32, 256, 256, 3, 1, 1, 0),
         (128, 16, 16, 128, 128, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
     ],
+    "fixed": [
+        (128, 8, 8, 128, 128, 3, 1, 1, 1), (128, 16, 16, 128, 128, 3, 1, 1, 1),
+        (128, 32, 32, 128, 128, 3, 1, 1, 1), (64, 32, 32, 256, 256, 3, 1, 1, 0),
+        (64, 8, 8, 256, 256, 3, 1, 1, 0),
+    ],
     "probe": [
         (128, 32, 32, 64, 128, 1, 1, 1, 0), (128, 32, 32, 128, 128, 1, 1, 1, 0),
         (128, 32, 32, 256, 128, 1, 1, 1, 0), (128, 32, 32, 512, 128, 1, 1, 1, 0),
