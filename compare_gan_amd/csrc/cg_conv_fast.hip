@@ -1449,13 +1449,18 @@ __global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restr
 
 // same sum, 8 split lanes per output float4: the serial loop over the partials is 8x shorter and 4
 // loads are in flight per thread (a single thread walking 128 partials is pure HBM latency)
-__global__ __launch_bounds__(256) void split_reduce4x8_kernel(const float* __restrict__ part,
-                                                              int splits, int64_t n4,
-                                                              float* __restrict__ out,
-                                                              int accumulate) {
+__global__ __launch_bounds__(256) void split_reduce4x8_kernel(
+    const float* __restrict__ part_a, int64_t n4_a, float* __restrict__ out_a, int blocks_a,
+    const float* __restrict__ part_b, int64_t n4_b, float* __restrict__ out_b, int splits,
+    int accumulate) {
+  // two reductions in one launch (weight gradient + bias gradient): blocks >= blocks_a do the second
   __shared__ float4 sm[8][32];
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const float* part = second ? part_b : part_a;
+  const int64_t n4 = second ? n4_b : n4_a;
+  float* out = second ? out_b : out_a;
   const int il = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  const int64_t i = (int64_t)blockIdx.x * 32 + il;
+  const int64_t i = (int64_t)(second ? blockIdx.x - blocks_a : blockIdx.x) * 32 + il;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float4* p4 = reinterpret_cast<const float4*>(part) + i;
@@ -1482,10 +1487,18 @@ __global__ __launch_bounds__(256) void split_reduce4x8_kernel(const float* __res
     *o = t;
   }
 }
+// weight-gradient partials (+ optionally the bias-gradient partials of the same splits) in one launch
+static void launch_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a,
+                                      const float* part_b, int64_t n4_b, float* out_b, int splits,
+                                      int accumulate, hipStream_t st) {
+  const int ba = cdiv(n4_a, 32), bb = out_b ? cdiv(n4_b, 32) : 0;
+  split_reduce4x8_kernel<<<ba + bb, 256, 0, st>>>(part_a, n4_a, out_a, ba, part_b, n4_b, out_b,
+                                                  splits, accumulate);
+}
 static void launch_split_reduce4(const float* part, int splits, int64_t n4, float* out,
                                  int accumulate, hipStream_t st) {
   if (splits >= 8)
-    split_reduce4x8_kernel<<<cdiv(n4, 32), 256, 0, st>>>(part, splits, n4, out, accumulate);
+    launch_split_reduce4_pair(part, n4, out, nullptr, 0, nullptr, splits, accumulate, st);
   else
     split_reduce4_kernel<<<cdiv(n4, 256), 256, 0, st>>>(part, splits, n4, out, accumulate);
 }
@@ -1665,7 +1678,13 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.ntiles = cdiv(g->Co, 128);
   a.dNt = make_fastdiv(a.ntiles);
   const int tiles128 = cdiv(a.Mp, 128) * a.ntiles * phases;
-  if (tiles128 >= 256) {
+  // 128x128 tiles only once they give > 2 workgroups per CU; below that 64x128 tiles double the
+  // grid, which buys more overlap than the larger tile saves in operand traffic (measured: -2 % step)
+  static const int t128_min = [] {
+    const char* e = getenv("CGAMD_CONV_T128_MIN");
+    return e ? atoi(e) : 513;
+  }();
+  if (tiles128 >= t128_min) {
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles * a.ntiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_128x128, g, st);
@@ -1943,9 +1962,8 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     }
     if (p.splits > 1) {
       const int64_t n4 = (int64_t)(KC / 4);
-      launch_split_reduce4(wsf, p.splits, n4, dw, accumulate, st);
-      if (dbias)
-        launch_split_reduce4(wsf + (size_t)p.splits * KC, p.splits, g->Co / 4, dbias, accumulate, st);
+      launch_split_reduce4_pair(wsf, n4, dw, wsf + (size_t)p.splits * KC, g->Co / 4, dbias,
+                                p.splits, accumulate, st);
     }
     return;
   }
@@ -1997,9 +2015,8 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
   const int64_t c4 = g->Co / 4;
   if (splits > 1) {
     const int64_t n4 = (int64_t)(KC / 4);  // Ci % 64 == 0 and Co % 8 == 0 -> divisible
-    launch_split_reduce4(wsf, splits, n4, dw, accumulate, st);
-    if (bias_in_kernel)
-      launch_split_reduce4(wsf + (size_t)splits * KC, splits, c4, dbias, accumulate, st);
+    launch_split_reduce4_pair(wsf, n4, dw, wsf + (size_t)splits * KC, c4,
+                              bias_in_kernel ? dbias : nullptr, splits, accumulate, st);
   }
   if (dbias && !bias_in_kernel) {
     // stream-ordered after the reduce above: the partial area of the workspace is free again

@@ -346,7 +346,8 @@ class ModularGAN(AbstractGAN):
       self.create_loss(features, labels)
     # torch.autograd.grad hands the gradients over directly: no AccumulateGrad nodes, whose
     # stream affinity would break hipGraph capture (they run on the stream they were created on)
-    grads = torch.autograd.grad(self.d_loss, self.d_opt.params, allow_unused=True)
+    grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
+                                allow_unused=True)
     self.d_opt.apply_gradients(self.global_step_disc, grads=self._fill_unused(self.d_opt, grads))
     K.counter_add(self.global_step_disc, 1)
     self.d_loss = self.d_loss.detach()
@@ -367,7 +368,8 @@ class ModularGAN(AbstractGAN):
         sampled_y = self._get_one_hot_labels(features["sampled_labels"])
       features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
-    grads = torch.autograd.grad(self.g_loss, self.g_opt.params, allow_unused=True)
+    grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
+                                allow_unused=True)
     self.g_opt.apply_gradients(self.global_step, ema_decay=self._ema_decay,
                                ema_start=self._ema_start_step,
                                grads=self._fill_unused(self.g_opt, grads))
@@ -376,6 +378,12 @@ class ModularGAN(AbstractGAN):
     self.g_loss = self.g_loss.detach()
     self.d_loss = self.d_loss.detach()
     return self.g_loss
+
+  def _unit_grad(self):
+    """d(loss)/d(loss) = 1, allocated once (autograd would launch a fill per backward pass)."""
+    if getattr(self, "_unit", None) is None:
+      self._unit = torch.ones((), dtype=torch.float32, device=self.device)
+    return self._unit
 
   @staticmethod
   def _fill_unused(opt_state, grads):

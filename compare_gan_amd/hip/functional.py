@@ -266,6 +266,7 @@ class SpectralNormBatchFn(torch.autograd.Function):
     ctx.modes = list(modes)
     ctx.n = len(weights)
     ctx.save_for_backward(*(w2 + u_news + vs + sigmas))
+    ctx.set_materialize_grads(False)
     return tuple(wb.view(w.shape) for wb, w in zip(wbars, weights))
 
   @staticmethod
@@ -322,11 +323,14 @@ class BatchNormActFn(torch.autograd.Function):
     ctx.cfg = (eps, per_sample, relu, batch_stats, shape, sync_fn)
     ctx.save_for_backward(x3, y3, gamma, mean, var)
     ctx.mark_non_differentiable(mean, var)
+    ctx.set_materialize_grads(False)   # no zero-fill launches for the moments' unused gradients
     return y3.reshape(shape), mean, var
 
   @staticmethod
   @torch.autograd.function.once_differentiable
   def backward(ctx, dy, _dm, _dv):
+    if dy is None:
+      return (None,) * 10
     x3, y3, gamma, mean, var = ctx.saved_tensors
     eps, per_sample, relu, batch_stats, shape, sync_fn = ctx.cfg
     dy3 = _bf16(dy).reshape(x3.shape)
@@ -618,7 +622,8 @@ class GanLossFn(torch.autograd.Function):
     losses, dd, dg = K.gan_loss(kind, logits.contiguous())
     ctx.save_for_backward(dd, dg)
     ctx.shape = logits.shape
-    return tuple(losses[i].clone() for i in range(4))
+    ctx.set_materialize_grads(False)   # only one of the four is differentiated per sub-step
+    return tuple(losses.unbind(0))
 
   @staticmethod
   @torch.autograd.function.once_differentiable
@@ -631,7 +636,7 @@ class GanLossFn(torch.autograd.Function):
         continue
       term = K.scale_f32(base, up.reshape(1).to(F32).contiguous())
       out = term if out is None else K.axpby_f32(out, 1.0, term, 1.0)
-    return out.reshape(ctx.shape), None
+    return (out.reshape(ctx.shape) if out is not None else None), None
 
 
 class GradientPenaltyFn(torch.autograd.Function):
