@@ -50,5 +50,29 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_timing():
+    """libcgamd_timing.so: the same library with -DCG_CONV_TIMING (s_memtime phase stamps in
+    fast_conv_kernel, read by scripts/conv_timing.py via CGAMD_LIB_PATH).  Debug aid only."""
+    odir = os.path.join(LIB_DIR, "obj_timing")
+    os.makedirs(odir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
+        cmd = [HIPCC] + FLAGS + ["-DCG_CONV_TIMING", "-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        objs.append(obj)
+    out = os.path.join(LIB_DIR, "libcgamd_timing.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--timing" in sys.argv:
+        print(build_timing())
+    else:
+        print(build(force="--force" in sys.argv))

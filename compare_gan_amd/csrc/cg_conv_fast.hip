@@ -73,7 +73,20 @@ struct FastConvArgs {
   int self_gate;  // gate_out == out: the output activation is applied to the value itself
   float slope_out;
   FastDiv dWp, dHp, dNt;
+#ifdef CG_CONV_TIMING
+  unsigned long long* tdbg;   // s_memtime stamps of workgroup 0 (scripts/conv_timing.py)
+#endif
 };
+#ifdef CG_CONV_TIMING
+#define TSTAMP()                                                                      \
+  do {                                                                                \
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && tsi < 250)       \
+      a.tdbg[wave * 256 + tsi] = __builtin_amdgcn_s_memtime();                        \
+    ++tsi;                                                                            \
+  } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -102,6 +115,10 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
   constexpr int D = NS - 1;        // prefetch distance
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CG_CONV_TIMING
+  int tsi = 0;
+#endif
+  TSTAMP();   // 0: kernel entry
   const int wm = wave / WN, wn = wave % WN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = (int)fdiv((uint32_t)wg, a.dNt);
@@ -210,7 +227,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
   const int brow0 = (wn * (BN / WN) + frow) * 64;
 
   int staged = 0;
+  TSTAMP();   // 1: descriptors done
   for (; staged < D && staged < nk; ++staged) stage(staged % NS);
+  TSTAMP();   // 2: prologue stages issued
 
   if constexpr (NS == 1) {
     for (int it = 0; it < nk; ++it) {
@@ -246,11 +265,14 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
     if (D >= 3 && ahead >= 2) wait_vmcnt<2 * LOADS>();
     else if (D >= 2 && ahead == 1) wait_vmcnt<LOADS>();
     else wait_vmcnt<0>();
+    TSTAMP();   // 3 + 4 it: slice landed (this wave's share)
     asm volatile("s_barrier" ::: "memory");
+    TSTAMP();   // 4 + 4 it: barrier passed
     if (staged < nk) {
       stage(staged % NS);
       ++staged;
     }
+    TSTAMP();   // 5 + 4 it: next slice issued
     const int buf = it % NS;
     const bf16_t* Ab = Abuf(buf);
     const bf16_t* Bb = Bbuf(buf);
@@ -271,7 +293,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
+    TSTAMP();   // 6 + 4 it: MFMA work of the slice issued
   }
+  TSTAMP();     // 3 + 4 nk: loop done
 
   // ---- epilogue, coalesced form (Co % 8 == 0): the accumulators (+ bias, self-activation) go
   // through LDS in WM passes of BM/WM rows, then every thread finishes 8 consecutive channels of
@@ -284,7 +308,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
     constexpr int C8 = BN / 8;           // 8-channel items per row
     float* Cs = reinterpret_cast<float*>(smem);
     for (int h = 0; h < WM; ++h) {
+      TSTAMP();   // epilogue pass h: entry
       __syncthreads();
+      TSTAMP();   // barrier 1
       if (wm == h) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -308,7 +334,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
               *reinterpret_cast<float4*>(Cs + (i * 32 + frow) * LDC + col) = v;
             }
       }
+      TSTAMP();   // accumulators in LDS
       __syncthreads();
+      TSTAMP();   // barrier 2
       for (int t = tid; t < RP * C8; t += 256) {
         const int row = t / C8, c8 = t - row * C8;
         const int m = m0 + h * RP + row;
@@ -348,6 +376,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
         }
       }
     }
+    TSTAMP();   // last: epilogue stores issued
     return;
   }
 
@@ -1547,6 +1576,11 @@ bool phase_ok(const cgConvGeom* g) {
 
 static int ilog2x(int x);
 
+#ifdef CG_CONV_TIMING
+static unsigned long long* g_conv_tdbg = nullptr;
+extern "C" void cg_debug_set_conv_timing_buffer(void* p) { g_conv_tdbg = (unsigned long long*)p; }
+#endif
+
 bool cg_fast_conv_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                             float slope_in) {
   if (g->Ci % 32 != 0) return false;   // 64-channel K slices; the last one may be half empty
@@ -1576,6 +1610,9 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.Hp = g->Ho / g->U; a.Wp = g->Wo / g->U;
   a.Mp = g->N * a.Hp * a.Wp;
   a.cblocks = (g->Ci + 63) / 64;
+#ifdef CG_CONV_TIMING
+  a.tdbg = g_conv_tdbg;
+#endif
   a.relu_in = gate_in != nullptr;
   a.out_f32 = out_is_f32;
   a.slope_out = slope_out;

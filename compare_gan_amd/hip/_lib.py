@@ -146,11 +146,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CGAMD_LIB_PATH") or LIB_PATH   # override: instrumented debug builds only
+    if not os.path.exists(path):
         raise CgamdError(
             "libcgamd.so not found at %s: run `python -m compare_gan_amd.csrc.build` "
-            "(there is no CPU / eager fallback for the HIP kernels)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "(there is no CPU / eager fallback for the HIP kernels)" % path)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.restype = res
