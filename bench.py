@@ -80,6 +80,23 @@ def cpu_baseline(config, batch, budget_s=20.0):
                       "step includes variable creation" % (steps, ora.disc_iters, config, batch, dt)}
 
 
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                "r01_pmc_traffic.json")
+PMC_TRAFFIC_NOTE = ("HBM bytes per launch of this kernel family = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
+                    "from two rocprofv3 --pmc passes of this workload (scripts/pmc_traffic.py -> "
+                    "profiles/r01_pmc_traffic.json); null when that summary is absent")
+
+
+def pmc_traffic(family):
+    """PMC counters cannot be read from inside the timed process: the committed summary of the
+    separate `rocprofv3 --pmc` passes over this same command is reported (bytes per launch)."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            return json.load(f)["families"][family]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline_guarded(config, batch, budget_s):
     """Runs cpu_baseline in a child process under a hard timeout so that a slow or oversubscribed
     host can never stall the benchmark line."""
@@ -219,7 +236,8 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(name),
+            "traffic_source": PMC_TRAFFIC_NOTE,
             "launches_per_step": st["launches"] / n_prof,
             "avg_launch_us": round(1e3 * st["ms"] / st["launches"], 3),
             "avg_launch_gflop": round(st["flops"] / st["launches"] / 1e9, 3),
