@@ -276,6 +276,12 @@ def main():
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.barrier()
+        # the captured graph holds RCCL kernel nodes: release it before the communicator goes away
+        torch.cuda.synchronize()
+        step_fn = None
+        if getattr(gan, "_graph", None) is not None:
+            gan._graph = None   # pylint: disable=protected-access
+        torch.cuda.synchronize()
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio; flush it so that the JSON line is the LAST
     # line on stdout
@@ -286,7 +292,12 @@ def main():
         pass
     if rank == 0:
         sys.stdout.write(json.dumps(result) + "\n")
-        sys.stdout.flush()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if world > 1 or force_dp:
+        # skip interpreter teardown of HIP / RCCL objects: one run in ~5 died there with a core dump
+        # AFTER the measurement (exit order of communicator, graph and stream destructors)
+        os._exit(0)
 
 
 if __name__ == "__main__":

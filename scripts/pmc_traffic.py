@@ -11,10 +11,10 @@ import collections, csv, glob, json, os, re, sys
 
 FAMILIES = [
     (r"halo_conv_kernel", "halo_conv_kernel<*>"),
-    (r"fast_conv_kernel<128, 128", "fast_conv_kernel<128, 128, *>"),
-    (r"fast_conv_kernel<64, 128", "fast_conv_kernel<64, 128, *>"),
-    (r"fast_conv_kernel<128, 64", "fast_conv_kernel<128, 64, *>"),
-    (r"fast_conv_kernel<128, 32", "fast_conv_kernel<128, 32, *>"),
+    (r"fast_conv(_sk)?_kernel<128, 128", "fast_conv_kernel<128, 128, *>"),
+    (r"fast_conv(_sk)?_kernel<64, 128", "fast_conv_kernel<64, 128, *>"),
+    (r"fast_conv(_sk)?_kernel<128, 64", "fast_conv_kernel<128, 64, *>"),
+    (r"fast_conv(_sk)?_kernel<128, 32", "fast_conv_kernel<128, 32, *>"),
     (r"stem_fwd_kernel", "stem_fwd_kernel<*>"),
     (r"gconv_kernel", "gconv_kernel<...>"),
     (r"halo_wgrad_kernel", "halo_wgrad_kernel<*>"),
