@@ -541,3 +541,33 @@ def test_error_codes(K, dev):
         K.gconv(geom, x, bt)
     with pytest.raises(CgamdError):
         K.avgpool2(torch.zeros((1, 3, 4, 8), dtype=BF16, device=dev))
+
+
+# The convolution dispatcher picks a kernel variant from the grid size and a few environment
+# overrides that are read once per process.  Every variant must stay parity-green, including the ones
+# the default policy does not select for the small test shapes: run the convolution cases again in a
+# child process per override.
+CONV_VARIANT_ENVS = [
+    ("no_splitk", {"CGAMD_CONV_SK": "0"}),              # 4-wave kernels on small grids
+    ("ring2", {"CGAMD_CONV_SK": "0", "CGAMD_CONV_NS": "2"}),
+    ("single_buffer", {"CGAMD_CONV_SK": "0", "CGAMD_CONV_NS": "1"}),
+    ("tiles128", {"CGAMD_CONV_SK": "0", "CGAMD_CONV_T128_MIN": "1"}),   # 128x128 tiles everywhere
+    ("splitk_tiles128", {"CGAMD_CONV_T128_MIN": "1"}),
+    ("halo_forward", {"CGAMD_HALO": "1"}),             # experimental halo-staged forward kernel
+    ("one_tap_wgrad", {"CGAMD_NO_HALO_WGRAD": "1"}),   # one-tap-per-workgroup weight gradient
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", CONV_VARIANT_ENVS, ids=[v[0] for v in CONV_VARIANT_ENVS])
+def test_conv_kernel_variants(dev, variant):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(variant[1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
+                        "-x", "-k", "test_gconv_forward_adjoint_wgrad"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
