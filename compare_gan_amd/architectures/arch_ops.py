@@ -520,6 +520,16 @@ def avg_pool2(x):
   return Fn.avg_pool2(x)
 
 
+def unpool(x, residual=None):
+  """resnet_ops.unpool (resnet_ops.py:35-56) on its own: zero-insertion 2x upsampling, with the
+  block's `outputs += shortcut` fused in as `residual` (resnet_biggan_deep.py:102-103,188)."""
+  x = as_tensor(x)
+  if x.is_meta:
+    n, h, w, c = x.shape
+    return torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device="meta")
+  return Fn.unpool2(x, None if residual is None else as_tensor(residual))
+
+
 def max_pool2(x):
   """tf.layers.max_pooling2d(pool_size=[2,2], strides=2) (arch_ops.py:741,750)."""
   if x.is_meta:

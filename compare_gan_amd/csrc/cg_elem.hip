@@ -400,6 +400,72 @@ extern "C" int cg_axpby(const void* a, float alpha, const void* b, float beta, v
   return CG_OK;
 }
 
+// ---- zero-insertion upsampling (resnet_ops.unpool) on its own --------------------------------------
+// The convolutions take the upsampling as a launch parameter (U = 2, no zero is ever stored); the
+// BigGAN-deep generator also upsamples its shortcut branch WITHOUT a convolution
+// (resnet_biggan_deep.py:102-103).  out[n, 2i, 2j, :] = x[n, i, j, :] (+ residual), every other pixel
+// = residual (or 0): one thread per 8 channels (C % 8 == 0) or per channel of one OUTPUT pixel.
+template <bool VEC>
+__global__ void unpool2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, int N,
+                               int H, int W, int C, bf16_t* __restrict__ y) {
+  const int Ho = H * 2, Wo = W * 2;
+  const int CV = VEC ? C / 8 : C;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int ow = (int)(p % Wo);
+    p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const bool hit = !(oh & 1) && !(ow & 1);
+    const int64_t xo = (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * C;
+    const int64_t yo = (((int64_t)n * Ho + oh) * Wo + ow) * C;
+    if (VEC) {
+      V8 a, r, o;
+      a.q = make_uint4(0, 0, 0, 0);
+      r.q = make_uint4(0, 0, 0, 0);
+      if (hit) a.q = *reinterpret_cast<const uint4*>(x + xo + cv * 8);
+      if (res) r.q = *reinterpret_cast<const uint4*>(res + yo + cv * 8);
+      if (res && hit) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = f2bf(bf2f(a.h[e]) + bf2f(r.h[e]));
+      } else {
+        o.q = hit ? a.q : r.q;
+      }
+      *reinterpret_cast<uint4*>(y + yo + cv * 8) = o.q;
+    } else {
+      const float a = hit ? bf2f(x[xo + cv]) : 0.f;
+      const float r = res ? bf2f(res[yo + cv]) : 0.f;
+      y[yo + cv] = f2bf(a + r);
+    }
+  }
+}
+// gradient with respect to x: dx[n, i, j, :] = dy[n, 2i, 2j, :] (the residual's gradient is dy itself)
+template <bool VEC>
+__global__ void unpool2_bwd_kernel(const bf16_t* __restrict__ dy, int N, int H, int W, int C,
+                                   bf16_t* __restrict__ dx) {
+  const int Ho = H * 2, Wo = W * 2;
+  const int CV = VEC ? C / 8 : C;
+  const int64_t total = (int64_t)N * H * W * CV;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    const int64_t so = (((int64_t)n * Ho + 2 * h) * Wo + 2 * w) * C;
+    const int64_t dst_o = (((int64_t)n * H + h) * W + w) * C;
+    if (VEC)
+      *reinterpret_cast<uint4*>(dx + dst_o + cv * 8) = *reinterpret_cast<const uint4*>(dy + so + cv * 8);
+    else
+      dx[dst_o + cv] = dy[so + cv];
+  }
+}
+
 static int check_pool(const void* x, int N, int H, int W, int C, const void* y, const char* who) {
   if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "%s: null pointer", who);
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1))
@@ -440,6 +506,38 @@ extern "C" int cg_avgpool2_bwd(const void* dy, int N, int H, int W, int C, void*
   pool2_bwd_kernel<false><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
       nullptr, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
   CG_CHECK_LAUNCH("cg_avgpool2_bwd");
+  return CG_OK;
+}
+extern "C" int cg_unpool2(const void* x, const void* residual, int N, int H, int W, int C,
+                          void* y, cgStream stream) {
+  if (!x || !y) CG_FAIL(CG_ERR_BAD_ARG, "cg_unpool2: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_unpool2: bad shape [%d,%d,%d,%d]", N, H, W, C);
+  const bool vec = (C % 8) == 0;
+  const int64_t work = (int64_t)N * H * 2 * W * 2 * (vec ? C / 8 : C);
+  if (vec)
+    unpool2_kernel<true><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, (const bf16_t*)residual, N, H, W, C, (bf16_t*)y);
+  else
+    unpool2_kernel<false><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, (const bf16_t*)residual, N, H, W, C, (bf16_t*)y);
+  CG_CHECK_LAUNCH("cg_unpool2");
+  return CG_OK;
+}
+extern "C" int cg_unpool2_bwd(const void* dy, int N, int H, int W, int C, void* dx,
+                              cgStream stream) {
+  if (!dy || !dx) CG_FAIL(CG_ERR_BAD_ARG, "cg_unpool2_bwd: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_unpool2_bwd: bad shape [%d,%d,%d,%d]", N, H, W, C);
+  const bool vec = (C % 8) == 0;
+  const int64_t work = (int64_t)N * H * W * (vec ? C / 8 : C);
+  if (vec)
+    unpool2_bwd_kernel<true><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
+  else
+    unpool2_bwd_kernel<false><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
+  CG_CHECK_LAUNCH("cg_unpool2_bwd");
   return CG_OK;
 }
 extern "C" int cg_maxpool2_bwd(const void* x, const void* dy, int N, int H, int W, int C,

@@ -20,6 +20,7 @@ from compare_gan_amd.architectures import arch_ops as ops
 from compare_gan_amd.architectures import dcgan
 from compare_gan_amd.architectures import resnet5
 from compare_gan_amd.architectures import resnet_biggan
+from compare_gan_amd.architectures import resnet_biggan_deep
 from compare_gan_amd.architectures import resnet_cifar
 from compare_gan_amd.architectures import sndcgan
 from compare_gan_amd.gans import consts as c
@@ -180,6 +181,7 @@ class ModularGAN(AbstractGAN):
           c.DCGAN_ARCH: dcgan.Generator,
           c.RESNET5_ARCH: resnet5.Generator,
           c.RESNET_BIGGAN_ARCH: resnet_biggan.Generator,
+          c.RESNET_BIGGAN_DEEP_ARCH: resnet_biggan_deep.Generator,
           c.RESNET_CIFAR_ARCH: resnet_cifar.Generator,
           c.SNDCGAN_ARCH: sndcgan.Generator,
       }
@@ -197,6 +199,7 @@ class ModularGAN(AbstractGAN):
           c.DCGAN_ARCH: dcgan.Discriminator,
           c.RESNET5_ARCH: resnet5.Discriminator,
           c.RESNET_BIGGAN_ARCH: resnet_biggan.Discriminator,
+          c.RESNET_BIGGAN_DEEP_ARCH: resnet_biggan_deep.Discriminator,
           c.RESNET_CIFAR_ARCH: resnet_cifar.Discriminator,
           c.SNDCGAN_ARCH: sndcgan.Discriminator,
       }

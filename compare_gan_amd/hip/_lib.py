@@ -92,6 +92,8 @@ SIGNATURES = {
     "cg_dot_bf16": (c_int, [vp, vp, c_i64, vp, vp, c_sz, vp]),
     "cg_avgpool2": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_avgpool2_bwd": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_unpool2": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp]),
+    "cg_unpool2_bwd": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_maxpool2": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_maxpool2_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_spatial_reduce": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),

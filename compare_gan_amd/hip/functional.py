@@ -402,6 +402,36 @@ class AvgPool2BwdFn(torch.autograd.Function):
     return AvgPool2Fn.apply(_bf16(ddx))
 
 
+class UnpoolFn(torch.autograd.Function):
+  """Zero-insertion 2x upsampling (+ residual): resnet_ops.unpool outside a convolution."""
+
+  @staticmethod
+  def forward(ctx, x, residual):
+    ctx.has_res = residual is not None
+    return K.unpool2(x.contiguous(), None if residual is None else residual.contiguous())
+
+  @staticmethod
+  def backward(ctx, dy):
+    dy16 = _bf16(dy)
+    return UnpoolBwdFn.apply(dy16), (dy16 if ctx.has_res else None)
+
+
+class UnpoolBwdFn(torch.autograd.Function):
+  """dx = dy[:, ::2, ::2, :]; its own gradient is the upsampling again."""
+
+  @staticmethod
+  def forward(ctx, dy):
+    return K.unpool2_bwd(dy.contiguous())
+
+  @staticmethod
+  def backward(ctx, ddx):
+    return UnpoolFn.apply(_bf16(ddx), None)
+
+
+def unpool2(x, residual=None):
+  return UnpoolFn.apply(x, residual)
+
+
 class MaxPool2Fn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x):

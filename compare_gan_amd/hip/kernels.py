@@ -440,6 +440,32 @@ def maxpool2(x):
     return _pool(lib().cg_maxpool2, "cg_maxpool2", x)
 
 
+def unpool2(x, residual=None):
+    """Zero-insertion upsampling x [N,H,W,C] -> [N,2H,2W,C] (+ residual of that shape)."""
+    _req(x, BF16, "x")
+    N, H, W, C = x.shape
+    if residual is not None:
+        _req(residual, BF16, "residual")
+        if tuple(residual.shape) != (N, 2 * H, 2 * W, C):
+            raise ValueError("residual shape %r does not match the upsampled %r" % (
+                tuple(residual.shape), (N, 2 * H, 2 * W, C)))
+    y = torch.empty((N, 2 * H, 2 * W, C), dtype=BF16, device=x.device)
+    check(lib().cg_unpool2(_p(x), _p(residual), N, H, W, C, _p(y), _stream()), "cg_unpool2")
+    return y
+
+
+def unpool2_bwd(dy):
+    """dy [N,2H,2W,C] -> dx [N,H,W,C] = dy[:, ::2, ::2, :]."""
+    _req(dy, BF16, "dy")
+    N, Ho, Wo, C = dy.shape
+    if (Ho | Wo) & 1:
+        raise ValueError("unpool2_bwd needs even spatial sizes, got %r" % (tuple(dy.shape),))
+    dx = torch.empty((N, Ho // 2, Wo // 2, C), dtype=BF16, device=dy.device)
+    check(lib().cg_unpool2_bwd(_p(dy), N, Ho // 2, Wo // 2, C, _p(dx), _stream()),
+          "cg_unpool2_bwd")
+    return dx
+
+
 def avgpool2_bwd(dy):
     """dy [N,H/2,W/2,C] -> dx [N,H,W,C]."""
     _req(dy, BF16, "dy")

@@ -252,6 +252,14 @@ int cg_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* ws, s
 /* 2x2 average pooling, stride 2 (resnet_ops.py:131-133), x [N,H,W,C] -> y [N,H/2,W/2,C]. */
 int cg_avgpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream);
 int cg_avgpool2_bwd(const void* dy, int N, int H, int W, int C, void* dx, cgStream stream);
+/* Zero-insertion 2x upsampling without a convolution (resnet_ops.py:35-56 `unpool`, used bare by
+ * the BigGAN-deep generator's shortcut, resnet_biggan_deep.py:102-103): x [N,H,W,C] ->
+ * y [N,2H,2W,C], y[n,2i,2j,:] = x[n,i,j,:], zero elsewhere; `residual` [N,2H,2W,C] (may be NULL) is
+ * added (the block's `outputs += shortcut`).  Gradient w.r.t. x: dx[n,i,j,:] = dy[n,2i,2j,:]
+ * (H, W are the sizes of x in both calls). */
+int cg_unpool2(const void* x, const void* residual, int N, int H, int W, int C, void* y,
+               cgStream stream);
+int cg_unpool2_bwd(const void* dy, int N, int H, int W, int C, void* dx, cgStream stream);
 /* 2x2 max pooling stride 2 (arch_ops.py:741,750) and its gradient (routes to first max). */
 int cg_maxpool2(const void* x, int N, int H, int W, int C, void* y, cgStream stream);
 int cg_maxpool2_bwd(const void* x, const void* dy, int N, int H, int W, int C, void* dx,

@@ -2,7 +2,8 @@
 
 CPU restatement of the reference's generator / discriminator definitions:
   architectures/abstract_arch.py:48-146, resnet_ops.py:70-182, resnet_cifar.py:34-167,
-  resnet5.py:36-145, resnet_biggan.py:80-425, dcgan.py:39-129, sndcgan.py:36-127.
+  resnet5.py:36-145, resnet_biggan.py:80-425, resnet_biggan_deep.py:62-433, dcgan.py:39-129,
+  sndcgan.py:36-127.
 Pinned by the reference's structural tests (variable names/shapes and parameter counts:
 architectures/resnet_norm_test.py:39-369, resnet_biggan_test.py:112-154); the forward numerics
 are "parity unpinned" (no reference test asserts a value) -- see tests/test_oracle_pins.py.
@@ -299,6 +300,127 @@ def biggan_discriminator(vs, cfg, x, y, is_training):
 
 
 # ------------------------------------------------------------------------------------------------
+# BigGAN-deep (resnet_biggan_deep.py:62-433); pinned by the parameter totals of
+# resnet_biggan_deep_test.py:56-60 through the product's variable shapes, numerics "parity unpinned"
+# ------------------------------------------------------------------------------------------------
+_G_MULT_DEEP = {512: 4 * [16] + 4 * [8] + [4, 4, 2, 2, 1, 1, 1], 256: 4 * [16] + 4 * [8] + [4, 4, 2, 2, 1],
+                128: 4 * [16] + 2 * [8] + [4, 4, 2, 2, 1], 64: 4 * [16] + 2 * [8] + [4, 4, 2],
+                32: 8 * [4]}
+_D_MULT_DEEP = {512: [1, 1, 1, 2, 2, 4, 4] + 4 * [8] + 4 * [16], 256: [1, 2, 2, 4, 4] + 4 * [8] + 4 * [16],
+                128: [1, 2, 2, 4, 4] + 2 * [8] + 4 * [16], 64: [2, 4, 4] + 2 * [8] + 4 * [16],
+                32: 8 * [2]}
+
+
+def biggan_deep_block(vs, cfg, x, scope, in_ch, out_ch, scale, z, y, is_training):
+  """resnet_biggan_deep.py:131-196: bn-relu-1x1, bn-relu-[unpool]-3x3, bn-relu-3x3,
+  bn-relu-[avgpool]-1x1, plus the parameter-free shortcut of :90-117."""
+  if x.shape[-1] != in_ch:
+    raise ValueError("Unexpected number of input channels (expected {}, got {}).".format(
+        in_ch, x.shape[-1]))
+  bott = max(in_ch, out_ch) // 4
+  sn, sc = cfg.spectral_norm, cfg.sn_cfg
+  bn = lambda t, name: _batch_norm(vs, cfg, t, scope + "/" + name + "/bn", z=z, y=y,
+                                   is_training=is_training, relu=True)
+  out = ops.conv2d(vs, bn(x, "conv1"), bott, 1, 1, 1, 1, scope + "/conv1/1x1_conv", sc, use_sn=sn)
+  out = bn(out, "conv2")
+  if scale == "up":
+    out = ops.unpool(out)
+  out = ops.conv2d(vs, out, bott, 3, 3, 1, 1, scope + "/conv2/3x3_conv", sc, use_sn=sn)
+  out = ops.conv2d(vs, bn(out, "conv3"), bott, 3, 3, 1, 1, scope + "/conv3/3x3_conv", sc, use_sn=sn)
+  out = bn(out, "conv4")
+  if scale == "down":
+    out = vs.q(ops.avg_pool2(out))
+  # shortcut (:90-117)
+  shortcut = x
+  if in_ch > out_ch:
+    assert scale == "up"
+    shortcut = shortcut[:, :, :, :out_ch]
+  if scale == "up":
+    shortcut = ops.unpool(shortcut)
+  if scale == "down":
+    shortcut = vs.q(ops.avg_pool2(shortcut))
+  if in_ch < out_ch:
+    assert scale == "down"
+    added = ops.conv2d(vs, shortcut, out_ch - in_ch, 1, 1, 1, 1, scope + "/shortcut/add_channels",
+                       sc, use_sn=sn)
+    shortcut = torch.cat([shortcut, added], dim=-1)
+  if scale == "up":
+    # the HIP path stores conv4's output, then the upsampling kernel adds the shortcut to it
+    out = ops.conv2d(vs, out, out_ch, 1, 1, 1, 1, scope + "/conv4/1x1_conv", sc, use_sn=sn)
+    return vs.q(out + shortcut)
+  return ops.conv2d(vs, out, out_ch, 1, 1, 1, 1, scope + "/conv4/1x1_conv", sc, use_sn=sn,
+                    residual=shortcut)
+
+
+def biggan_deep_generator(vs, cfg, z, y, is_training, image_shape=(128, 128, 3)):
+  """resnet_biggan_deep.py:201-311."""
+  kw = cfg.arch_kwargs
+  ch = kw.get("ch", 128)
+  embed_y, embed_y_dim = kw.get("embed_y", True), kw.get("embed_y_dim", 128)
+  s = "generator"
+  res = image_shape[0]
+  if res not in _G_MULT_DEEP:
+    raise ValueError("Unsupported resolution: {}".format(res))
+  mult = _G_MULT_DEEP[res]
+  in_ch = [ch * c for c in mult[:-1]]
+  out_ch = [ch * c for c in mult[1:]]
+  if embed_y:
+    y = ops.linear(vs, y, embed_y_dim, s + "/embed_y", cfg.sn_cfg, use_sn=False, use_bias=False)
+  if y is not None:
+    y = torch.cat([z, y], 1)
+    z = y
+  net = ops.linear(vs, z, in_ch[0] * 16, s + "/fc_noise", cfg.sn_cfg, use_sn=cfg.spectral_norm)
+  net = net.reshape(-1, 4, 4, in_ch[0])
+  for b in range(len(in_ch)):
+    scale = "none" if b % 2 == 0 else "up"
+    net = biggan_deep_block(vs, cfg, net, s + "/B%d" % (b + 1), in_ch[b], out_ch[b], scale, z, y,
+                            is_training)
+    if scale == "up" and net.shape[1] == 64:
+      net = ops.non_local_block(vs, net, s + "/non_local_block", cfg.spectral_norm, cfg.sn_cfg)
+  net = ops.batch_norm(vs, net, is_training, s + "/final_norm", cfg.bn_cfg, relu=True)
+  net = ops.conv2d(vs, net, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg,
+                   use_sn=cfg.spectral_norm, out_f32=True)
+  return (torch.tanh(net) + 1.0) / 2.0
+
+
+def biggan_deep_discriminator(vs, cfg, x, y, is_training):
+  """resnet_biggan_deep.py:314-433."""
+  kw = cfg.arch_kwargs
+  ch = kw.get("ch", 128)
+  project_y = kw.get("project_y", True)
+  s = "discriminator"
+  colors, res = x.shape[-1], x.shape[1]
+  if colors not in (1, 3):
+    raise ValueError("Unsupported color channels: {}".format(colors))
+  if res not in _D_MULT_DEEP:
+    raise ValueError("Unsupported resolution: {}".format(res))
+  mult = _D_MULT_DEEP[res]
+  in_ch = [ch * c for c in mult[:-1]]
+  out_ch = [ch * c for c in mult[1:]]
+  net = ops.conv2d(vs, x, in_ch[0], 3, 3, 1, 1, s + "/initial_conv", cfg.sn_cfg,
+                   use_sn=cfg.spectral_norm)
+  for b in range(len(in_ch)):
+    scale = "down" if b % 2 == 0 else "none"
+    net = biggan_deep_block(vs, cfg, net, s + "/B%d" % (b + 1), in_ch[b], out_ch[b], scale, None,
+                            y, is_training)
+    if scale == "none" and net.shape[1] == 64:
+      net = ops.non_local_block(vs, net, s + "/non_local_block", cfg.spectral_norm, cfg.sn_cfg)
+  net = torch.relu(net)
+  h = vs.q(net.sum(dim=(1, 2)))
+  logit = ops.linear(vs, h, 1, s + "/final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm,
+                     out_f32=True)
+  if project_y:
+    if y is None:
+      raise ValueError("You must provide class information y to project.")
+    kernel = vs.get(s + "/embedding_fc/kernel", (y.shape[1], out_ch[-1]), vs.glorot_normal_init())
+    if cfg.spectral_norm:
+      kernel = ops.spectral_norm(vs, kernel, s + "/embedding_fc/kernel", cfg.sn_cfg.epsilon,
+                                 cfg.sn_cfg.singular_value)
+    logit = logit + (vs.q(vs.q(y) @ vs.qw(kernel)) * h).sum(dim=1, keepdim=True)
+  return torch.sigmoid(logit), logit, h
+
+
+# ------------------------------------------------------------------------------------------------
 # dcgan (dcgan.py:39-129) and sndcgan (sndcgan.py:36-127)
 # ------------------------------------------------------------------------------------------------
 def _half(size):
@@ -386,10 +508,12 @@ def sndcgan_discriminator(vs, cfg, x, y, is_training):
 GENERATORS = {
     "resnet_cifar_arch": resnet_cifar_generator, "resnet5_arch": resnet5_generator,
     "resnet_biggan_arch": biggan_generator, "dcgan_arch": dcgan_generator,
+    "resnet_biggan_deep_arch": biggan_deep_generator,
     "sndcgan_arch": sndcgan_generator,
 }
 DISCRIMINATORS = {
     "resnet_cifar_arch": resnet_cifar_discriminator, "resnet5_arch": resnet5_discriminator,
     "resnet_biggan_arch": biggan_discriminator, "dcgan_arch": dcgan_discriminator,
+    "resnet_biggan_deep_arch": biggan_deep_discriminator,
     "sndcgan_arch": sndcgan_discriminator,
 }

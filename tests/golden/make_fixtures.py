@@ -49,8 +49,11 @@ def main():
                      "tolerance": 1e-4},
       "param_counts": {
           "source": "compare_gan/architectures/resnet_biggan_test.py:139,154; "
-                    "resnet_biggan.py:39-62; resnet_norm_test.py:124-162",
+                    "resnet_biggan.py:39-62; resnet_norm_test.py:124-162; "
+                    "resnet_biggan_deep_test.py:31-60 (z_dim 128, 1000 classes, 128 px, "
+                    "conditional batch norm, default ch = 128)",
           "resnet_biggan_arch_128": {"G": 70433988, "D": 87982370},
+          "resnet_biggan_deep_arch_128": {"G": 50244484, "D": 34590210},
           "resnet_cifar_arch": {"G": 5849603, "D": 1483137},
       },
       "resnet_cifar_variables": dict(

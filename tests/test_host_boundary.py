@@ -67,6 +67,73 @@ def test_biggan_pins():
   assert gan.store.initializers["generator/non_local_block/sigma"] == "zeros"
 
 
+def test_biggan_deep_pins():
+  """resnet_biggan_deep_test.py:31-60: 50,244,484 generator / 34,590,210 discriminator weights at
+  128 px (z_dim 128, 1000 classes, conditional batch norm), output shapes, and the naming of the
+  bottleneck blocks / parameter-free shortcuts."""
+  from compare_gan_amd import gin
+  from compare_gan_amd.architectures import arch_ops as ops
+  from compare_gan_amd.architectures import resnet_biggan_deep as deep
+  gin.clear_config()
+  store = ops.VariableStore("meta")
+  with ops.use_store(store):
+    z = torch.empty((2, 128), dtype=torch.float32, device="meta")
+    y = torch.empty((2, 1000), dtype=torch.float32, device="meta")
+    gen = deep.Generator(image_shape=(128, 128, 3), batch_norm_fn=ops.conditional_batch_norm)
+    fake = gen(z, y=y, is_training=True)
+    assert tuple(fake.shape) == (2, 128, 128, 3)
+    out = deep.Discriminator()(fake, y=y, is_training=True)
+    assert [tuple(o.shape) for o in out] == [(2, 1), (2, 1), (2, 2048)]
+  tv = store.trainable_variables()
+  pin = PINS["param_counts"]["resnet_biggan_deep_arch_128"]
+  assert sum(v.numel() for n, v in tv if n.startswith("generator/")) == pin["G"]
+  assert sum(v.numel() for n, v in tv if n.startswith("discriminator/")) == pin["D"]
+  v = dict(tv)
+  # no hierarchical z: every conditional BN sees concat(z[128], embed_y[128])
+  assert tuple(v["generator/B1/conv1/bn/condition/gamma/kernel"].shape) == (256, 2048)
+  assert tuple(v["generator/B4/conv2/3x3_conv/kernel"].shape) == (3, 3, 512, 512)   # max(2048,1024)/4
+  assert tuple(v["generator/fc_noise/kernel"].shape) == (256, 4 * 4 * 2048)
+  # G's shortcuts have no weights; D's "down" blocks append out - in channels with one 1x1 conv
+  assert not any("shortcut" in n for n in v if n.startswith("generator/"))
+  assert tuple(v["discriminator/B1/shortcut/add_channels/kernel"].shape) == (1, 1, 128, 128)
+  assert "discriminator/B2/shortcut/add_channels/kernel" not in v
+  # self-attention where the feature map is 64x64
+  assert tuple(v["generator/non_local_block/conv2d_theta/kernel"].shape) == (1, 1, 256, 32)
+  assert tuple(v["discriminator/non_local_block/conv2d_theta/kernel"].shape) == (1, 1, 256, 32)
+  with pytest.raises(ValueError):
+    with ops.use_store(ops.VariableStore("meta")):
+      deep.Generator(image_shape=(48, 48, 3))(z, y=y, is_training=True)
+
+
+def test_biggan_deep_oracle_and_product_agree_structurally():
+  """The oracle's restatement of resnet_biggan_deep.py and the product create the same variables
+  (names and shapes, spectral-norm vectors and BN accumulators included) under
+  biggan_imagenet128.gin's settings -- what the GPU parity test mirrors one into the other by."""
+  from oracle import architectures as OA
+  from oracle import arch_ops as oops
+  bind = ['options.architecture = "resnet_biggan_deep_arch"',
+          "resnet_biggan_deep.Generator.ch = 32", "resnet_biggan_deep.Discriminator.ch = 32"]
+  gan, options, _ = U.build_product("biggan_imagenet128.gin", 2, "meta", bindings=bind)
+  assert options["architecture"] == "resnet_biggan_deep_arch"
+  product = {n: tuple(v.shape) for n, v in gan.store.vars.items()}
+  vs = oops.VarStore(dtype=torch.float64)
+  sn = oops.SNConfig(singular_value="auto")
+  g_cfg = OA.ArchConfig(batch_norm_fn="conditional_batch_norm", spectral_norm=True,
+                        bn_cfg=oops.BNConfig(0.9, 1e-5, use_moving_averages=False), sn_cfg=sn,
+                        embed_y=True, ch=32)
+  d_cfg = OA.ArchConfig(spectral_norm=True, sn_cfg=sn, project_y=True, ch=32)
+  z = torch.zeros(2, 120, dtype=torch.float64)
+  y = torch.zeros(2, 1000, dtype=torch.float64)
+  y[0, 3] = y[1, 977] = 1.0
+  with torch.no_grad():
+    img = OA.biggan_deep_generator(vs, g_cfg, z, y, True, (128, 128, 3))
+    prob, logit, h = OA.biggan_deep_discriminator(vs, d_cfg, img, y, True)
+  assert tuple(img.shape) == (2, 128, 128, 3) and tuple(h.shape) == (2, 512)
+  assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+  oracle = {n: tuple(v.shape) for n, v in vs.vars.items()}
+  assert oracle == product
+
+
 def _cifar_vars(module_kind, trainable_only=True, **kwargs):
   from compare_gan_amd import gin
   from compare_gan_amd.architectures import arch_ops as ops

@@ -571,3 +571,29 @@ def test_conv_kernel_variants(dev, variant):
                         "-x", "-k", "test_gconv_forward_adjoint_wgrad"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 4, 4, 64), (3, 5, 7, 24), (1, 8, 8, 3)],
+                         ids=["vec", "ragged_vec", "scalar"])
+def test_unpool_standalone(K, dev, shape):
+    """cg_unpool2 / cg_unpool2_bwd (resnet_ops.py:35-56 outside a convolution): bit-exact copy into
+    the even pixels, residual added with one bf16 rounding; autograd of the Function pair."""
+    from compare_gan_amd.hip import functional as Fn
+    g = _gen(sum(shape))
+    x_ref, x = rand_bf16(shape, g)
+    n, h, w, c = shape
+    r_ref, r = rand_bf16((n, 2 * h, 2 * w, c), g)
+    up = K.unpool2(x.to(dev))
+    assert torch.equal(up.cpu().double(), oops.unpool(x_ref))
+    up_r = K.unpool2(x.to(dev), r.to(dev))
+    want = (oops.unpool(x_ref) + r_ref).float().to(torch.bfloat16).double()
+    assert torch.equal(up_r.cpu().double(), want)
+    dy_ref, dy = rand_bf16((n, 2 * h, 2 * w, c), g)
+    assert torch.equal(K.unpool2_bwd(dy.to(dev)).cpu().double(), dy_ref[:, ::2, ::2, :])
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True)
+    out = Fn.unpool2(xd, rd)
+    gx, gr = torch.autograd.grad(out, [xd, rd], grad_outputs=dy.to(dev))
+    assert torch.equal(gx.cpu().double(), dy_ref[:, ::2, ::2, :])
+    assert torch.equal(gr.cpu().double(), dy_ref)
