@@ -1,0 +1,59 @@
+"""Host-side tooling around the measurement: the PMC traffic summariser and bench.py's lookup of it."""
+import csv
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _write_pass(d, counter, rows):
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "p_counter_collection.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+        w.writeheader()
+        for disp, kern, val in rows:
+            w.writerow({"Dispatch_Id": disp, "Kernel_Name": kern, "Counter_Name": counter,
+                        "Counter_Value": val})
+
+
+def test_pmc_traffic_summary(tmp_path):
+    """(2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch, 4-wave and split-K launches of one tile shape
+    folded into the family bench.py's event brackets use, counters of other kernels kept apart."""
+    pt = _load(os.path.join(ROOT, "scripts", "pmc_traffic.py"), "pmc_traffic")
+    k4 = "void (anonymous namespace)::fast_conv_kernel<64, 128, false, 4>((anonymous namespace)::FastConvArgs)"
+    k8 = "void (anonymous namespace)::fast_conv_sk_kernel<64, 128, true>((anonymous namespace)::FastConvArgs)"
+    kb = "(anonymous namespace)::bn_apply_vec_kernel(unsigned short const*, int)"
+    fdir, wdir = str(tmp_path / "f"), str(tmp_path / "w")
+    _write_pass(fdir, "FETCH_SIZE", [(1, k4, 100.0), (2, k8, 300.0), (3, kb, 50.0)])
+    _write_pass(wdir, "WRITE_SIZE", [(1, k4, 10.0), (2, k8, 30.0), (3, kb, 50.0)])
+    out = str(tmp_path / "t.json")
+    argv = sys.argv
+    try:
+        sys.argv = ["pmc_traffic.py", fdir, wdir, out]
+        pt.main()
+    finally:
+        sys.argv = argv
+    fam = json.load(open(out))["families"]
+    conv = fam["fast_conv_kernel<64, 128, *>"]
+    assert conv["launches_fetch_pass"] == 2 and conv["launches_write_pass"] == 2
+    assert conv["hbm_bytes_per_launch"] == int((2 * 200.0 + 20.0) * 1024)
+    assert fam["bn_apply_vec_kernel"]["hbm_bytes_per_launch"] == int((2 * 50.0 + 50.0) * 1024)
+    assert pt.family("void (anonymous namespace)::halo_wgrad_kernel<true, false>(x)") == "halo_wgrad_kernel<*>"
+
+
+def test_bench_reads_the_committed_traffic_summary():
+    bench = _load(os.path.join(ROOT, "bench.py"), "bench_module")
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    for family in ("fast_conv_kernel<64, 128, *>", "fast_conv_kernel<128, 128, *>",
+                   "halo_wgrad_kernel<*>"):
+        assert bench.pmc_traffic(family) == summary["families"][family]["hbm_bytes_per_launch"] > 0
+    assert bench.pmc_traffic("no_such_kernel") is None
