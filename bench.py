@@ -160,6 +160,8 @@ def main():
         pool.append((torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev)))
 
     use_graph = not args.no_graph
+    if (world > 1 or force_dp) and os.environ.get("CGAMD_DP_GRAPH", "1") == "0":
+        use_graph = False     # operator override: eager launches around the RCCL all-reduces
     step_fn = gan.train_step
     if use_graph:
         # the whole step -- including the RCCL gradient all-reduces under data parallelism -- is
