@@ -465,7 +465,13 @@ class ModularGAN(AbstractGAN):
     self.d_opt.reserve_tables(self._disc_iters)
     self.g_opt.reserve_tables(1)
     self._graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self._graph):
+    graph_kwargs = {}
+    if tpu_ops.num_replicas() > 1 or tpu_ops.force_data_parallel():
+      # the process group's watchdog thread queries events while this thread captures: in the
+      # default "global" capture mode such a call from ANOTHER thread invalidates the capture
+      # (and aborts the process); thread-local mode confines the restrictions to this thread
+      graph_kwargs["capture_error_mode"] = "thread_local"
+    with torch.cuda.graph(self._graph, **graph_kwargs):
       self._graph_out = self.train_step(self._static_images, self._static_labels)
     for opt in (self.g_opt, self.d_opt):
       for t in opt.captured_tables:
