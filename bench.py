@@ -45,6 +45,10 @@ def parse_args():
     p.add_argument("--no-fid", action="store_true", help="skip the FID-10k wall-clock leg")
     p.add_argument("--cpu-budget-s", type=float, default=20.0)
     p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--no-legs", action="store_true",
+                   help="skip the resnet128 D-step / BigGAN-128 legs")
+    p.add_argument("--legs", default="", help="comma list of legs to run (default: all)")
+    p.add_argument("--biggan-batch", type=int, default=64)
     return p.parse_args()
 
 
@@ -115,6 +119,88 @@ def cpu_baseline_guarded(config, batch, budget_s):
     except subprocess.TimeoutExpired:
         note = "cpu baseline exceeded its hard timeout"
     return {"value": None, "unit": "img/s", "cores": 0, "kind": "port", "sample": note}
+
+
+def family_table(fam, n_prof):
+    """Per-kernel-family rows of cg_prof_collect (HIP-event brackets on the launch stream)."""
+    return {k: {"ms_per_step": round(v["ms"] / n_prof, 4),
+                "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                "algorithmic_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                "launches_per_step": v["launches"] / n_prof}
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def extra_leg(config, bindings, batch, mode, steps, warmup, dev, survey_tflop=None):
+    """A second workload measured in the same process AFTER the headline line's timed region:
+    mode "dstep" = ONE discriminator sub-step (fresh z, G forward, D forward/backward, D Adam), the
+    unit BASELINE.json's north star names for the 128x128 ResNet; mode "step" = one full unrolled
+    train step.  Replayed from a hipGraph, timed with a synchronize on both sides; then the same
+    work runs eagerly with HIP-event brackets around every convolution launch for the per-kernel
+    table and the count of useful FLOPs (useful MACs x 2 of the convolution / linear launches;
+    attention, normalisation and element-wise work is NOT counted, so the fraction is conservative)."""
+    from compare_gan_amd import datasets, gin, runner_lib
+    from compare_gan_amd.hip import kernels as K
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([os.path.join(CONFIG_DIR, config)], list(bindings))
+    options = runner_lib.get_options_dict()
+    dataset = datasets.get_dataset()
+    gan = options["gan_class"](dataset=dataset, parameters=options, model_dir="/tmp/cg_bench_leg")
+    gan.build(batch_size=batch, device=dev, seed=3)
+    nsub = 1 if mode == "dstep" else options["disc_iters"] + 1
+    batches = dataset.train_batches(batch * nsub, seed=547)
+    pool = []
+    for _ in range(2):
+        images, labels = next(batches)
+        if dataset.num_classes:
+            labels = np.random.RandomState(7).randint(0, dataset.num_classes, size=labels.shape).astype(np.int32)
+        pool.append((torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev)))
+    eager = gan.disc_step if mode == "dstep" else gan.train_step
+    run = gan.capture_disc_step() if mode == "dstep" else gan.capture_train_step()
+    for i in range(warmup):
+        run(*pool[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = run(*pool[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(out["d_loss"] if mode == "dstep" else out["g_loss"])
+    if not np.isfinite(loss):
+        raise RuntimeError("non-finite loss in leg %s: %r" % (config, loss))
+    K.prof_reset()
+    K.prof_enable(True)
+    n_prof = 2
+    for i in range(n_prof):
+        eager(*pool[i % 2])
+    torch.cuda.synchronize()
+    K.prof_enable(False)
+    fam = {k: v for k, v in K.prof_collect().items() if v["launches"] > 0}
+    counted = sum(v["flops"] for v in fam.values()) / n_prof / 1e12
+    conv_ms = sum(v["ms"] for v in fam.values()) / n_prof
+    leg = {
+        "workload": "%s%s: %s, batch %d per GPU, %dx%dx%d, bf16, synthetic, hipGraph replay" % (
+            config, (" [" + "; ".join(bindings) + "]") if bindings else "",
+            "ONE discriminator sub-step (G forward + D forward/backward + D Adam update)"
+            if mode == "dstep" else "full unrolled train step (%d D + 1 G sub-steps)" % options["disc_iters"],
+            batch, *dataset.image_shape),
+        "batch": batch, "steps": steps, "warmup": warmup,
+        "ms": round(1e3 * dt, 4),
+        "img_per_s": round(batch * nsub / dt, 1),
+        "useful_tflop_counted": round(counted, 4),
+        "useful_tflop_survey": survey_tflop,
+        "tflops": round(counted / dt, 2),
+        "frac": round(counted / dt / PEAK_BF16_TFLOPS, 4),
+        "peak": PEAK_BF16_TFLOPS,
+        "conv_kernel_ms_eager": round(conv_ms, 4),
+        "kernels": family_table(fam, n_prof),
+    }
+    del run, eager, out
+    gan._graph = None   # pylint: disable=protected-access
+    del gan
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return leg
 
 
 def main():
@@ -246,12 +332,7 @@ def main():
             "avg_launch_algorithmic_MB": round(st["bytes"] / st["launches"] / 1e6, 3),
             "flops_definition": "useful MACs x 2 of the launches of this kernel (zero-inserted taps "
                                 "not counted), summed / summed kernel time",
-            "kernels": {k: {"ms_per_step": round(v["ms"] / n_prof, 4),
-                            "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
-                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                            "algorithmic_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                            "launches_per_step": v["launches"] / n_prof}
-                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernels": family_table(fam, n_prof),
         }
     if rank == 0 and world == 1 and not args.no_fid:
         # second half of BASELINE.json's metric: FID-10k wall-clock (10,000 generated vs 10,000
@@ -274,6 +355,31 @@ def main():
                     "comparable with published FIDs"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_guarded(args.config, bsz, args.cpu_budget_s)
+    if rank == 0 and world == 1 and not args.no_legs:
+        # the north star's target configurations as driver-visible numbers.
+        # The headline model is released first: its captured graph pins its memory pool.
+        step_fn = None
+        gan._graph = None   # pylint: disable=protected-access
+        gan = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        legs = [
+            # D-step = 2*[B*G_fwd + 3*(2B)*D_fwd] = 3.53 useful TFLOP at B = 64
+            ("resnet128_dstep", "resnet_lsun-bedroom128.gin", ("penalty.fn = @no_penalty",), 64,
+             "dstep", 20, 3, 3.53),
+            ("resnet128_dstep_gp", "resnet_lsun-bedroom128.gin", (), 64, "dstep", 10, 2, None),
+            # one BigGAN-128 iteration (2 D + 1 G) ~ 0.6 TFLOP per image of batch
+            ("biggan128", "biggan_imagenet128.gin", (), args.biggan_batch, "step", 4, 2, None),
+        ]
+        for key, cfg, binds, b, mode, k, w, survey in legs:
+            if args.legs and key not in args.legs.split(","):
+                continue
+            try:
+                result[key] = extra_leg(cfg, binds, b, mode, k, w, dev, survey)
+            except Exception as e:  # pylint: disable=broad-except
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                result[key] = {"error": repr(e)[:400]}
 
     if world > 1 or force_dp:
         import torch.distributed as dist

@@ -427,14 +427,28 @@ class ModularGAN(AbstractGAN):
     d_losses = []
     with ops.use_store(self.store):
       for i in range(self._disc_iters):
-        with torch.no_grad():
-          sampled_y = None
-          if self.conditional:
-            sampled_y = self._get_one_hot_labels(fs[i]["sampled_labels"])
-          fs[i]["generated"] = self.generator(fs[i]["z"], y=sampled_y, is_training=True)
-        d_losses.append(self._train_discriminator(fs[i], ls[i]))
+        d_losses.append(self._disc_sub_step(fs[i], ls[i]))
       g_loss = self._train_generator(fs[-1], ls[-1])
     return {"d_losses": d_losses, "g_loss": g_loss}
+
+  def _disc_sub_step(self, features, labels):
+    """G forward (no gradient) on the sub-step's z + one D update (modular_gan.py:465-485)."""
+    with torch.no_grad():
+      sampled_y = None
+      if self.conditional:
+        sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+      features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
+    return self._train_discriminator(features, labels)
+
+  def disc_step(self, images, labels):
+    """ONE discriminator sub-step on its own (the unit BASELINE.json's north star quotes the
+    128x128 ResNet on): fresh z, G forward, D forward + backward (+ penalty), D Adam update.
+    images [B,H,W,C] fp32, labels [B] int32.  Returns {"d_loss": device scalar}."""
+    if not self._built:
+      raise RuntimeError("call build() first")
+    f, l = self._preprocess(images, labels, 0)
+    with ops.use_store(self.store):
+      return {"d_loss": self._disc_sub_step(f, l)}
 
   # -- hipGraph capture of the whole step ---------------------------------------------------------------
   def capture_train_step(self, num_warmup=2):
@@ -442,28 +456,29 @@ class ModularGAN(AbstractGAN):
     hipGraph: small configs are launch-bound, replay removes the per-launch
     host cost.  Inputs are copied into static device buffers before each replay.  Returns
     run(images, labels) -> same dict as train_step."""
+    return self._capture(self.train_step, self._disc_iters + 1, self._disc_iters, 1, num_warmup)
+
+  def capture_disc_step(self, num_warmup=2):
+    """disc_step() as a hipGraph: run(images [B,...], labels [B]) -> {"d_loss": ...}."""
+    return self._capture(self.disc_step, 1, 1, 0, num_warmup)
+
+  def _capture(self, step, nsub, d_updates, g_updates, num_warmup):
     import os
     # weight gradients become a parallel branch of the graph (CGAMD_NO_WGRAD_STREAM=1: A/B switch)
     Fn.enable_wgrad_stream(os.environ.get("CGAMD_WGRAD_STREAM", "") == "1")
-    nsub = self._disc_iters + 1
     shape = (nsub * self.batch_size,) + tuple(self._dataset.image_shape)
     self._static_images = torch.zeros(shape, dtype=torch.float32, device=self.device)
     self._static_labels = torch.zeros((shape[0],), dtype=torch.int32, device=self.device)
-
-    def run_eager(images, labels):
-      self._static_images.copy_(images)
-      self._static_labels.copy_(labels)
-      return self.train_step(self._static_images, self._static_labels)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
       for _ in range(num_warmup):
-        self.train_step(self._static_images, self._static_labels)
+        step(self._static_images, self._static_labels)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    self.d_opt.reserve_tables(self._disc_iters)
-    self.g_opt.reserve_tables(1)
+    self.d_opt.reserve_tables(d_updates)
+    self.g_opt.reserve_tables(g_updates)
     self._graph = torch.cuda.CUDAGraph()
     graph_kwargs = {}
     if tpu_ops.num_replicas() > 1 or tpu_ops.force_data_parallel():
@@ -472,7 +487,7 @@ class ModularGAN(AbstractGAN):
       # (and aborts the process); thread-local mode confines the restrictions to this thread
       graph_kwargs["capture_error_mode"] = "thread_local"
     with torch.cuda.graph(self._graph, **graph_kwargs):
-      self._graph_out = self.train_step(self._static_images, self._static_labels)
+      self._graph_out = step(self._static_images, self._static_labels)
     for opt in (self.g_opt, self.d_opt):
       for t in opt.captured_tables:
         t.flush()
@@ -483,7 +498,6 @@ class ModularGAN(AbstractGAN):
       self._graph.replay()
       return self._graph_out
 
-    del run_eager
     return run
 
   # -- inference -----------------------------------------------------------------------------------
