@@ -90,6 +90,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm4) {
 // one family per kernel symbol, so that the numbers line up with `rocprofv3 --kernel-trace --stats`
 enum {
   CG_PROF_HALO_CONV = 0,          // halo_conv_kernel<*>
+  CG_PROF_HCONV_128,              // hconv_kernel<128, *> (cg_conv_halo.hip)
+  CG_PROF_HCONV_64,               // hconv_kernel<64, *>
   CG_PROF_FAST_CONV_128x128,      // fast_conv_kernel<128, 128, *>
   CG_PROF_FAST_CONV_64x128,       // fast_conv_kernel<64, 128, *>
   CG_PROF_FAST_CONV_128x64,       // fast_conv_kernel<128, 64, *>

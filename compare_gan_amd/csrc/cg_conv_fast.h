@@ -10,6 +10,12 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
                          const void* gate_out, float slope_out, const void* residual,
                          hipStream_t st);
 
+// halo-staged kernel for unit-stride <= 3x3 filters on >= 16x16 maps (cg_conv_halo.hip)
+bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in);
+void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                     int out_is_f32, const float* bias, const void* gate_in, const void* gate_out,
+                     float slope_out, const void* residual, hipStream_t st);
+
 bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                              float slope_in, const void* gate_dy);
 size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g);

@@ -27,6 +27,7 @@ bool g_prof_on = false;
 ProfSlot g_prof[CG_PROF_COUNT];
 const char* const g_prof_names[CG_PROF_COUNT] = {
     "halo_conv_kernel<*>",
+    "hconv_kernel<128, *>",          "hconv_kernel<64, *>",
     "fast_conv_kernel<128, 128, *>", "fast_conv_kernel<64, 128, *>", "fast_conv_kernel<128, 64, *>",
     "fast_conv_kernel<128, 32, *>",  "stem_fwd_kernel<*>",           "gconv_kernel<...>",
     "halo_wgrad_kernel<*>",

@@ -616,6 +616,12 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
     CG_CHECK_LAUNCH("cg_gconv(stem)");
     return CG_OK;
   }
+  if (cg_hconv_supported(g, in, gate_in, slope_in)) {
+    hipStream_t fst = (hipStream_t)stream;
+    cg_hconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fst);
+    CG_CHECK_LAUNCH("cg_gconv(halo)");
+    return CG_OK;
+  }
   if (cg_fast_conv_supported(g, in, gate_in, slope_in)) {
     hipStream_t fst = (hipStream_t)stream;
     cg_fast_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,

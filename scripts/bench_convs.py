@@ -32,6 +32,15 @@ SHAPES = {
         (128, 32, 32, 1024, 128, 1, 1, 1, 0), (128, 32, 32, 64, 128, 3, 1, 1, 0),
         (128, 32, 32, 128, 128, 3, 1, 1, 0), (128, 32, 32, 256, 128, 3, 1, 1, 0),
     ],
+    # the unit-stride 3x3 layers of the ResNet5-128 D-step (N = 2B = 128) and G forward (B = 64)
+    "hc": [
+        (128, 128, 128, 64, 64, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
+        (128, 64, 64, 128, 128, 3, 1, 1, 1), (128, 32, 32, 128, 256, 3, 1, 1, 1),
+        (128, 32, 32, 256, 256, 3, 1, 1, 1), (128, 16, 16, 256, 256, 3, 1, 1, 1),
+        (64, 64, 64, 128, 64, 3, 1, 2, 0), (64, 32, 32, 256, 128, 3, 1, 2, 0),
+        (64, 16, 16, 256, 256, 3, 1, 2, 0), (64, 128, 128, 64, 64, 3, 1, 1, 0),
+        (128, 32, 32, 128, 128, 3, 1, 1, 1), (64, 32, 32, 256, 256, 3, 1, 1, 0),
+    ],
     "resnet128": [
         (128, 128, 128, 64, 64, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
         (128, 64, 64, 128, 128, 3, 1, 1, 1), (128, 32, 32, 128, 256, 3, 1, 1, 1),
@@ -74,7 +83,8 @@ for (N, H, W, Ci, Co, k, s, up, relu) in SHAPES:
     gi = x if relu else None
     t_f = timed(lambda: K.gconv(geom, x, bt_f, bias=bias, gate_in=gi, slope_in=0.0))
     t_d = timed(lambda: K.gconv(K.geom_adjoint(geom), dy, bt_b, gate_out=gi, slope_out=0.0))
-    t_w = timed(lambda: K.gwgrad(geom, x, dy, gate_in=gi, slope_in=0.0, want_dbias=True))
+    t_w = 0.0 if os.environ.get("BENCH_NO_WGRAD") else timed(
+        lambda: K.gwgrad(geom, x, dy, gate_in=gi, slope_in=0.0, want_dbias=True))
     print("%-44s %6.1f|%4.0f %6.1f|%4.0f %6.1f|%4.0f" % (
         ",".join(map(str, (N, H, W, Ci, Co, k, s, up, relu))), t_f, fl / t_f / 1e6, t_d, fl / t_d / 1e6,
-        t_w, fl / t_w / 1e6))
+        t_w, fl / max(t_w, 1e-9) / 1e6))

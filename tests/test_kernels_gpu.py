@@ -79,6 +79,15 @@ CONV_CASES = [
     ("halo_64x64", 2, 64, 64, 64, 64, 3, 1, 1),
     ("halo_4x16", 3, 4, 16, 64, 72, 3, 1, 1),
     ("halo_16x4", 3, 16, 4, 64, 64, 3, 1, 1),
+    # halo-staged forward / data-gradient kernel (cg_conv_halo.hip; selected for these small grids
+    # by the "hconv_all" variant below): 16x16 and 8x32 tiles, ragged channel tile, 64-channel
+    # tile, non-square maps, zero-insertion phases, 1x1 filters
+    ("hc_16x16", 3, 16, 16, 128, 192, 3, 1, 1),
+    ("hc_32x32_c64", 2, 32, 32, 64, 64, 3, 1, 1),
+    ("hc_64x32", 1, 64, 32, 64, 128, 3, 1, 1),
+    ("hc_up16", 2, 16, 16, 128, 128, 3, 1, 2),
+    ("hc_up32_c64", 1, 32, 32, 64, 64, 3, 1, 2),
+    ("hc_1x1", 2, 32, 32, 128, 136, 1, 1, 1),
 ]
 
 
@@ -115,11 +124,13 @@ def test_gconv_forward_adjoint_wgrad(K, dev, case):
     assert_close_f32(db, dy64.sum(dim=(0, 1, 2)), name + " dbias", rtol=2e-4, abs_rms=2e-4)
 
 
+@pytest.mark.parametrize("size", [8, 32])
 @pytest.mark.parametrize("slope", [0.0, 0.2])
-def test_gconv_gates_residual(K, dev, slope):
-    """out = d(gate_out) * (conv(lrelu(x)) + b) + residual and its wgrad with gated operands."""
+def test_gconv_gates_residual(K, dev, slope, size):
+    """out = d(gate_out) * (conv(lrelu(x)) + b) + residual and its wgrad with gated operands
+    (size 32 is eligible for the halo-staged kernel, cg_conv_halo.hip)."""
     g = _gen(7)
-    N, H, W, Ci, Co, k = 2, 8, 8, 128, 64, 3
+    N, H, W, Ci, Co, k = 2, size, size, 128, 64, 3
     x64, xb = rand_bf16((N, H, W, Ci), g)
     w64, wb = rand_bf16((k, k, Ci, Co), g, 0.05)
     go64, gob = rand_bf16((N, H, W, Co), g)
@@ -555,6 +566,8 @@ CONV_VARIANT_ENVS = [
     ("splitk_tiles128", {"CGAMD_CONV_T128_MIN": "1"}),
     ("halo_forward", {"CGAMD_HALO": "1"}),             # experimental halo-staged forward kernel
     ("one_tap_wgrad", {"CGAMD_NO_HALO_WGRAD": "1"}),   # one-tap-per-workgroup weight gradient
+    ("hconv_all", {"CGAMD_HCONV_MIN": "1"}),           # halo-staged kernel wherever it applies
+    ("no_hconv", {"CGAMD_HCONV": "0"}),
     # round 2: fast_conv_w8_kernel (8 waves, 256x128 tiles) was written after the GPU budget of
     # round 1 was spent and has never run; verify it with this entry, then A/B it:
     # ("w8_tiles", {"CGAMD_CONV_W8": "1", "CGAMD_CONV_T128_MIN": "1"}),
@@ -571,7 +584,7 @@ def test_conv_kernel_variants(dev, variant):
     env.update(variant[1])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
-                        "-x", "-k", "test_gconv_forward_adjoint_wgrad"],
+                        "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
 
