@@ -43,6 +43,20 @@ __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// 8 floats <-> 8 packed bf16 with the hardware conversions (v_cvt_pk_bf16_f32: round to nearest
+// even, NaN stays NaN -- the same results as f2bf above)
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+__device__ __forceinline__ uint4 pack8_bf16(const float* v) {
+  const f32x8_t f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  return __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
+}
+__device__ __forceinline__ void unpack8_bf16(uint4 q, float* v) {
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+
 struct __attribute__((aligned(16))) bf16x8_raw {
   bf16_t v[8];
 };
@@ -98,6 +112,7 @@ enum {
   CG_PROF_FAST_CONV_128x32,       // fast_conv_kernel<128, 32, *>
   CG_PROF_STEM_FWD,               // stem_fwd_kernel<*>
   CG_PROF_GCONV_GENERIC,          // gconv_kernel<...> (channel counts not a multiple of 64, leaky gates)
+  CG_PROF_HWGRAD,                 // hwgrad_kernel<*> (cg_conv_halo.hip; + split reduce)
   CG_PROF_HALO_WGRAD,             // halo_wgrad_kernel<*> (+ split reduce)
   CG_PROF_FAST_WGRAD_128,         // fast_wgrad_kernel<128, *> (+ split reduce)
   CG_PROF_FAST_WGRAD_64,          // fast_wgrad_kernel<64, *> (+ split reduce)

@@ -22,6 +22,19 @@ size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g);
 void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
                           float* dw, int accumulate, float* dbias, void* ws, hipStream_t st);
 
+// out_a[i] (+)= sum_z part_a[z][i] over n4_a float4 items (and the same for the optional b pair:
+// bias-gradient partials), 8 split lanes per output; splits >= 1
+void cg_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a, const float* part_b,
+                           int64_t n4_b, float* out_b, int splits, int accumulate,
+                           hipStream_t st);
+
+// halo-staged 3x3 weight gradient (cg_conv_halo.hip)
+bool cg_hwgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in,
+                         const void* gate_dy);
+size_t cg_hwgrad_workspace_bytes(const cgConvGeom* g);
+void cg_hwgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
+                      float* dw, int accumulate, float* dbias, void* ws, hipStream_t st);
+
 // image-like inputs (Ci <= 4): im2col-in-LDS stem kernels
 bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
                             const void* gate_in, float slope_in, const void* gate_out,

@@ -2284,6 +2284,12 @@ bool phase_ok(const cgConvGeom* g) {
 
 }  // namespace
 
+void cg_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a, const float* part_b,
+                           int64_t n4_b, float* out_b, int splits, int accumulate,
+                           hipStream_t st) {
+  launch_split_reduce4_pair(part_a, n4_a, out_a, part_b, n4_b, out_b, splits, accumulate, st);
+}
+
 static int ilog2x(int x);
 
 #ifdef CG_CONV_TIMING

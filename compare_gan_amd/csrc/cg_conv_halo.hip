@@ -21,10 +21,13 @@
 //  * LDS image: 128-byte rows (one pixel x 64 channels), 16-byte chunk c of a row stored at chunk
 //    c ^ ((halo_x >> 1) & 7): the 16 lanes of every ds_read_b128 group hold 16 distinct halo_x values
 //    for any tap shift, so fragment reads are conflict-free (halo pitch TW + 2 is even);
-//  * epilogue through LDS (bias, activation, gate, residual) writing whole 16-byte channel groups.
+//  * epilogue: per-wave staging through LDS (one workgroup barrier), bias / activation / gate /
+//    residual on 8 consecutive channels per lane, hardware bf16 conversion, 16-byte stores.
 #include "cg_conv_fast.h"
 
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace {
 
@@ -49,7 +52,19 @@ struct HConvArgs {
   int out_f32, self_gate;
   float slope_out;
   FastDiv dNt, dTx, dTy;
+#ifdef CG_CONV_TIMING
+  unsigned long long* tdbg;   // 8 stamps per workgroup (scripts/hconv_timeline.py)
+#endif
 };
+#ifdef CG_CONV_TIMING
+#define HC_STAMP(slot)                                                                          \
+  do {                                                                                          \
+    if (a.tdbg && tid == 0)                                                                     \
+      a.tdbg[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define HC_STAMP(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ int hc_xcd_remap(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = b & 7;
@@ -75,15 +90,22 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   constexpr int TN = BN / 64;         // 32-channel MFMA tiles per wave (2 waves along channels)
   constexpr int BJ = BN / 64;         // weight staging pieces per wave and K-slice
   constexpr int B_BYTES = BN * 128;   // one K-slice of weights: BN rows x 64 k x 2 B
-  constexpr int LDC = BN + 4;         // epilogue staging row (floats)
   constexpr int LDS_BYTES = HC_HALO_BYTES + 2 * B_BYTES;
-  static_assert(128 * LDC * 4 <= LDS_BYTES, "epilogue staging does not fit");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 31, half = lane >> 5;
+  HC_STAMP(0);
+#ifdef CG_CONV_TIMING
+  if (a.tdbg && tid == 0) {
+    a.tdbg[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    a.tdbg[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+        __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |                 // HW_ID
+        ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // XCC_ID
+  }
+#endif
 
   // ---- workgroup -> (image, tile row, tile column, channel tile), XCD-contiguous ----
   const int wg = hc_xcd_remap(blockIdx.x, gridDim.x);
@@ -155,6 +177,10 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
                smem + HC_HALO_BYTES + slot * B_BYTES + (wave * BJ + j) * 1024);
   };
 
+  // the first loads leave before the rest of the set-up (their latency is the longest pole)
+  issue_halo(0);
+  issue_b(0, ((r0 * a.kw) + s0) * a.Ci);
+
   // ---- fragment addressing ----
   // pixel p = wm*64 + i*32 + frow of the tile -> (y, x); halo row of its tap-(0,0) input pixel
   int hb[2], hx0[2];
@@ -180,14 +206,14 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
   // ---- main loop: K-slice = (channel block, tap); the halo is staged once per channel block ----
-  issue_halo(0);
-  issue_b(0, ((r0 * a.kw) + s0) * a.Ci);
+  HC_STAMP(1);
   int tap = 0, cb = 0, ri = 0, si = 0;
   for (int it = 0; it < nk; ++it) {
     // this wave's pieces of slice `it` (and of the halo, on a block's first tap) have landed; after
     // the barrier so have everybody's, and every wave is done with the weight slot restaged below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+    if (it == 0) HC_STAMP(2);
     int ntap = tap + 1, ncb = cb, nri = ri, nsi = si + 1;
     if (nsi == ns) {
       nsi = 0;
@@ -239,79 +265,278 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     si = nsi;
   }
 
-  // ---- epilogue through LDS in two passes of 128 pixels: accumulators (fp32) -> LDS, then every
-  // thread finishes 8 consecutive channels of one pixel (bias, activation, gate, residual) and
-  // writes 16 (bf16) / 32 (fp32) contiguous bytes ----
-  constexpr int C8 = BN / 8;
-  float* Cs = reinterpret_cast<float*>(smem);
-  const int c8 = tid & (C8 - 1);
-  const int co = n0 + c8 * 8;
+  HC_STAMP(3);
+  // ---- epilogue: every wave stages its own 64-pixel x WCO-channel accumulator tile through a
+  // private LDS region (fp32, two passes of 32 pixels), then each lane finishes 8 consecutive channels
+  // of one pixel (bias, activation, gate, residual: one rounding to bf16) and writes 16 (bf16) / 32
+  // (fp32) contiguous bytes; 8 (4) lanes cover a pixel's WCO channels.  One workgroup barrier (the
+  // halo / weight images are dead), nothing block-wide after it: LDS operations of one wave complete
+  // in order.
+  constexpr int WCO = BN / 2;            // channels per wave
+  constexpr int SP = WCO * 4 + 16;       // staging row pitch in bytes (+16: conflict-free b128 writes)
+  constexpr int G8 = WCO / 8;            // 8-channel groups per row
+  constexpr int RPI = 64 / G8;           // rows per sweep of the 64 lanes
+  static_assert(8 * 32 * SP <= LDS_BYTES, "per-wave epilogue staging does not fit");
+  unsigned char* Sw = smem + wave * (32 * SP);
+  const int g8 = lane & (G8 - 1), rl = lane / G8;
+  const int co = n0 + wn * WCO + g8 * 8;
+  const bool co_ok = co < a.Co;          // Co % 8 == 0
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-  if (a.bias && co < a.Co) {
+  if (a.bias && co_ok) {
     const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
     const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
     bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
     bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
   }
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-    if ((wm >> 1) == h) {
+  __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int col = wn * (BN / 2) + j * 32 + q * 8 + 4 * half;
-            const int row = (wm & 1) * 64 + i * 32 + frow;
-            *reinterpret_cast<float4*>(Cs + row * LDC + col) =
-                make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
-                            acc[i][j][q * 4 + 3]);
-          }
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q * 8 + 4 * half) * 4) =
+            make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
+                        acc[i][j][q * 4 + 3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 32 / RPI; ++k) {
+      const int row = rl + RPI * k;
+      const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
+      const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
+      if (!co_ok) continue;
+      const int p = wm * 64 + i * 32 + row;
+      const int y = p >> TWL, x = p & (TW - 1);
+      const int oy = (ty * TH + y) * a.U + ph, ox = (tx * TW + x) * a.U + pw;
+      const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
+      float v[8] = {lo.x + bv[0], lo.y + bv[1], lo.z + bv[2], lo.w + bv[3],
+                    hi.x + bv[4], hi.y + bv[5], hi.z + bv[6], hi.w + bv[7]};
+      if (a.self_gate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+      }
+      if (a.gate_out) {
+        float gv[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!(gv[e] > 0.f)) v[e] *= a.slope_out;
+      }
+      if (a.residual) {
+        float rv[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (a.out_f32) {
+        float* op = reinterpret_cast<float*>(a.out) + o;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+      }
     }
-    __syncthreads();
-    if (co < a.Co) {
-      for (int row = tid / C8; row < 128; row += 512 / C8) {
-        const int p = h * 128 + row;
-        const int y = p >> TWL, x = p & (TW - 1);
-        const int oy = (ty * TH + y) * a.U + ph, ox = (tx * TW + x) * a.U + pw;
-        const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
-        const float4 lo = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8 + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    __builtin_amdgcn_wave_barrier();
+  }
+  HC_STAMP(4);
+#ifdef CG_CONV_TIMING
+  if (a.tdbg && tid == 0)
+    a.tdbg[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+
+// -------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions (3x3, unit stride, 'SAME'): dw[tap][ci][co] =
+// sum_pixels x[pixel + tap][ci] * dy[pixel][co]  (tf.gradients of arch_ops.conv2d w.r.t. the kernel,
+// arch_ops.py:559-573).  A workgroup owns a 64-channel x 64-out-channel block of ALL 9 taps and a
+// range of 256-pixel tiles; per tile the input window with its halo (42.5 KiB) and the dy tile
+// (32 KiB) are staged once (double-buffered, buffer_load ... lds, padding by the bounds check) and
+// every tap's operand is a shifted hardware-transpose read (ds_read_b64_tr_b16) of that window.
+// What bounded the round-1 kernel was VALU issue (13 VALU instructions per MFMA: per-tap address
+// arithmetic; PMC in profiles/r02_pmc_wgrad.txt), so here every LDS address is a per-lane base
+// register plus a compile-time immediate: the 16-byte chunk swizzle byte ^= (row & 2) << 5 only
+// depends on (row mod 4), and tap shifts / k-step offsets are constants, so four base registers
+// (one per residue) cover all 9 taps x 16 k-steps.
+// 8 waves = 2 (channel halves) x 2 (out-channel halves) x 2 (tap groups: taps 0-4 / taps 5-8 + the
+// bias-gradient column sums), 5 accumulator tiles per wave, one workgroup per CU.
+// -------------------------------------------------------------------------------------------
+struct HWgradArgs {
+  const bf16_t* in;
+  const bf16_t* dy;
+  float* out;    // dw (splits == 1) or partials [splits][K*Co]
+  float* bias;   // nullptr, dbias (splits == 1) or partials [splits][Co]
+  int N, Hin, Win, Ci, Co, pt, pl;
+  int K, ntiles;
+  int tiles_x, tiles_y, nslices, slices_per_split;
+  int accumulate;
+  FastDiv dNt, dTx, dTy;
+};
+
+typedef __attribute__((ext_vector_type(4))) short hc_s16x4_t;
+typedef __attribute__((address_space(3))) hc_s16x4_t* hc_tr_ptr;
+typedef __attribute__((address_space(3))) unsigned char* hc_lds_ptr;
+
+__device__ __forceinline__ bf16x8_t hc_tr_read2(hc_lds_ptr p) {
+  const hc_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((hc_tr_ptr)p);
+  const hc_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((hc_tr_ptr)(p + 512));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <bool RELU, int TWL>
+__global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
+  constexpr int TW = 1 << TWL, TH = 256 >> TWL, PITCH = TW + 2;
+  constexpr int HROWS = (TH + 2) * PITCH;
+  constexpr int X_BYTES = HC_HALO_BYTES, Y_BYTES = 256 * 128, BUF = X_BYTES + Y_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2, wk = (wave >> 1) & 1, wn = wave & 1;
+  const int cb = (int)fdiv((uint32_t)blockIdx.x, a.dNt);
+  const int nt = blockIdx.x - cb * a.ntiles;
+  const int c0 = nt * 64;
+
+  // ---- staging descriptors (relative to the tile's origin; the origin goes into the descriptor
+  // base).  Halo piece p = wave + 8 j: row 8 p + (lane >> 3); 16-byte chunk c of row r lives at chunk
+  // c ^ (((r >> 1) & 1) << 2), so LDS chunk (lane & 7) holds source chunk (lane & 7) ^ that
+  uint32_t hrel[HC_HSLOTS];
+  int hyx[HC_HSLOTS];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        if (a.self_gate) {
+  for (int j = 0; j < HC_HSLOTS; ++j) {
+    const int row = (wave + 8 * j) * 8 + (lane >> 3);
+    const int hy = row / PITCH, hx = row - hy * PITCH;
+    const int c = (lane & 7) ^ (((row >> 1) & 1) << 2);
+    const bool ok = row < HROWS && (cb * 64 + c * 8) < a.Ci;
+    hrel[j] = (uint32_t)(((hy * a.Win + hx) * a.Ci + c * 8) * 2);
+    hyx[j] = ok ? (hy | (hx << 16)) : 0x7fff7fff;
+  }
+  uint32_t yrel[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (!(v[e] > 0.f)) v[e] *= a.slope_out;
-        }
-        if (a.gate_out) {
-          union { uint4 q; bf16_t h8[8]; } g;
-          g.q = *reinterpret_cast<const uint4*>(a.gate_out + o);
+  for (int j = 0; j < 4; ++j) {
+    const int p = (wave * 4 + j) * 8 + (lane >> 3);
+    const int y = p >> TWL, x = p & (TW - 1);
+    const int c = (lane & 7) ^ (((p >> 1) & 1) << 2);
+    yrel[j] = (c0 + c * 8) < a.Co ? (uint32_t)(((y * a.Win + x) * a.Co + c0 + c * 8) * 2) : HC_OOB;
+  }
+  auto stage = [&](int buf, int sl) {
+    // slice -> (image, tile row, tile column): wave-uniform
+    const int t1 = (int)fdiv((uint32_t)sl, a.dTx);
+    const int tx = sl - t1 * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)t1, a.dTy);
+    const int ty = t1 - n * a.tiles_y;
+    const int iy0 = ty * TH - a.pt, ix0 = tx * TW - a.pl;
+    const bf16_t* xo = a.in + (((int64_t)n * a.Hin + iy0) * a.Win + ix0) * a.Ci + cb * 64;
+    const bf16_t* yo = a.dy + (((int64_t)n * a.Hin + ty * TH) * a.Win + tx * TW) * a.Co;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)xo, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc((void*)yo, 0, 0x7fffffff, 0x00020000);
+    unsigned char* Xb = smem + buf * BUF;
+    unsigned char* Yb = Xb + X_BYTES;
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (!(bf2f(g.h8[e]) > 0.f)) v[e] *= a.slope_out;
-        }
-        if (a.residual) {
-          union { uint4 q; bf16_t h8[8]; } r;
-          r.q = *reinterpret_cast<const uint4*>(a.residual + o);
+    for (int j = 0; j < HC_HSLOTS; ++j) {
+      if (wave + 8 * j < HC_HALO_PIECES) {
+        const int hy = hyx[j] & 0xffff, hx = hyx[j] >> 16;
+        const bool ok = (unsigned)(iy0 + hy) < (unsigned)a.Hin &&
+                        (unsigned)(ix0 + hx) < (unsigned)a.Win;
+        hc_dma16(rx, ok ? hrel[j] : HC_OOB, 0, Xb + (wave + 8 * j) * 1024);
+      }
+    }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bf2f(r.h8[e]);
-        }
-        if (a.out_f32) {
-          float* op = reinterpret_cast<float*>(a.out) + o;
-          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          union { uint4 q; bf16_t h8[8]; } w;
+    for (int j = 0; j < 4; ++j) hc_dma16(ry, yrel[j], 0, Yb + (wave * 4 + j) * 1024);
+  };
+
+  // ---- transpose-read addressing: for k-step ks (16 pixels) this lane supplies pixel
+  // ks*16 + prow (lo read) and + 4 (hi read: +512 B, the same tile row), 4 channels at tcolb
+  const int l16 = lane & 15;
+  const int prow = (lane >> 5) * 8 + (l16 >> 2);
+  const int tcolb = (((lane >> 4) & 1) * 16 + (l16 & 3) * 4) * 2;
+  const int xcolb = wk * 64 + tcolb, ycolb = wn * 64 + tcolb;
+  int xb0[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w.h8[e] = f2bf(v[e]);
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = w.q;
+  for (int c = 0; c < 4; ++c) xb0[c] = prow * 128 + (xcolb ^ (((prow + c) & 2) << 5));
+  const int yb0 = X_BYTES + prow * 128 + (ycolb ^ ((prow & 2) << 5));
+
+  f32x16_t acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+  f32x16_t accb;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) accb[v] = 0.f;
+  const bool want_bias = a.bias != nullptr && cb == 0 && wk == 0 && tg == 1;   // wave-uniform
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  const int sbeg = blockIdx.y * a.slices_per_split;
+  const int send = min(a.nslices, sbeg + a.slices_per_split);
+  if (sbeg < send) stage(0, sbeg);
+
+  hc_lds_ptr lds = (hc_lds_ptr)smem;
+  for (int sl = sbeg; sl < send; ++sl) {
+    const int buf = (sl - sbeg) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");   // slice landed for everybody; the other buffer is free
+    if (sl + 1 < send) stage(buf ^ 1, sl + 1);
+    const int boff = buf * BUF;
+    int xb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xb[c] = xb0[c] + boff;
+    const int yb = yb0 + boff;
+    auto compute = [&](auto tgc) {
+      constexpr int TG = decltype(tgc)::value;
+      constexpr int NT = TG == 0 ? 5 : 4;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int kc = TWL == 5 ? (ks >> 1) * PITCH + (ks & 1) * 16 : ks * PITCH;
+        const bf16x8_t yf = hc_tr_read2(lds + yb + ks * 2048);
+        if (TG == 1 && want_bias)
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yf, accb, 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const int tap = TG * 5 + tt;
+          const int sh = kc + (tap / 3) * PITCH + (tap % 3);
+          bf16x8_t xf = hc_tr_read2(lds + xb[sh & 3] + sh * 128);
+          if (RELU) xf = hc_relu(xf);
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc[tt], 0, 0, 0);
         }
       }
+    };
+    if (tg == 0) compute(std::integral_constant<int, 0>());
+    else compute(std::integral_constant<int, 1>());
+  }
+
+  // ---- write-out: acc[tt][v] = dw[tap][ci = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)][co = lane & 31]
+  const bool direct = (gridDim.y == 1);
+  float* outp = a.out + (direct ? 0 : (int64_t)blockIdx.y * a.K * a.Co);
+  const int co = c0 + wn * 32 + (lane & 31);
+  if (co < a.Co) {
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) {
+      const int tap = tg * 5 + tt;
+      if (tap < 9) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int ch = cb * 64 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+          if (ch >= a.Ci) continue;
+          const int64_t o = ((int64_t)tap * a.Ci + ch) * a.Co + co;
+          if (direct && a.accumulate)
+            outp[o] += acc[tt][v];
+          else
+            outp[o] = acc[tt][v];
+        }
+      }
+    }
+    // every row of accb holds the column sums; row 0 lives in accb[0] of lanes 0..31
+    if (want_bias && lane < 32) {
+      float* bp = a.bias + (direct ? 0 : (int64_t)blockIdx.y * a.Co) + co;
+      *bp = (direct && a.accumulate) ? *bp + accb[0] : accb[0];
     }
   }
 }
@@ -329,6 +554,11 @@ int hc_tile_log(int Hp, int Wp) {
 }
 
 }  // namespace
+
+#ifdef CG_CONV_TIMING
+static unsigned long long* g_hconv_tdbg = nullptr;
+extern "C" void cg_debug_set_hconv_timing_buffer(void* p) { g_hconv_tdbg = (unsigned long long*)p; }
+#endif
 
 bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in) {
   static const int enabled = hc_env("CGAMD_HCONV", 1);
@@ -380,6 +610,9 @@ void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
   a.dNt = make_fastdiv(a.ntiles);
   a.dTx = make_fastdiv(a.tiles_x);
   a.dTy = make_fastdiv(a.tiles_y);
+#ifdef CG_CONV_TIMING
+  a.tdbg = g_hconv_tdbg;
+#endif
   const bool relu = gate_in != nullptr;
   dim3 grid(g->N * a.tiles_y * a.tiles_x * a.ntiles, g->U * g->U);
   CgProfScope prof(bn == 128 ? CG_PROF_HCONV_128 : CG_PROF_HCONV_64, g, st);
@@ -396,4 +629,86 @@ void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
     else HC_LAUNCH(64, 4);
   }
 #undef HC_LAUNCH
+}
+
+// ---- weight gradient ----
+namespace {
+struct HWgradPlan {
+  int twl, tiles_x, tiles_y, nslices, tiles, splits, sps;
+};
+bool hwgrad_geom_ok(const cgConvGeom* g) {
+  return g->S == 1 && g->U == 1 && g->kh == 3 && g->kw == 3 && g->Ho == g->Hin &&
+         g->Wo == g->Win && g->pt == 1 && g->pl == 1 && (g->Ci % 64) == 0 && (g->Co % 8) == 0 &&
+         g->Co >= 32 && hc_tile_log(g->Ho, g->Wo) != 0 &&
+         (int64_t)12 * g->Win * (g->Ci > g->Co ? g->Ci : g->Co) * 2 < (1ll << 31);
+}
+HWgradPlan hwgrad_plan(const cgConvGeom* g) {
+  HWgradPlan p;
+  p.twl = hc_tile_log(g->Ho, g->Wo);
+  const int TW = 1 << p.twl, TH = 256 >> p.twl;
+  p.tiles_x = g->Wo / TW;
+  p.tiles_y = g->Ho / TH;
+  p.nslices = g->N * p.tiles_y * p.tiles_x;
+  p.tiles = (g->Ci / 64) * cdiv(g->Co, 64);
+  // one workgroup per CU: every split costs a K x Co fp32 partial
+  static const int target = hc_env("CGAMD_HWGRAD_BLOCKS", 256);
+  int s = cdiv(target, p.tiles);
+  if (s > p.nslices) s = p.nslices;
+  if (s < 1) s = 1;
+  p.sps = cdiv(p.nslices, s);
+  p.splits = cdiv(p.nslices, p.sps);
+  return p;
+}
+}  // namespace
+
+bool cg_hwgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in,
+                         const void* gate_dy) {
+  static const int enabled = hc_env("CGAMD_HWGRAD", 1);
+  static const int min_work = hc_env("CGAMD_HWGRAD_MIN", 128);
+  if (!enabled || gate_dy || !hwgrad_geom_ok(g)) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  const HWgradPlan p = hwgrad_plan(g);
+  return (int64_t)p.nslices * p.tiles >= min_work;
+}
+
+size_t cg_hwgrad_workspace_bytes(const cgConvGeom* g) {
+  if (!hwgrad_geom_ok(g)) return 0;
+  const HWgradPlan p = hwgrad_plan(g);
+  const size_t K = (size_t)9 * g->Ci;
+  return align_up(p.splits > 1 ? (size_t)p.splits * (K + 1) * g->Co * sizeof(float) : 256, 256);
+}
+
+void cg_hwgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
+                      float* dw, int accumulate, float* dbias, void* ws, hipStream_t st) {
+  const HWgradPlan p = hwgrad_plan(g);
+  HWgradArgs h;
+  h.in = (const bf16_t*)in;
+  h.dy = (const bf16_t*)dy;
+  h.N = g->N; h.Hin = g->Hin; h.Win = g->Win; h.Ci = g->Ci; h.Co = g->Co;
+  h.pt = g->pt; h.pl = g->pl;
+  h.K = 9 * g->Ci;
+  h.ntiles = cdiv(g->Co, 64);
+  h.tiles_x = p.tiles_x; h.tiles_y = p.tiles_y; h.nslices = p.nslices;
+  h.slices_per_split = p.sps;
+  h.accumulate = accumulate;
+  h.dNt = make_fastdiv(h.ntiles);
+  h.dTx = make_fastdiv(p.tiles_x);
+  h.dTy = make_fastdiv(p.tiles_y);
+  float* wsf = (float*)ws;
+  const size_t KC = (size_t)h.K * g->Co;
+  h.out = p.splits == 1 ? dw : wsf;
+  h.bias = !dbias ? nullptr : (p.splits == 1 ? dbias : wsf + (size_t)p.splits * KC);
+  dim3 grid(p.tiles, p.splits);
+  CgProfScope prof(CG_PROF_HWGRAD, g, st);
+  const bool relu = gate_in != nullptr;
+  if (p.twl == 5) {
+    if (relu) hwgrad_kernel<true, 5><<<grid, 512, 0, st>>>(h);
+    else hwgrad_kernel<false, 5><<<grid, 512, 0, st>>>(h);
+  } else {
+    if (relu) hwgrad_kernel<true, 4><<<grid, 512, 0, st>>>(h);
+    else hwgrad_kernel<false, 4><<<grid, 512, 0, st>>>(h);
+  }
+  if (p.splits > 1)
+    cg_split_reduce4_pair(wsf, (int64_t)(KC / 4), dw, wsf + (size_t)p.splits * KC, g->Co / 4,
+                          dbias, p.splits, accumulate, st);
 }

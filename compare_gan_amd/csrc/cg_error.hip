@@ -30,7 +30,7 @@ const char* const g_prof_names[CG_PROF_COUNT] = {
     "hconv_kernel<128, *>",          "hconv_kernel<64, *>",
     "fast_conv_kernel<128, 128, *>", "fast_conv_kernel<64, 128, *>", "fast_conv_kernel<128, 64, *>",
     "fast_conv_kernel<128, 32, *>",  "stem_fwd_kernel<*>",           "gconv_kernel<...>",
-    "halo_wgrad_kernel<*>",
+    "hwgrad_kernel<*>",              "halo_wgrad_kernel<*>",
     "fast_wgrad_kernel<128, *>",     "fast_wgrad_kernel<64, *>",     "stem_wgrad_kernel<*>",
     "gwgrad_kernel<...>"};
 }  // namespace

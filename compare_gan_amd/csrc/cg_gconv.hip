@@ -695,6 +695,8 @@ extern "C" size_t cg_gwgrad_workspace_bytes(const cgConvGeom* g) {
     const size_t cs = cg_colsum_workspace_bytes((int64_t)g->N * g->Ho * g->Wo, g->Co);
     if (cs > fast) fast = cs;
   }
+  const size_t halo = cg_hwgrad_workspace_bytes(g);   // 0 when the geometry is not covered
+  if (halo > fast) fast = halo;
   const size_t slow = gwgrad_slow_workspace_bytes(g);
   return fast > slow ? fast : slow;
 }
@@ -733,6 +735,12 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
       rc2 = cg_colsum(dy, (int64_t)g->N * g->Ho * g->Wo, g->Co, dbias, ws, ws_bytes, stream);
     }
     return rc2;
+  }
+  if (cg_hwgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
+    hipStream_t fst = (hipStream_t)stream;
+    cg_hwgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, ws, fst);
+    CG_CHECK_LAUNCH("cg_gwgrad(halo)");
+    return CG_OK;
   }
   if (cg_fast_wgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
