@@ -35,6 +35,20 @@ size_t cg_hwgrad_workspace_bytes(const cgConvGeom* g);
 void cg_hwgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
                       float* dw, int accumulate, float* dbias, void* ws, hipStream_t st);
 
+// RGB-input 3x3 convolutions with the input window staged in LDS (cg_conv_halo.hip)
+bool cg_wstem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
+                             const void* gate_in, float slope_in, const void* gate_out,
+                             const void* residual);
+void cg_wstem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                          int out_is_f32, const float* bias, const void* gate_in,
+                          const void* gate_out, float slope_out, hipStream_t st);
+bool cg_wstem_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                              float slope_in, const void* gate_dy);
+size_t cg_wstem_wgrad_workspace_bytes(const cgConvGeom* g);
+void cg_wstem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
+                           const void* dy, int want_bias, void* ws, int* splits_out,
+                           hipStream_t st);
+
 // image-like inputs (Ci <= 4): im2col-in-LDS stem kernels
 bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
                             const void* gate_in, float slope_in, const void* gate_out,

@@ -2551,7 +2551,9 @@ size_t cg_stem_wgrad_workspace_bytes(const cgConvGeom* g) {
   int splits, rps;
   stem_wgrad_plan(g, &splits, &rps);
   const size_t K = (size_t)g->kh * g->kw * g->Ci;
-  return align_up((size_t)splits * (K * g->Co + g->Co) * sizeof(float), 256);
+  const size_t a = align_up((size_t)splits * (K * g->Co + g->Co) * sizeof(float), 256);
+  const size_t b = cg_wstem_wgrad_workspace_bytes(g);   // window-staged form (0 if not covered)
+  return a > b ? a : b;
 }
 
 // geometry of the adjoint (data-gradient) convolution: input = g's output space
@@ -2592,6 +2594,19 @@ void cg_narrow_wgrad_launch(const cgConvGeom* g, const void* in, const void* dy,
 void cg_stem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
                           const void* dy, float* dw, int accumulate, float* dbias, void* ws,
                           hipStream_t st) {
+  if (cg_wstem_wgrad_supported(g, in, gate_in, gate_in ? 0.f : 0.f, nullptr)) {
+    // window-staged kernel (cg_conv_halo.hip); same partial layout, same strided reduce
+    CgProfScope prof(CG_PROF_STEM_WGRAD, g, st);
+    int splits = 0;
+    cg_wstem_wgrad_launch(g, in, gate_in, dy, dbias != nullptr, ws, &splits, st);
+    const int64_t KC = (int64_t)g->kh * g->kw * g->Ci * g->Co, stride = KC + g->Co;
+    split_reduce_strided_kernel<<<cdiv(KC, 32), 32 * SR_ZL, 0, st>>>((const float*)ws, splits,
+                                                                      stride, KC, dw, accumulate);
+    if (dbias)
+      split_reduce_strided_kernel<<<cdiv(g->Co, 32), 32 * SR_ZL, 0, st>>>(
+          (const float*)ws + KC, splits, stride, g->Co, dbias, accumulate);
+    return;
+  }
   stem_wgrad_run(g, in, gate_in != nullptr, dy, dw, accumulate, dbias, ws, 0, st);
 }
 

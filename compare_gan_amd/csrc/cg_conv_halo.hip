@@ -541,6 +541,295 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Image-input ("stem") 3x3 convolutions, Ci <= 3 (the first convolutions of every discriminator:
+// resnet5.py:118-121, resnet_cifar.py:136-139, resnet_biggan.py:372-377).  ~1 % of the FLOPs but HBM-
+// bound on the activation they write (forward) or read (weight gradient): 268 MB at 128x128x64 and
+// batch 128.  The round-1 kernels gathered the im2col rows from global memory element by element
+// (1.9 TB/s forward, 1.2 TB/s weight gradient); here the input window of a 256-pixel tile is staged
+// in LDS once (2 KiB), the K = 9 Ci <= 27 im2col elements of a fragment are 2-byte LDS reads at
+// per-lane constant offsets, the weights live in registers for the whole workgroup, and a
+// workgroup walks several tiles.
+// -------------------------------------------------------------------------------------------
+struct WStemArgs {
+  const bf16_t* in;
+  const bf16_t* bt;    // forward: [Co][32] bf16 (k = (r*3 + s)*Ci + c, zero-padded)
+  const bf16_t* dy;    // weight gradient: [N,H,W,Co] bf16
+  void* out;           // forward: [N,H,W,Co];  weight gradient: partials [splits][K*Co + Co] fp32
+  const float* bias;
+  int N, H, W, Ci, Co;
+  int tiles_x, tiles_y, ntiles, tiles_per_wg;
+  int relu_in, out_f32, self_gate, want_bias;
+  float slope_out;
+  FastDiv dTx, dTy;
+};
+
+constexpr int WS_WIN_MAX = 1024;   // window elements: 10 x 34 x 3 = 1020, 18 x 18 x 3 = 972
+constexpr int WS_CI = 3;           // RGB inputs (K = 27, padded to 32)
+
+// window of tile (n, ty, tx) -> LDS (u16 [TH + 2][(TW + 2) Ci]), zero outside the image
+template <int TWL>
+__device__ __forceinline__ void ws_load_window(const WStemArgs& a, int n, int ty, int tx,
+                                               bf16_t* win, int tid, int nthreads) {
+  constexpr int TW = 1 << TWL, TH = 256 >> TWL;
+  constexpr int WC = (TW + 2) * WS_CI, WE = (TH + 2) * WC;
+  const int rowlen = a.W * WS_CI;
+  for (int e = tid; e < WE; e += nthreads) {
+    const int wy = e / WC, wc = e - wy * WC;
+    const int iy = ty * TH - 1 + wy, ic = (tx * TW - 1) * WS_CI + wc;
+    bf16_t v = 0;
+    if ((unsigned)iy < (unsigned)a.H && (unsigned)ic < (unsigned)rowlen) {
+      v = a.in[((int64_t)n * a.H + iy) * rowlen + ic];
+      if (a.relu_in && (v & 0x8000)) v = 0;
+    }
+    win[e] = v;
+  }
+}
+
+// forward: 4 waves, each 64 pixels x all CT*32 output channels of a 256-pixel tile
+template <int CT, int TWL>
+__global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
+  constexpr int TW = 1 << TWL, TH = 256 >> TWL;
+  constexpr int CO = CT * 32;
+  constexpr int SP = CO * 4 + 16;   // epilogue staging row pitch (bytes)
+  constexpr int G8 = CO / 8;        // 8-channel groups per pixel
+  __shared__ __attribute__((aligned(16))) bf16_t win[WS_WIN_MAX + 8];
+  __shared__ __attribute__((aligned(16))) unsigned char stg[4 * 32 * SP];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, half = lane >> 5;
+  constexpr int WC = (TW + 2) * WS_CI, K = 9 * WS_CI;
+
+  // weights: B fragments for every channel tile and both k-steps stay in registers
+  bf16x8_t bfr[CT][2];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      bfr[ct][kk] = *reinterpret_cast<const bf16x8_t*>(a.bt + (ct * 32 + frow) * 32 + kk * 16 + half * 8);
+  // this lane's 16 im2col offsets (elements, relative to the pixel's window origin); k >= K reads
+  // the pixel's own tap-(0,0) element: its weight is zero and it belongs to the true window
+  int koff[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = (j >> 3) * 16 + half * 8 + (j & 7);
+    const int r = k / (3 * WS_CI), rem = k - r * 3 * WS_CI;
+    koff[j] = k < K ? r * WC + rem : 0;
+  }
+  float bv[8];
+  const int g8 = lane % G8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[g8 * 8 + e] : 0.f;
+
+  const int t0 = blockIdx.x * a.tiles_per_wg;
+  const int t1e = min(a.ntiles, t0 + a.tiles_per_wg);
+  for (int t = t0; t < t1e; ++t) {
+    const int q = (int)fdiv((uint32_t)t, a.dTx);
+    const int tx = t - q * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)q, a.dTy);
+    const int ty = q - n * a.tiles_y;
+    __syncthreads();   // the previous tile's window reads are done
+    ws_load_window<TWL>(a, n, ty, tx, win, tid, 256);
+    __syncthreads();
+
+    f32x16_t acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][ct][v] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = wave * 64 + i * 32 + frow;
+      const int y = p >> TWL, x = p & (TW - 1);
+      const bf16_t* wp = win + y * WC + x * WS_CI;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        union { bf16x8_t f; bf16_t h[8]; } af;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af.h[e] = wp[koff[kk * 8 + e]];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ct][kk], af.f, acc[i][ct], 0, 0, 0);
+      }
+    }
+    // epilogue: per-wave staging (see hconv_kernel), 32 pixels per pass
+    unsigned char* Sw = stg + wave * (32 * SP);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          *reinterpret_cast<float4*>(Sw + frow * SP + (ct * 32 + qq * 8 + 4 * half) * 4) =
+              make_float4(acc[i][ct][qq * 4 + 0], acc[i][ct][qq * 4 + 1], acc[i][ct][qq * 4 + 2],
+                          acc[i][ct][qq * 4 + 3]);
+      __builtin_amdgcn_wave_barrier();
+      for (int it = lane; it < 32 * G8; it += 64) {
+        const int row = it / G8;   // it % G8 == g8 when 64 % G8 == 0; general otherwise
+        const int gg = it - row * G8;
+        const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + gg * 32);
+        const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + gg * 32 + 16);
+        const int p = wave * 64 + i * 32 + row;
+        const int y = p >> TWL, x = p & (TW - 1);
+        const int64_t o = (((int64_t)n * a.H + ty * TH + y) * a.W + tx * TW + x) * a.Co + gg * 8;
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (gg == g8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        } else if (a.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += a.bias[gg * 8 + e];
+        }
+        if (a.self_gate) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+        }
+        if (a.out_f32) {
+          float* op = reinterpret_cast<float*>(a.out) + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// weight gradient: block = (64 output channels, split); per 256-pixel tile the window (LDS, as
+// above) and the dy tile (DMA, hwgrad's transpose-read image) are staged, 4 waves split the 16
+// k-steps; dw^T fragments are 8 two-byte LDS reads at constant offsets.  Partials per split
+// [K*Co + Co] (dw then dbias), reduced by the caller.
+template <int TWL>
+__global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
+  constexpr int TW = 1 << TWL, TH = 256 >> TWL, CI = WS_CI;
+  constexpr int WC = (TW + 2) * CI, K = 9 * CI;
+  constexpr int Y_BYTES = 256 * 128;
+  __shared__ __attribute__((aligned(1024))) unsigned char ysm[2 * Y_BYTES];
+  __shared__ __attribute__((aligned(16))) bf16_t win[2][WS_WIN_MAX + 8];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 64;
+  const int K_Co = K * a.Co;
+
+  // dy staging: 32 pieces of 8 pixels, 8 per wave (see hwgrad_kernel)
+  uint32_t yrel[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int p = (wave * 8 + j) * 8 + (lane >> 3);
+    const int y = p >> TWL, x = p & (TW - 1);
+    const int c = (lane & 7) ^ (((p >> 1) & 1) << 2);
+    yrel[j] = (c0 + c * 8) < a.Co ? (uint32_t)(((y * a.W + x) * a.Co + c0 + c * 8) * 2) : HC_OOB;
+  }
+  auto stage = [&](int buf, int t) {
+    const int q = (int)fdiv((uint32_t)t, a.dTx);
+    const int tx = t - q * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)q, a.dTy);
+    const int ty = q - n * a.tiles_y;
+    const bf16_t* yo = a.dy + (((int64_t)n * a.H + ty * TH) * a.W + tx * TW) * a.Co;
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc((void*)yo, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      hc_dma16(ry, yrel[j], 0, ysm + buf * Y_BYTES + (wave * 8 + j) * 1024);
+    ws_load_window<TWL>(a, n, ty, tx, win[buf], tid, 256);
+  };
+
+  // A^T fragment of k-step ks: lane -> im2col element k = lane & 31, pixels ks*16 + half*8 + e
+  const int kq = lane & 31, half = lane >> 5;
+  const int kr = kq / (3 * CI), krem = kq - kr * 3 * CI;
+  const int abase = (kq < K ? kr * WC + krem : 0) + half * 8 * CI;
+  // dy fragments (transpose reads, hwgrad_kernel's addressing)
+  const int l16 = lane & 15;
+  const int prow = half * 8 + (l16 >> 2);
+  const int tcolb = (((lane >> 4) & 1) * 16 + (l16 & 3) * 4) * 2;
+  int yb0[2];   // the 16-byte chunk swizzle flips bit 6 of the byte column, i.e. the channel tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) yb0[j] = prow * 128 + ((j * 64 + tcolb) ^ ((prow & 2) << 5));
+
+  f32x16_t acc[2], accb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      acc[j][v] = 0.f;
+      accb[j][v] = 0.f;
+    }
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  const int t0 = blockIdx.y * a.tiles_per_wg;
+  const int t1e = min(a.ntiles, t0 + a.tiles_per_wg);
+  if (t0 < t1e) stage(0, t0);
+  hc_lds_ptr ylds = (hc_lds_ptr)ysm;
+  for (int t = t0; t < t1e; ++t) {
+    const int buf = (t - t0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < t1e) stage(buf ^ 1, t + 1);
+    const bf16_t* wb = win[buf] + abase;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ks = wave * 4 + kk;
+      const int wo = TWL == 5 ? (ks >> 1) * WC + (ks & 1) * 16 * CI : ks * WC;
+      union { bf16x8_t f; bf16_t h[8]; } af;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) af.h[e] = wb[wo + e * CI];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8_t yf = hc_tr_read2(ylds + buf * Y_BYTES + yb0[j] + ks * 2048);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.f, yf, acc[j], 0, 0, 0);
+        if (a.want_bias) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yf, accb[j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- cross-wave sum through LDS, then one partial per (split): dw[k][co] rows k < K, dbias
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(ysm);   // [4 waves][64 lanes][33] floats
+  {
+    float* mine = red + (wave * 64 + lane) * 33;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) mine[j * 16 + v] = acc[j][v];
+    mine[32] = 0.f;
+  }
+  float* redb = red + 4 * 64 * 33;              // [4 waves][2][32] column sums (row 0 of accb)
+  if (lane < 32) {
+    redb[(wave * 2 + 0) * 32 + lane] = accb[0][0];
+    redb[(wave * 2 + 1) * 32 + lane] = accb[1][0];
+  }
+  __syncthreads();
+  float* outp = reinterpret_cast<float*>(a.out) + (int64_t)blockIdx.y * (K_Co + a.Co);
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = c0 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * 64 + lane) * 33 + j * 16 + v];
+        if (k < K && co < a.Co) outp[(int64_t)k * a.Co + co] = s;
+      }
+    }
+  } else if (wave == 1 && a.want_bias) {
+    const int j = lane >> 5, co = c0 + j * 32 + (lane & 31);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += redb[(w * 2 + j) * 32 + (lane & 31)];
+    if (co < a.Co) outp[K_Co + co] = s;
+  }
+}
+
 int hc_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -711,4 +1000,99 @@ void cg_hwgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, 
   if (p.splits > 1)
     cg_split_reduce4_pair(wsf, (int64_t)(KC / 4), dw, wsf + (size_t)p.splits * KC, g->Co / 4,
                           dbias, p.splits, accumulate, st);
+}
+
+// ---- image-input (stem) 3x3 convolutions ----
+namespace {
+bool wstem_geom_ok(const cgConvGeom* g) {
+  return g->S == 1 && g->U == 1 && g->kh == 3 && g->kw == 3 && g->Ci == 3 && g->pt == 1 &&
+         g->pl == 1 && g->Ho == g->Hin && g->Wo == g->Win && hc_tile_log(g->Ho, g->Wo) != 0 &&
+         (int64_t)g->N * g->Ho * g->Wo < (1ll << 31);
+}
+void wstem_fill(const cgConvGeom* g, WStemArgs* a) {
+  const int twl = hc_tile_log(g->Ho, g->Wo);
+  const int TW = 1 << twl, TH = 256 >> twl;
+  a->N = g->N; a->H = g->Hin; a->W = g->Win; a->Ci = g->Ci; a->Co = g->Co;
+  a->tiles_x = g->Wo / TW;
+  a->tiles_y = g->Ho / TH;
+  a->ntiles = g->N * a->tiles_x * a->tiles_y;
+  a->dTx = make_fastdiv(a->tiles_x);
+  a->dTy = make_fastdiv(a->tiles_y);
+}
+int wstem_wgrad_splits(const cgConvGeom* g, int* tiles_per_split) {
+  WStemArgs a;
+  wstem_fill(g, &a);
+  int s = a.ntiles < 512 ? a.ntiles : 512;
+  const int tps = cdiv(a.ntiles, s);
+  *tiles_per_split = tps;
+  return cdiv(a.ntiles, tps);
+}
+}  // namespace
+
+bool cg_wstem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
+                             const void* gate_in, float slope_in, const void* gate_out,
+                             const void* residual) {
+  static const int enabled = hc_env("CGAMD_WSTEM", 1);
+  if (!enabled || !wstem_geom_ok(g)) return false;
+  if (g->Co != 64 && g->Co != 96 && g->Co != 128) return false;
+  if ((gate_out && gate_out != out) || residual) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  return true;
+}
+
+void cg_wstem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                          int out_is_f32, const float* bias, const void* gate_in,
+                          const void* gate_out, float slope_out, hipStream_t st) {
+  WStemArgs a;
+  wstem_fill(g, &a);
+  a.in = (const bf16_t*)in; a.bt = (const bf16_t*)bt; a.dy = nullptr; a.out = out; a.bias = bias;
+  a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.self_gate = gate_out != nullptr;
+  a.want_bias = 0; a.slope_out = slope_out;
+  a.tiles_per_wg = a.ntiles >= 8192 ? 4 : (a.ntiles >= 2048 ? 2 : 1);
+  const int grid = cdiv(a.ntiles, a.tiles_per_wg);
+  const int twl = hc_tile_log(g->Ho, g->Wo);
+  CgProfScope prof(CG_PROF_STEM_FWD, g, st);
+#define WS_FWD(CT_)                                                             \
+  do {                                                                          \
+    if (twl == 5) wstem_fwd_kernel<CT_, 5><<<grid, 256, 0, st>>>(a);            \
+    else wstem_fwd_kernel<CT_, 4><<<grid, 256, 0, st>>>(a);                     \
+  } while (0)
+  if (g->Co == 64) WS_FWD(2);
+  else if (g->Co == 96) WS_FWD(3);
+  else WS_FWD(4);
+#undef WS_FWD
+}
+
+bool cg_wstem_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                              float slope_in, const void* gate_dy) {
+  static const int enabled = hc_env("CGAMD_WSTEM", 1);
+  if (!enabled || !wstem_geom_ok(g) || gate_dy || (g->Co % 8) != 0 || g->Co < 32) return false;
+  if ((int64_t)10 * g->Win * g->Co * 2 >= (1ll << 31)) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  return true;
+}
+
+size_t cg_wstem_wgrad_workspace_bytes(const cgConvGeom* g) {
+  if (!wstem_geom_ok(g)) return 0;
+  int tps;
+  const int splits = wstem_wgrad_splits(g, &tps);
+  return align_up((size_t)splits * ((size_t)27 * g->Co + g->Co) * sizeof(float), 256);
+}
+
+// partial layout [splits][K*Co + Co]; the caller (cg_conv_fast.hip) owns the strided reduce
+void cg_wstem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
+                           const void* dy, int want_bias, void* ws, int* splits_out,
+                           hipStream_t st) {
+  WStemArgs a;
+  wstem_fill(g, &a);
+  int tps;
+  const int splits = wstem_wgrad_splits(g, &tps);
+  a.in = (const bf16_t*)in; a.bt = nullptr; a.dy = (const bf16_t*)dy; a.out = ws; a.bias = nullptr;
+  a.relu_in = gate_in != nullptr; a.out_f32 = 1; a.self_gate = 0; a.slope_out = 0.f;
+  a.want_bias = want_bias;
+  a.tiles_per_wg = tps;
+  dim3 grid(cdiv(g->Co, 64), splits);
+  if (hc_tile_log(g->Ho, g->Wo) == 5) wstem_wgrad_kernel<5><<<grid, 256, 0, st>>>(a);
+  else wstem_wgrad_kernel<4><<<grid, 256, 0, st>>>(a);
+  *splits_out = splits;
 }

@@ -610,6 +610,12 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   int rc = check_geom(g, "cg_gconv");
   if (rc) return rc;
   if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
+  if (cg_wstem_conv_supported(g, in, out, gate_in, slope_in, gate_out, residual)) {
+    hipStream_t fst = (hipStream_t)stream;
+    cg_wstem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, fst);
+    CG_CHECK_LAUNCH("cg_gconv(wstem)");
+    return CG_OK;
+  }
   if (cg_stem_conv_supported(g, in, out, gate_in, slope_in, gate_out, residual)) {
     hipStream_t fst = (hipStream_t)stream;
     cg_stem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, fst);

@@ -107,6 +107,11 @@ def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slo
         raise ValueError("gate_in has the wrong number of elements")
     if bias is not None and bias.numel() != geom.Co:
         raise ValueError("bias has the wrong number of elements")
+    if gate_in is not None and gate_in.data_ptr() != x.data_ptr():
+        # a gate that is a separate tensor (second-order terms of the gradient penalty,
+        # penalty_lib.py:74-82) is only understood by the generic kernel (~85 TFLOP/s): one
+        # element-wise pass x * D(gate) and the MFMA-tiled kernels apply (exact for ReLU gates)
+        x, gate_in = lrelu_bwd(gate_in, x, slope_in), None
     out = torch.empty(oshape, dtype=F32 if out_f32 else BF16, device=x.device)
     if act_out is not None:
         if gate_out is not None:
@@ -129,6 +134,11 @@ def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, 
         raise ValueError("x has the wrong number of elements for %s" % (geom.key(),))
     if dy.numel() != geom.N * geom.Ho * geom.Wo * geom.Co:
         raise ValueError("dy has the wrong number of elements for %s" % (geom.key(),))
+    # separate gate tensors: see gconv
+    if gate_in is not None and gate_in.data_ptr() != x.data_ptr():
+        x, gate_in = lrelu_bwd(gate_in, x, slope_in), None
+    if gate_dy is not None:
+        dy, gate_dy = lrelu_bwd(gate_dy, dy, slope_dy), None
     dw = out if out is not None else torch.empty((geom.kh, geom.kw, geom.Ci, geom.Co), dtype=F32,
                                                   device=x.device)
     _req(dw, F32, "dw")

@@ -41,6 +41,10 @@ SHAPES = {
         (64, 16, 16, 256, 256, 3, 1, 2, 0), (64, 128, 128, 64, 64, 3, 1, 1, 0),
         (128, 32, 32, 128, 128, 3, 1, 1, 1), (64, 32, 32, 256, 256, 3, 1, 1, 0),
     ],
+    "stem": [
+        (128, 128, 128, 3, 64, 3, 1, 1, 1), (64, 128, 128, 3, 64, 3, 1, 1, 1),
+        (128, 32, 32, 3, 128, 3, 1, 1, 1), (128, 128, 128, 3, 96, 3, 1, 1, 1),
+    ],
     "resnet128": [
         (128, 128, 128, 64, 64, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
         (128, 64, 64, 128, 128, 3, 1, 1, 1), (128, 32, 32, 128, 256, 3, 1, 1, 1),

@@ -88,6 +88,11 @@ CONV_CASES = [
     ("hc_up16", 2, 16, 16, 128, 128, 3, 1, 2),
     ("hc_up32_c64", 1, 32, 32, 64, 64, 3, 1, 2),
     ("hc_1x1", 2, 32, 32, 128, 136, 1, 1, 1),
+    # window-staged RGB-input kernels (cg_conv_halo.hip: wstem_*): 8x32 and 16x16 tiles, 64 / 96 /
+    # 128 output channels
+    ("wstem_32", 3, 32, 32, 3, 64, 3, 1, 1),
+    ("wstem_64x32_c96", 1, 64, 32, 3, 96, 3, 1, 1),
+    ("wstem_16_c128", 5, 16, 16, 3, 128, 3, 1, 1),
 ]
 
 
@@ -164,11 +169,12 @@ def test_gconv_gates_residual(K, dev, slope, size):
         assert_close_f32(db2, dy64.sum(dim=(0, 1, 2)), "relu-gated dbias", rtol=2e-4, abs_rms=2e-4)
 
 
-def test_stem_relu_gate(K, dev):
+@pytest.mark.parametrize("size", [12, 32])
+def test_stem_relu_gate(K, dev, size):
     """Image-like input (Ci = 3) with the ReLU input gate of a D block's first convolution
-    (resnet_ops.py:165): forward, weight and bias gradients."""
+    (resnet_ops.py:165): forward, weight and bias gradients (size 32: window-staged kernels)."""
     g = _gen(21)
-    N, H, W, Ci, Co, k = 3, 12, 12, 3, 64, 3
+    N, H, W, Ci, Co, k = 3, size, size, 3, 64, 3
     x64, xb = rand_bf16((N, H, W, Ci), g)
     w64, wb = rand_bf16((k, k, Ci, Co), g, 0.2)
     bias = torch.randn(Co, generator=g, dtype=torch.float32)
@@ -568,7 +574,7 @@ CONV_VARIANT_ENVS = [
     ("one_tap_wgrad", {"CGAMD_NO_HALO_WGRAD": "1"}),   # one-tap-per-workgroup weight gradient
     # halo-staged forward / weight-gradient kernels wherever they apply
     ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1"}),
-    ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0"}),
+    ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0", "CGAMD_WSTEM": "0"}),
     # round 2: fast_conv_w8_kernel (8 waves, 256x128 tiles) was written after the GPU budget of
     # round 1 was spent and has never run; verify it with this entry, then A/B it:
     # ("w8_tiles", {"CGAMD_CONV_W8": "1", "CGAMD_CONV_T128_MIN": "1"}),
@@ -585,7 +591,7 @@ def test_conv_kernel_variants(dev, variant):
     env.update(variant[1])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
-                        "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual"],
+                        "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual or test_stem_relu_gate"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
 
