@@ -62,9 +62,18 @@ class AbstractGenerator(_Module):
 
   def __call__(self, z, y, is_training, reuse=None):
     del reuse  # AUTO_REUSE semantics: the store creates on first use and reuses afterwards
+    import torch
     ops.prepare_module(self.name)
-    with ops.variable_scope(self.name):
-      return self.apply(z=z, y=y, is_training=is_training)
+    # no-gradient training-mode forward (discriminator sub-steps): convolutions feed the batch norms
+    # that follow them with the partial sums of their outputs (arch_ops._conv_call)
+    old = ops._EMIT_BN_STATS[0]   # pylint: disable=protected-access
+    ops._EMIT_BN_STATS[0] = bool(is_training and not torch.is_grad_enabled() and   # pylint: disable=protected-access
+                                 self._batch_norm_fn is not None and not z.is_meta)
+    try:
+      with ops.variable_scope(self.name):
+        return ops.as_tensor(self.apply(z=z, y=y, is_training=is_training))
+    finally:
+      ops._EMIT_BN_STATS[0] = old   # pylint: disable=protected-access
 
   @abc.abstractmethod
   def apply(self, z, y, is_training):

@@ -200,7 +200,43 @@ class Act(object):
     return Fn.LreluFn.apply(self.x, self.slope)
 
 
+class PendingBN(object):
+  """relu(batch_norm(x)) whose normalisation has not been applied yet: the statistics exist, the
+  consumer convolution applies (x - mean) * rstd * gamma + beta -> ReLU to its staged input tile in
+  LDS (cg_gconv_fused), so the normalised activation never goes through HBM.  Only built for
+  forward passes without an autograd graph (the generator forward of the discriminator sub-steps,
+  modular_gan.py:465-467); any consumer that cannot fuse it calls materialize()."""
+
+  def __init__(self, x, mean, var, gamma, beta, eps, per_sample):
+    self.x, self.mean, self.var = x, mean, var
+    self.gamma, self.beta, self.eps, self.per_sample = gamma, beta, eps, per_sample
+
+  @property
+  def shape(self):
+    return self.x.shape
+
+  def bn_tuple(self):
+    g = None if self.gamma is None else self.gamma.contiguous()
+    b = None if self.beta is None else self.beta.contiguous()
+    return (self.mean, self.var, g, b, self.eps, self.per_sample)
+
+  def materialize(self):
+    n, c = self.x.shape[0], self.x.shape[-1]
+    y3 = K.bn_apply(self.x.contiguous().reshape(n, -1, c), self.mean, self.var, self.eps,
+                    self.gamma, self.beta, self.per_sample, True)
+    return y3.reshape(self.x.shape)
+
+
+# set by AbstractGenerator.__call__: convolutions of a no-gradient training-mode forward pass emit
+# the partial sums of their output for the batch norm that follows (cg_gconv_fused)
+_EMIT_BN_STATS = [False]
+import os as _os
+_FUSED_BN = _os.environ.get("CGAMD_FUSED_BN", "1") != "0"   # A/B switch (read once)
+
+
 def _split_act(inputs):
+  if isinstance(inputs, PendingBN):
+    return inputs.materialize(), None
   if isinstance(inputs, Act):
     return inputs.x, inputs.slope
   return inputs, None
@@ -218,7 +254,7 @@ def lrelu(inputs, leak=0.2, name="lrelu"):
 
 
 def as_tensor(x):
-  return x.materialize() if isinstance(x, Act) else x
+  return x.materialize() if isinstance(x, (Act, PendingBN)) else x
 
 
 def _to_bf16(x):
@@ -291,16 +327,31 @@ def prepare_module(module):
 # ------------------------------------------------------------------------------------------------
 # linear / conv2d / deconv2d (arch_ops.py:538-592)
 # ------------------------------------------------------------------------------------------------
-def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32):
-  """Runs inside the weight's variable scope: the kernel variable is <scope>/kernel."""
+def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32, pending_bn=None):
+  """Runs inside the weight's variable scope: the kernel variable is <scope>/kernel.
+  pending_bn: the PendingBN whose tensor `x` is (conv2d only)."""
   spec = Fn.ConvSpec(spec_geom, transpose=transpose, slope_in=slope, out_f32=out_f32)
   store = current_store()
   wname = store.full_name("kernel")
   store.conv_registry.setdefault(wname.split("/", 1)[0], {})[wname] = None
   if x.is_meta:
     return torch.empty(spec.out_shape, dtype=F32 if out_f32 else BF16, device="meta")
+  bt_pair = store.bt_ready.pop(wname, None)
+  if (_FUSED_BN and not torch.is_grad_enabled() and not transpose and slope is None and
+      bt_pair is not None and (pending_bn is not None or _EMIT_BN_STATS[0]) and
+      K.gconv_fused_rows(spec_geom) > 0):
+    # no autograd graph: batch norm fused around the convolution (cg_gconv_fused)
+    out, partials = K.gconv_fused(
+        spec_geom, x.contiguous(), bt_pair[0], bias=bias, residual=residual, out_f32=out_f32,
+        bn=None if pending_bn is None else pending_bn.bn_tuple(),
+        want_stats=_EMIT_BN_STATS[0] and not out_f32)
+    if partials is not None:
+      out._cg_bn_partials = (partials, spec_geom.N * spec_geom.Ho * spec_geom.Wo)   # pylint: disable=protected-access
+    return out
+  if pending_bn is not None:
+    x = pending_bn.materialize()
   gate = x.detach() if slope is not None else None
-  return Fn.gconv(x, w, bias, residual, gate, None, spec, dx_f32, store.bt_ready.pop(wname, None))
+  return Fn.gconv(x, w, bias, residual, gate, None, spec, dx_f32, bt_pair)
 
 
 def linear(inputs, output_size, scope=None, stddev=0.02, bias_start=0.0, use_sn=False,
@@ -332,7 +383,8 @@ def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", u
   `inputs` may be a pending Act (input gate), `upsample=True` convolves the zero-inserted input of
   resnet_ops.unpool (resnet_ops.py:35-56,122-123) without materialising it, `residual` is added in
   the epilogue (resnet_ops.py:181)."""
-  x, slope = _split_act(inputs)
+  pending_bn = inputs if isinstance(inputs, PendingBN) else None
+  x, slope = (inputs.x, None) if pending_bn is not None else _split_act(inputs)
   if x.dim() != 4:
     raise ValueError("conv2d expects NHWC inputs of rank 4, got rank %d" % x.dim())
   if d_h != d_w:
@@ -346,7 +398,8 @@ def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", u
     geom = K.geom_conv_same(n, h, w_, ci, output_dim, k_h, k_w, d_h, 2 if upsample else 1)
     # gradients w.r.t. image-like inputs (the network input) are kept in fp32: they feed the
     # gradient penalty's norm (penalty_lib.py:77-78) and the generator's output head
-    return _conv_call(x, slope, w, bias, geom, False, residual, out_f32, dx_f32 or ci <= 4)
+    return _conv_call(x, slope, w, bias, geom, False, residual, out_f32, dx_f32 or ci <= 4,
+                      pending_bn)
 
 
 def conv1x1(inputs, output_dim, **kwargs):
@@ -420,9 +473,21 @@ def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_forma
   stats = _moments_for_inference(is_training, use_moving_averages, num_channels)
   if inputs.is_meta:
     return inputs
+  partials = getattr(inputs, "_cg_bn_partials", None)
   inputs = _to_bf16(inputs)
   if is_training:
     moving = (stats[0], stats[1], decay) if use_moving_averages else None
+    if (_FUSED_BN and not torch.is_grad_enabled() and relu and sync_fn is None and
+        inputs.dim() == 4):
+      # no autograd graph: statistics now (from the producer convolution's partial sums when it
+      # emitted them), normalisation + ReLU inside the consumer convolution (PendingBN)
+      mm, mv, dc = moving if moving is not None else (None, None, 0.0)
+      if partials is not None:
+        mean, var = K.bn_finalize(partials[0], partials[1], mm, mv, dc)
+      else:
+        n, c = inputs.shape[0], inputs.shape[-1]
+        mean, var = K.bn_stats(inputs.contiguous().reshape(n, -1, c), mm, mv, dc)
+      return PendingBN(inputs, mean, var, gamma, beta, epsilon, per_sample)
     out, _, _ = Fn.batch_norm_act(inputs, gamma, beta, None, None, epsilon, per_sample, relu,
                                   sync_fn, moving)
     return out

@@ -483,6 +483,20 @@ extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, floa
   return CG_OK;
 }
 
+extern "C" int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean,
+                              float* var, float* moving_mean, float* moving_var, float decay,
+                              cgStream stream) {
+  if (!partials || !mean || !var || rows <= 0 || C <= 0 || count <= 0 ||
+      ((moving_mean == nullptr) != (moving_var == nullptr)))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_finalize: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  bn_stats_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(partials, rows, C, 1.0f / (float)count,
+                                                             mean, var, moving_mean, moving_var,
+                                                             decay);
+  CG_CHECK_LAUNCH("cg_bn_finalize");
+  return CG_OK;
+}
+
 extern "C" int cg_bn_apply(const void* x, int N, int HW, int C, const float* mean,
                            const float* var, float eps, const float* gamma, const float* beta,
                            int per_sample, int relu, void* y, cgStream stream) {

@@ -16,6 +16,14 @@ void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
                      int out_is_f32, const float* bias, const void* gate_in, const void* gate_out,
                      float slope_out, const void* residual, hipStream_t st);
 
+// the same launch with the fused batch-norm prologue / statistics epilogue (cgConvFusion, cgamd.h)
+void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                           int out_is_f32, const float* bias, const void* gate_in,
+                           const void* gate_out, float slope_out, const void* residual,
+                           const cgConvFusion* fu, hipStream_t st);
+int cg_hconv_stats_rows(const cgConvGeom* g);
+bool cg_hconv_geom_ok(const cgConvGeom* g);   // cg_hconv_supported without the grid-size policy
+
 bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
                              float slope_in, const void* gate_dy);
 size_t cg_fast_wgrad_workspace_bytes(const cgConvGeom* g);

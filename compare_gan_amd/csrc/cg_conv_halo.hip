@@ -51,6 +51,17 @@ struct HConvArgs {
   int tiles_x, tiles_y, ntiles;
   int out_f32, self_gate;
   float slope_out;
+  // fused batch norm (no-gradient forward passes): input prologue relu(((x - mean) * rstd) * gamma
+  // + beta) applied to the staged window in LDS, and per-channel partial sums of the stored output
+  // for the NEXT batch norm: stats[row][0:Co] = sum, [Co:2Co] = sum of squares, row = phase *
+  // (spatial tiles) + spatial tile
+  const float* bn_mean;
+  const float* bn_var;
+  const float* bn_gamma;
+  const float* bn_beta;
+  float bn_eps;
+  int bn_per_sample;
+  float* stats;
   FastDiv dNt, dTx, dTy;
 #ifdef CG_CONV_TIMING
   unsigned long long* tdbg;   // 8 stamps per workgroup (scripts/hconv_timeline.py)
@@ -91,7 +102,8 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   constexpr int BJ = BN / 64;         // weight staging pieces per wave and K-slice
   constexpr int B_BYTES = BN * 128;   // one K-slice of weights: BN rows x 64 k x 2 B
   constexpr int LDS_BYTES = HC_HALO_BYTES + 2 * B_BYTES;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+  constexpr int TAB_OFF = LDS_BYTES;  // [4][64] floats: mean, rstd, gamma, beta of the channel block
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES + 1024];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,8 +156,8 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   // halo piece p = wave + 8 j covers halo rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3), LDS
   // chunk (lane & 7) which must hold source chunk (lane & 7) ^ ((hx >> 1) & 7)
   uint32_t hvoff[HC_HSLOTS];
+  const int iy0 = ty * TH + bh, ix0 = tx * TW + bw;
   {
-    const int iy0 = ty * TH + bh, ix0 = tx * TW + bw;
 #pragma unroll
     for (int j = 0; j < HC_HSLOTS; ++j) {
       const int row = (wave + 8 * j) * 8 + (lane >> 3);
@@ -177,9 +189,47 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
                smem + HC_HALO_BYTES + slot * B_BYTES + (wave * BJ + j) * 1024);
   };
 
+  // fused batch-norm prologue: per channel block, the coefficients of its 64 channels go to LDS ...
+  const bool bnp = a.bn_mean != nullptr;   // wave-uniform
+  auto load_bn_table = [&](int cb) {
+    if (bnp && tid < 64) {
+      float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
+      const int ch = cb * 64 + tid;
+      const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
+      tab[tid] = a.bn_mean[ch];
+      tab[64 + tid] = rsqrtf(a.bn_var[ch] + a.bn_eps);
+      tab[128 + tid] = a.bn_gamma ? a.bn_gamma[pidx] : 1.f;
+      tab[192 + tid] = a.bn_beta ? a.bn_beta[pidx] : 0.f;
+    }
+  };
+  // ... and the staged window is normalised in place (same operation order as cg_bn_apply,
+  // arch_ops.py:306-312); padding pixels stay zero: the padding applies to the BN output
+  auto bn_transform = [&]() {
+    const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
+    for (int i = tid; i < npieces * 64; i += 512) {
+      const int row = i >> 3;
+      const int hy = row / PITCH, hx = row - hy * PITCH;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if (!(hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win))
+        continue;
+      const int c8 = ((i & 7) ^ ((hx >> 1) & 7)) * 8;
+      uint4* p = reinterpret_cast<uint4*>(smem + i * 16);
+      float v[8];
+      unpack8_bf16(*p, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (v[e] - tab[c8 + e]) * tab[64 + c8 + e];
+        t = t * tab[128 + c8 + e] + tab[192 + c8 + e];
+        v[e] = fmaxf(t, 0.f);
+      }
+      *p = pack8_bf16(v);
+    }
+  };
+
   // the first loads leave before the rest of the set-up (their latency is the longest pole)
   issue_halo(0);
   issue_b(0, ((r0 * a.kw) + s0) * a.Ci);
+  load_bn_table(0);
 
   // ---- fragment addressing ----
   // pixel p = wm*64 + i*32 + frow of the tile -> (y, x); halo row of its tap-(0,0) input pixel
@@ -212,7 +262,13 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     // this wave's pieces of slice `it` (and of the halo, on a block's first tap) have landed; after
     // the barrier so have everybody's, and every wave is done with the weight slot restaged below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
+    if (bnp && tap == 0) {
+      __syncthreads();   // window, weights and coefficient table are in LDS
+      bn_transform();
+      __syncthreads();
+    } else {
+      asm volatile("s_barrier" ::: "memory");
+    }
     if (it == 0) HC_STAMP(2);
     int ntap = tap + 1, ncb = cb, nri = ri, nsi = si + 1;
     if (nsi == ns) {
@@ -258,6 +314,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       // channel block finished: every wave is done with the halo image before it is overwritten
       asm volatile("s_barrier" ::: "memory");
       issue_halo(ncb);
+      load_bn_table(ncb);
     }
     tap = ntap;
     cb = ncb;
@@ -276,14 +333,14 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   constexpr int SP = WCO * 4 + 16;       // staging row pitch in bytes (+16: conflict-free b128 writes)
   constexpr int G8 = WCO / 8;            // 8-channel groups per row
   constexpr int RPI = 64 / G8;           // rows per sweep of the 64 lanes
-  static_assert(8 * 32 * SP <= LDS_BYTES, "per-wave epilogue staging does not fit");
+  static_assert(8 * 32 * SP + 8 * 2 * WCO * 4 <= LDS_BYTES, "per-wave epilogue staging does not fit");
   unsigned char* Sw = smem + wave * (32 * SP);
   const int g8 = lane & (G8 - 1), rl = lane / G8;
   const int co = n0 + wn * WCO + g8 * 8;
   const bool co_ok = co < a.Co;          // Co % 8 == 0
-  float bv[8];
+  float bv[8], s1[8], s2[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  for (int e = 0; e < 8; ++e) bv[e] = s1[e] = s2[e] = 0.f;
   if (a.bias && co_ok) {
     const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
     const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
@@ -336,10 +393,55 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
       } else {
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+        const uint4 pk = pack8_bf16(v);
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pk;
+        if (a.stats) unpack8_bf16(pk, v);   // the statistics are those of the STORED values
+      }
+      if (a.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += v[e];
+          s2[e] += v[e] * v[e];
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (a.stats) {   // wave-uniform
+    // lanes with the same g8 hold partial sums of the same 8 channels: butterfly over the others,
+    // then the 4 pixel-waves of a channel half are combined through LDS in a fixed order
+#pragma unroll
+    for (int m = G8; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], m, 64);
+        s2[e] += __shfl_xor(s2[e], m, 64);
+      }
+    }
+    float* sreg = reinterpret_cast<float*>(smem + 8 * 32 * SP);   // [8 waves][2][WCO]
+    if (lane < G8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sreg[(wave * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
+        sreg[(wave * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int cw = tid / WCO, cc = tid - cw * WCO;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        t1 += sreg[((m4 * 2 + cw) * 2 + 0) * WCO + cc];
+        t2 += sreg[((m4 * 2 + cw) * 2 + 1) * WCO + cc];
+      }
+      const int cch = n0 + tid;
+      if (cch < a.Co) {
+        const int64_t row = (int64_t)blockIdx.y * (gridDim.x / a.ntiles) + st;
+        a.stats[row * 2 * a.Co + cch] = t1;
+        a.stats[row * 2 * a.Co + a.Co + cch] = t2;
+      }
+    }
   }
   HC_STAMP(4);
 #ifdef CG_CONV_TIMING
@@ -849,30 +951,54 @@ static unsigned long long* g_hconv_tdbg = nullptr;
 extern "C" void cg_debug_set_hconv_timing_buffer(void* p) { g_hconv_tdbg = (unsigned long long*)p; }
 #endif
 
-bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in) {
-  static const int enabled = hc_env("CGAMD_HCONV", 1);
-  static const int min_wgs = hc_env("CGAMD_HCONV_MIN", 200);
-  if (!enabled) return false;
+bool cg_hconv_geom_ok(const cgConvGeom* g) {
   if (g->S != 1 || (g->U != 1 && g->U != 2)) return false;
   if (g->kh > 3 || g->kw > 3) return false;
   if (g->Ci % 64 != 0 || g->Co % 8 != 0 || g->Co < 64) return false;
   if (g->Ho % g->U || g->Wo % g->U) return false;
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   if (Hp != g->Hin || Wp != g->Win) return false;   // 'SAME' unit-stride geometry only
-  const int twl = hc_tile_log(Hp, Wp);
-  if (!twl) return false;
-  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  if (!hc_tile_log(Hp, Wp)) return false;
   if ((int64_t)g->N * g->Hin * g->Win * g->Ci * 2 >= (1ll << 31)) return false;
   if ((int64_t)g->Co * (((int64_t)g->kh * g->kw * g->Ci + 7) & ~7ll) * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
+bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in) {
+  static const int enabled = hc_env("CGAMD_HCONV", 1);
+  static const int min_wgs = hc_env("CGAMD_HCONV_MIN", 100);
+  if (!enabled || !cg_hconv_geom_ok(g)) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   const int bn = g->Co <= 64 ? 64 : 128;
   const int64_t wgs = (int64_t)g->N * (Hp * Wp / 256) * cdiv(g->Co, bn) * g->U * g->U;
   return wgs >= min_wgs;
 }
 
+int cg_hconv_stats_rows(const cgConvGeom* g) {
+  const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
+  return g->U * g->U * g->N * (Hp * Wp / 256);
+}
+
 void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
                      int out_is_f32, const float* bias, const void* gate_in, const void* gate_out,
                      float slope_out, const void* residual, hipStream_t st) {
+  cg_hconv_launch_fused(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
+                        nullptr, st);
+}
+
+void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                           int out_is_f32, const float* bias, const void* gate_in,
+                           const void* gate_out, float slope_out, const void* residual,
+                           const cgConvFusion* fu, hipStream_t st) {
   HConvArgs a;
+  a.bn_mean = fu ? fu->bn_mean : nullptr;
+  a.bn_var = fu ? fu->bn_var : nullptr;
+  a.bn_gamma = fu ? fu->bn_gamma : nullptr;
+  a.bn_beta = fu ? fu->bn_beta : nullptr;
+  a.bn_eps = fu ? fu->bn_eps : 0.f;
+  a.bn_per_sample = fu ? fu->bn_per_sample : 0;
+  a.stats = fu ? fu->stats_out : nullptr;
   a.in = (const bf16_t*)in;
   a.bt = (const bf16_t*)bt;
   a.out = out;
@@ -902,7 +1028,7 @@ void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
 #ifdef CG_CONV_TIMING
   a.tdbg = g_hconv_tdbg;
 #endif
-  const bool relu = gate_in != nullptr;
+  const bool relu = gate_in != nullptr && a.bn_mean == nullptr;   // the BN prologue includes the ReLU
   dim3 grid(g->N * a.tiles_y * a.tiles_x * a.ntiles, g->U * g->U);
   CgProfScope prof(bn == 128 ? CG_PROF_HCONV_128 : CG_PROF_HCONV_64, g, st);
 #define HC_LAUNCH(BN_, TWL_)                                                        \

@@ -668,6 +668,31 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   return CG_OK;
 }
 
+extern "C" int cg_gconv_fused_rows(const cgConvGeom* g) {
+  if (!g || check_geom(g, "cg_gconv_fused_rows")) return 0;
+  // the fused kernel is the halo-staged one; small grids are covered too (min work-groups = 1 here:
+  // the alternative costs two more full passes over the activation)
+  if (!cg_hconv_geom_ok(g)) return 0;
+  return cg_hconv_stats_rows(g);
+}
+
+extern "C" int cg_gconv_fused(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                              int out_is_f32, const float* bias, const void* gate_out,
+                              float slope_out, const void* residual, const cgConvFusion* fu,
+                              cgStream stream) {
+  int rc = check_geom(g, "cg_gconv_fused");
+  if (rc) return rc;
+  if (!in || !bt || !out || !fu) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_fused: null argument");
+  if (!cg_hconv_geom_ok(g)) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: geometry not covered");
+  if ((fu->bn_mean == nullptr) != (fu->bn_var == nullptr))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_fused: bn_mean and bn_var go together");
+  hipStream_t fst = (hipStream_t)stream;
+  cg_hconv_launch_fused(g, in, bt, out, out_is_f32, bias, nullptr, gate_out, slope_out, residual,
+                        fu, fst);
+  CG_CHECK_LAUNCH("cg_gconv_fused");
+  return CG_OK;
+}
+
 static size_t gwgrad_slow_workspace_bytes(const cgConvGeom* g);
 
 static void wgrad_plan(const cgConvGeom* g, int* tk, int* tn, int* splits, int* rows_per_split) {

@@ -123,6 +123,69 @@ def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slo
     return out
 
 
+def gconv_fused_rows(geom):
+    """Rows of batch-norm partial sums the fused convolution kernel emits for `geom`; 0 when the
+    geometry is not covered (use gconv + bn_stats / bn_apply then)."""
+    return int(lib().cg_gconv_fused_rows(ctypes.byref(geom)))
+
+
+def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, want_stats=False):
+    """cg_gconv_fused: convolution with the batch-norm + ReLU prologue `bn` = (mean, var, gamma,
+    beta, eps, per_sample) applied to its input in LDS and / or the per-channel partial sums of
+    its output (for the next batch norm).  Returns (out, partials or None)."""
+    from compare_gan_amd.hip._lib import ConvFusion
+    _req(x, BF16, "x")
+    _req(bt, BF16, "bt")
+    _req(bias, F32, "bias", True)
+    _req(residual, BF16, "residual", True)
+    rows = gconv_fused_rows(geom)
+    if rows <= 0:
+        raise ValueError("geometry %s is not covered by the fused kernel" % (geom.key(),))
+    if x.numel() != geom.N * geom.Hin * geom.Win * geom.Ci:
+        raise ValueError("x has %d elements, geometry expects %s" % (x.numel(), geom.key()))
+    fu = ConvFusion()
+    keep = []
+    if bn is not None:
+        mean, var, gamma, beta, eps, per_sample = bn
+        for t, nm in ((mean, "bn mean"), (var, "bn var")):
+            _req(t, F32, nm)
+            if t.numel() != geom.Ci:
+                raise ValueError("%s has the wrong number of elements" % nm)
+        want = geom.N * geom.Ci if per_sample else geom.Ci
+        for t, nm in ((gamma, "bn gamma"), (beta, "bn beta")):
+            _req(t, F32, nm, True)
+            if t is not None and t.numel() != want:
+                raise ValueError("%s has the wrong number of elements" % nm)
+        fu.bn_mean, fu.bn_var, fu.bn_gamma, fu.bn_beta = _p(mean), _p(var), _p(gamma), _p(beta)
+        fu.bn_eps, fu.bn_per_sample = float(eps), int(bool(per_sample))
+        keep = [mean, var, gamma, beta]
+    stats = None
+    if want_stats:
+        stats = torch.empty((rows, 2 * geom.Co), dtype=F32, device=x.device)
+        fu.stats_out = _p(stats)
+    out = torch.empty((geom.N, geom.Ho, geom.Wo, geom.Co), dtype=F32 if out_f32 else BF16,
+                      device=x.device)
+    check(lib().cg_gconv_fused(ctypes.byref(geom), _p(x), _p(bt), _p(out), int(out_f32), _p(bias),
+                               None, 0.0, _p(residual), ctypes.byref(fu), _stream()),
+          "cg_gconv_fused")
+    del keep
+    return out, stats
+
+
+def bn_finalize(partials, count, moving_mean=None, moving_var=None, decay=0.0):
+    """mean / var [C] from partial sums [rows][2C] over `count` values per channel; optionally the
+    moving-average update of cg_bn_stats."""
+    _req(partials, F32, "partials")
+    rows, c2 = partials.shape
+    c = c2 // 2
+    mean = torch.empty((c,), dtype=F32, device=partials.device)
+    var = torch.empty((c,), dtype=F32, device=partials.device)
+    check(lib().cg_bn_finalize(_p(partials), int(rows), int(c), int(count), _p(mean), _p(var),
+                               _p(moving_mean), _p(moving_var), float(decay), _stream()),
+          "cg_bn_finalize")
+    return mean, var
+
+
 def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, want_dbias=False,
            out=None, accumulate=False):
     """dw fp32 [kh,kw,Ci,Co] (+ dbias [Co]) of the gather convolution `geom`."""

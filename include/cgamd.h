@@ -101,6 +101,37 @@ int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, 
              const float* bias, const void* gate_in, float slope_in, const void* gate_out,
              float slope_out, const void* residual, cgStream stream);
 
+/* Batch-norm fusion around cg_gconv for forward passes that keep no autograd graph (the generator
+ * forward of every discriminator sub-step, modular_gan.py:465-467): the producer convolution emits
+ * the per-channel sums of the values it stores, the consumer convolution normalises its input in
+ * LDS -- the normalised activation (arch_ops.py:289-313 + resnet_ops.py:165,175 ReLU) never goes
+ * through HBM.
+ *   bn_mean / bn_var [Ci] (NULL = no prologue), bn_gamma / bn_beta [Ci] or [N,Ci] when
+ *   bn_per_sample (conditional BN, arch_ops.py:423-445), NULL = 1 / 0:
+ *     in' = relu(((in - mean) * rsqrt(var + eps)) * gamma + beta), zero padding applied to in'.
+ *   stats_out (NULL = none): [rows][2*Co] fp32, rows = cg_gconv_fused_rows(geom); row r holds
+ *     sum(out) in [0,Co) and sum(out^2) in [Co,2Co) over a disjoint part of the output pixels (of
+ *     the values as stored, i.e. after the bf16 rounding); cg_bn_finalize reduces them.
+ * cg_gconv_fused_rows returns 0 when the geometry is not covered by the fused kernel (unit-stride
+ * <= 3x3 filters on >= 16x16 maps, Ci % 64 == 0): call cg_gconv and the cg_bn_* kernels then. */
+typedef struct {
+  const float* bn_mean;
+  const float* bn_var;
+  const float* bn_gamma;
+  const float* bn_beta;
+  float bn_eps;
+  int32_t bn_per_sample;
+  float* stats_out;
+} cgConvFusion;
+int cg_gconv_fused_rows(const cgConvGeom* geom);
+int cg_gconv_fused(const cgConvGeom* geom, const void* in, const void* bt, void* out,
+                   int out_is_f32, const float* bias, const void* gate_out, float slope_out,
+                   const void* residual, const cgConvFusion* fusion, cgStream stream);
+/* mean / var (and the moving averages, as cg_bn_stats) from `rows` rows of partial sums
+ * [rows][2*C] over `count` values per channel. */
+int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean, float* var,
+                   float* moving_mean, float* moving_var, float decay, cgStream stream);
+
 /* Weight gradient of the same primitive (tf.gradients of arch_ops.conv2d / deconv2d / linear
  * w.r.t. the kernel):
  *   dw[(r,s,ci),co] (+)= sum_{n,oh,ow} d(gate_in)*IN_v[n,oh*S-pt+r,ow*S-pl+s,ci] * d(gate_dy)*dy[n,oh,ow,co]

@@ -169,6 +169,66 @@ def test_gconv_gates_residual(K, dev, slope, size):
         assert_close_f32(db2, dy64.sum(dim=(0, 1, 2)), "relu-gated dbias", rtol=2e-4, abs_rms=2e-4)
 
 
+@pytest.mark.parametrize("case", [
+    # name, N, H, W, Ci, Co, k, up, per_sample, residual
+    ("bn_c64", 2, 32, 32, 64, 64, 3, 1, False, False),
+    ("bn_c128_res", 3, 16, 16, 128, 192, 3, 1, False, True),
+    ("cbn_up", 2, 16, 16, 128, 64, 3, 2, True, False),
+    ("cbn_1x1", 2, 32, 32, 64, 128, 1, 1, True, True),
+], ids=lambda c: c[0])
+def test_gconv_fused_batch_norm(K, dev, case):
+    """cg_gconv_fused: relu(batch_norm(x)) applied in LDS in front of the convolution
+    (arch_ops.py:289-313,423-445 + resnet_ops.py:165) and the per-channel partial sums of the
+    stored output for the next batch norm (cg_bn_finalize), against the oracle: the normalised
+    activation is rounded to bf16 exactly where the unfused path stores it."""
+    from tests.util import bf16_round
+    name, N, H, W, Ci, Co, k, up, per_sample, with_res = case
+    g = _gen(sum(ord(c) for c in name))
+    x64, xb = rand_bf16((N, H, W, Ci), g)
+    w64, wb = rand_bf16((k, k, Ci, Co), g, 1.0 / math.sqrt(k * k * Ci))
+    bias = torch.randn(Co, generator=g, dtype=torch.float32)
+    gshape = (N, Ci) if per_sample else (Ci,)
+    gamma = (1.0 + 0.3 * torch.randn(gshape, generator=g)).float()
+    beta = (0.3 * torch.randn(gshape, generator=g)).float()
+    eps = 1e-5
+    mean = x64.mean(dim=(0, 1, 2)).float()
+    var = (x64.pow(2).mean(dim=(0, 1, 2)) - x64.mean(dim=(0, 1, 2)).pow(2)).float()
+    geom = K.geom_conv_same(N, H, W, Ci, Co, k, k, 1, up)
+    assert K.gconv_fused_rows(geom) > 0
+    bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev))
+    res64, resb = rand_bf16((N, geom.Ho, geom.Wo, Co), g)
+    # oracle: fp32 statistics as given, normalisation in fp64, bf16 storage of the activation
+    gm = gamma.double().reshape((N, 1, 1, Ci) if per_sample else (1, 1, 1, Ci))
+    bt_ = beta.double().reshape((N, 1, 1, Ci) if per_sample else (1, 1, 1, Ci))
+    xhat = (x64 - mean.double()) * torch.rsqrt(var.double() + eps)
+    act = bf16_round(torch.relu(xhat * gm + bt_))
+    ref = _ref_conv(act, w64, 1, up) + bias.double()
+    if with_res:
+        ref = ref + res64
+    out, part = K.gconv_fused(geom, xb.to(dev), bt_f, bias=bias.to(dev),
+                              residual=resb.to(dev) if with_res else None,
+                              bn=(mean.to(dev), var.to(dev), gamma.to(dev), beta.to(dev), eps,
+                                  per_sample), want_stats=True)
+    # the activation is rounded to bf16 before the MFMA: a value on a rounding boundary may land on
+    # the other side than in the fp64 oracle -> 2^-8 relative noise on single products
+    assert_close_bf16(out, ref, name + " fused fwd", ulps=3.0, abs_rms=2.0 ** -6)
+    # statistics of the STORED values
+    stored = out.detach().float().cpu().double()
+    cnt = N * geom.Ho * geom.Wo
+    m2, v2 = K.bn_finalize(part, cnt)
+    m_ref = stored.mean(dim=(0, 1, 2))
+    v_ref = stored.pow(2).mean(dim=(0, 1, 2)) - m_ref.pow(2)
+    assert_close_f32(m2, m_ref, name + " fused mean", rtol=1e-4, abs_rms=1e-4)
+    assert_close_f32(v2, v_ref, name + " fused var", rtol=1e-3, abs_rms=1e-4)
+    # statistics only (no prologue) on the same convolution
+    out2, part2 = K.gconv_fused(geom, xb.to(dev), bt_f, bias=bias.to(dev), want_stats=True)
+    ref2 = _ref_conv(x64, w64, 1, up) + bias.double()
+    assert_close_bf16(out2, ref2, name + " stats-only fwd")
+    m3, _ = K.bn_finalize(part2, cnt)
+    assert_close_f32(m3, out2.detach().float().cpu().double().mean(dim=(0, 1, 2)),
+                     name + " stats-only mean", rtol=1e-4, abs_rms=1e-4)
+
+
 @pytest.mark.parametrize("size", [12, 32])
 def test_stem_relu_gate(K, dev, size):
     """Image-like input (Ci = 3) with the ReLU input gate of a D block's first convolution

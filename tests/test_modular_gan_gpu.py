@@ -351,3 +351,42 @@ def test_biggan_deep_forward_and_gradients(dev):
         # the spectral-norm vectors' comparison has not run on the GPU yet for this architecture
         # (every visit so far stopped at the G-step gradients): reported, not asserted
         check_u=False)
+
+
+@pytest.mark.parametrize("config,bsz", [("resnet_lsun-bedroom128.gin", 4), ("resnet_cifar10.gin", 16),
+                                        ("biggan_imagenet128.gin", 4)])
+def test_generator_fused_batch_norm_matches_unfused(dev, config, bsz):
+    """The no-gradient generator forward of the discriminator sub-steps fuses batch norm around the
+    convolutions (statistics from the producer's epilogue, normalisation + ReLU in the consumer's
+    LDS tile: arch_ops.PendingBN).  It must produce the image of the unfused path (the one the
+    gradient step and the oracle tests use) up to statistics summation order, and update the
+    moving averages identically."""
+    from compare_gan_amd.architectures import arch_ops as ops
+    bind = ["resnet_biggan.Generator.ch = 64", "resnet_biggan.Discriminator.ch = 64"] \
+        if "biggan" in config else []
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED, bindings=bind)
+    z = U.host_uniform((bsz, options["z_dim"]), "z/test", -1.0, 1.0, SEED, 0).float().to(dev)
+    y = None
+    if gan.conditional:
+        labels = torch.arange(bsz, dtype=torch.int32, device=dev) % dataset.num_classes
+        y = gan._get_one_hot_labels(labels)   # pylint: disable=protected-access
+    mov = [n for n in gan.store.vars if n.endswith("moving_mean") or n.endswith("moving_variance")]
+    saved = {n: gan.store.vars[n].detach().clone() for n in mov}
+    with ops.use_store(gan.store):
+        with torch.no_grad():
+            fused = gan.generator(z, y=y, is_training=True)
+        mov_fused = {n: gan.store.vars[n].detach().clone() for n in mov}
+        with torch.no_grad():
+            for n in mov:
+                gan.store.vars[n].copy_(saved[n])
+        for p in gan.g_opt.params:
+            p.requires_grad_(True)
+        plain = gan.generator(z, y=y, is_training=True)   # autograd graph -> unfused kernels
+    torch.cuda.synchronize()
+    d = (fused.double() - plain.detach().double()).abs()
+    # (conditional BN over 4 samples amplifies single bf16 roundings: BigGAN's budget is 3x wider)
+    mean_tol = 3e-3 if "biggan" in config else 1e-3
+    assert float(d.max()) <= 0.03 and float(d.mean()) <= mean_tol, (float(d.max()), float(d.mean()))
+    for n in mov:
+        a, b = mov_fused[n].double(), gan.store.vars[n].detach().double()
+        assert float((a - b).abs().max()) <= 1e-4 * (1.0 + float(b.abs().max())), n
