@@ -156,7 +156,9 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   // halo piece p = wave + 8 j covers halo rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3), LDS
   // chunk (lane & 7) which must hold source chunk (lane & 7) ^ ((hx >> 1) & 7)
   uint32_t hvoff[HC_HSLOTS];
+  int hc8[HC_HSLOTS];   // source channel offset of the slot's chunk (only read when Ci % 64 != 0)
   const int iy0 = ty * TH + bh, ix0 = tx * TW + bw;
+  const bool ragged_ci = (a.Ci & 63) != 0;   // last channel block half empty (Ci % 32 == 0)
   {
 #pragma unroll
     for (int j = 0; j < HC_HSLOTS; ++j) {
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       const bool ok = hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin &&
                       (unsigned)ix < (unsigned)a.Win;
       hvoff[j] = ok ? (uint32_t)((((n * a.Hin + iy) * a.Win + ix) * a.Ci + c * 8) * 2) : HC_OOB;
+      hc8[j] = c * 8;
     }
   }
   uint32_t bvoff[BJ];
@@ -177,10 +180,13 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     bvoff[j] = (n0 + row) < a.Co ? (uint32_t)(((n0 + row) * a.Kp + c * 8) * 2) : HC_OOB;
   }
   auto issue_halo = [&](int cb) {
+    const int crem = a.Ci - cb * 64;   // channels left in this block (32 in a ragged last block)
 #pragma unroll
     for (int j = 0; j < HC_HSLOTS; ++j)
-      if (wave + 8 * j < npieces)
-        hc_dma16(rs_in, hvoff[j], (uint32_t)(cb * 128), smem + (wave + 8 * j) * 1024);
+      if (wave + 8 * j < npieces) {
+        const uint32_t vo = (ragged_ci && hc8[j] >= crem) ? HC_OOB : hvoff[j];
+        hc_dma16(rs_in, vo, (uint32_t)(cb * 128), smem + (wave + 8 * j) * 1024);
+      }
   };
   auto issue_b = [&](int slot, int koff) {
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   auto load_bn_table = [&](int cb) {
     if (bnp && tid < 64) {
       float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
-      const int ch = cb * 64 + tid;
+      const int ch = min(cb * 64 + tid, a.Ci - 1);   // (a ragged last block only uses its first half)
       const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
       tab[tid] = a.bn_mean[ch];
       tab[64 + tid] = rsqrtf(a.bn_var[ch] + a.bn_eps);
@@ -204,8 +210,9 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   };
   // ... and the staged window is normalised in place (same operation order as cg_bn_apply,
   // arch_ops.py:306-312); padding pixels stay zero: the padding applies to the BN output
-  auto bn_transform = [&]() {
+  auto bn_transform = [&](int cb) {
     const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
+    const int crem = a.Ci - cb * 64;
     for (int i = tid; i < npieces * 64; i += 512) {
       const int row = i >> 3;
       const int hy = row / PITCH, hx = row - hy * PITCH;
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       if (!(hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win))
         continue;
       const int c8 = ((i & 7) ^ ((hx >> 1) & 7)) * 8;
+      if (c8 >= crem) continue;   // zero-filled half of a ragged last channel block
       uint4* p = reinterpret_cast<uint4*>(smem + i * 16);
       float v[8];
       unpack8_bf16(*p, v);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (bnp && tap == 0) {
       __syncthreads();   // window, weights and coefficient table are in LDS
-      bn_transform();
+      bn_transform(cb);
       __syncthreads();
     } else {
       asm volatile("s_barrier" ::: "memory");
@@ -954,7 +962,7 @@ extern "C" void cg_debug_set_hconv_timing_buffer(void* p) { g_hconv_tdbg = (unsi
 bool cg_hconv_geom_ok(const cgConvGeom* g) {
   if (g->S != 1 || (g->U != 1 && g->U != 2)) return false;
   if (g->kh > 3 || g->kw > 3) return false;
-  if (g->Ci % 64 != 0 || g->Co % 8 != 0 || g->Co < 64) return false;
+  if (g->Ci % 32 != 0 || g->Co % 8 != 0 || g->Co < 64) return false;
   if (g->Ho % g->U || g->Wo % g->U) return false;
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   if (Hp != g->Hin || Wp != g->Win) return false;   // 'SAME' unit-stride geometry only
@@ -1010,7 +1018,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = g->kh; a.kw = g->kw;
   a.U = g->U; a.pt = g->pt; a.pl = g->pl;
   a.Kp = (g->kh * g->kw * g->Ci + 7) & ~7;
-  a.cblocks = g->Ci / 64;
+  a.cblocks = cdiv(g->Ci, 64);
   a.in_bytes = (uint32_t)((int64_t)g->N * g->Hin * g->Win * g->Ci * 2);
   a.bt_bytes = (uint32_t)((int64_t)g->Co * a.Kp * 2);
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
@@ -1053,7 +1061,7 @@ struct HWgradPlan {
 };
 bool hwgrad_geom_ok(const cgConvGeom* g) {
   return g->S == 1 && g->U == 1 && g->kh == 3 && g->kw == 3 && g->Ho == g->Hin &&
-         g->Wo == g->Win && g->pt == 1 && g->pl == 1 && (g->Ci % 64) == 0 && (g->Co % 8) == 0 &&
+         g->Wo == g->Win && g->pt == 1 && g->pl == 1 && (g->Ci % 32) == 0 && (g->Co % 8) == 0 &&
          g->Co >= 32 && hc_tile_log(g->Ho, g->Wo) != 0 &&
          (int64_t)12 * g->Win * (g->Ci > g->Co ? g->Ci : g->Co) * 2 < (1ll << 31);
 }
@@ -1064,7 +1072,7 @@ HWgradPlan hwgrad_plan(const cgConvGeom* g) {
   p.tiles_x = g->Wo / TW;
   p.tiles_y = g->Ho / TH;
   p.nslices = g->N * p.tiles_y * p.tiles_x;
-  p.tiles = (g->Ci / 64) * cdiv(g->Co, 64);
+  p.tiles = cdiv(g->Ci, 64) * cdiv(g->Co, 64);
   // one workgroup per CU: every split costs a K x Co fp32 partial
   static const int target = hc_env("CGAMD_HWGRAD_BLOCKS", 256);
   int s = cdiv(target, p.tiles);

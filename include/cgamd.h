@@ -113,7 +113,7 @@ int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, 
  *     sum(out) in [0,Co) and sum(out^2) in [Co,2Co) over a disjoint part of the output pixels (of
  *     the values as stored, i.e. after the bf16 rounding); cg_bn_finalize reduces them.
  * cg_gconv_fused_rows returns 0 when the geometry is not covered by the fused kernel (unit-stride
- * <= 3x3 filters on >= 16x16 maps, Ci % 64 == 0): call cg_gconv and the cg_bn_* kernels then. */
+ * <= 3x3 filters on >= 16x16 maps, Ci % 32 == 0): call cg_gconv and the cg_bn_* kernels then. */
 typedef struct {
   const float* bn_mean;
   const float* bn_var;

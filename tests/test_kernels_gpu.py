@@ -88,6 +88,8 @@ CONV_CASES = [
     ("hc_up16", 2, 16, 16, 128, 128, 3, 1, 2),
     ("hc_up32_c64", 1, 32, 32, 64, 64, 3, 1, 2),
     ("hc_1x1", 2, 32, 32, 128, 136, 1, 1, 1),
+    ("hc_c96", 2, 32, 32, 96, 160, 3, 1, 1),
+    ("hc_c160_up", 1, 16, 16, 160, 96, 3, 1, 2),
     # window-staged RGB-input kernels (cg_conv_halo.hip: wstem_*): 8x32 and 16x16 tiles, 64 / 96 /
     # 128 output channels
     ("wstem_32", 3, 32, 32, 3, 64, 3, 1, 1),
@@ -175,6 +177,7 @@ def test_gconv_gates_residual(K, dev, slope, size):
     ("bn_c128_res", 3, 16, 16, 128, 192, 3, 1, False, True),
     ("cbn_up", 2, 16, 16, 128, 64, 3, 2, True, False),
     ("cbn_1x1", 2, 32, 32, 64, 128, 1, 1, True, True),
+    ("cbn_c96", 2, 16, 16, 96, 64, 3, 1, True, False),
 ], ids=lambda c: c[0])
 def test_gconv_fused_batch_norm(K, dev, case):
     """cg_gconv_fused: relu(batch_norm(x)) applied in LDS in front of the convolution
