@@ -232,6 +232,7 @@ class PendingBN(object):
 _EMIT_BN_STATS = [False]
 import os as _os
 _FUSED_BN = _os.environ.get("CGAMD_FUSED_BN", "1") != "0"   # A/B switch (read once)
+_FUSED_POOL = _os.environ.get("CGAMD_FUSED_POOL", "1") != "0"
 
 
 def _split_act(inputs):
@@ -327,16 +328,26 @@ def prepare_module(module):
 # ------------------------------------------------------------------------------------------------
 # linear / conv2d / deconv2d (arch_ops.py:538-592)
 # ------------------------------------------------------------------------------------------------
-def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32, pending_bn=None):
+def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32, pending_bn=None,
+               pool=False):
   """Runs inside the weight's variable scope: the kernel variable is <scope>/kernel.
-  pending_bn: the PendingBN whose tensor `x` is (conv2d only)."""
+  pending_bn: the PendingBN whose tensor `x` is (conv2d only).  pool: 2x2 average pooling fused
+  behind the convolution (residual at the pooled size; callers check conv_pool_supported)."""
   spec = Fn.ConvSpec(spec_geom, transpose=transpose, slope_in=slope, out_f32=out_f32)
   store = current_store()
   wname = store.full_name("kernel")
   store.conv_registry.setdefault(wname.split("/", 1)[0], {})[wname] = None
   if x.is_meta:
-    return torch.empty(spec.out_shape, dtype=F32 if out_f32 else BF16, device="meta")
+    shape = spec.out_shape
+    if pool:
+      shape = (shape[0], shape[1] // 2, shape[2] // 2, shape[3])
+    return torch.empty(shape, dtype=F32 if out_f32 else BF16, device="meta")
   bt_pair = store.bt_ready.pop(wname, None)
+  if pool:
+    if pending_bn is not None:
+      x = pending_bn.materialize()
+    gate = x.detach() if slope is not None else None
+    return Fn.conv_pool(x, w, bias, residual, gate, spec, dx_f32, bt_pair)
   if (_FUSED_BN and not torch.is_grad_enabled() and not transpose and slope is None and
       bt_pair is not None and (pending_bn is not None or _EMIT_BN_STATS[0]) and
       K.gconv_fused_rows(spec_geom) > 0):
@@ -375,8 +386,23 @@ def linear(inputs, output_size, scope=None, stddev=0.02, bias_start=0.0, use_sn=
     return out.reshape(b, output_size)
 
 
+def conv_pool_supported(inputs, output_dim, k_h, k_w):
+  """True when conv2d(inputs, ..., pool=True) exists for this call site: unit-stride convolution
+  + 2x2 average pooling in one kernel (cg_gconv_fused pool_out)."""
+  if isinstance(inputs, PendingBN):
+    x, slope = inputs.x, None
+  elif isinstance(inputs, Act):
+    x, slope = inputs.x, inputs.slope
+  else:
+    x, slope = inputs, None
+  if x.is_meta or x.dim() != 4 or slope not in (None, 0.0) or not _FUSED_POOL:
+    return False
+  n, h, w_, ci = x.shape
+  return K.gconv_pool_supported(K.geom_conv_same(n, h, w_, ci, output_dim, k_h, k_w, 1, 1))
+
+
 def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", use_sn=False,
-           use_bias=True, upsample=False, residual=None, out_f32=False, dx_f32=False):
+           use_bias=True, upsample=False, residual=None, out_f32=False, dx_f32=False, pool=False):
   """2-D convolution, TF 'SAME' padding (arch_ops.py:559-573).
 
   Extensions that keep the reference semantics but fuse its neighbours into the kernel:
@@ -398,8 +424,10 @@ def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", u
     geom = K.geom_conv_same(n, h, w_, ci, output_dim, k_h, k_w, d_h, 2 if upsample else 1)
     # gradients w.r.t. image-like inputs (the network input) are kept in fp32: they feed the
     # gradient penalty's norm (penalty_lib.py:77-78) and the generator's output head
+    if pool and (upsample or d_h != 1):
+      raise ValueError("conv2d: pool=True needs a unit-stride convolution without upsampling")
     return _conv_call(x, slope, w, bias, geom, False, residual, out_f32, dx_f32 or ci <= 4,
-                      pending_bn)
+                      pending_bn, pool)
 
 
 def conv1x1(inputs, output_dim, **kwargs):

@@ -31,6 +31,17 @@ def validate_image_inputs(inputs, validate_power2=True):
     raise ValueError("Input tensor `width` is not a power of 2: ", width)
 
 
+class _Shape(object):
+  """Duck-typed NHWC tensor description for ops.conv_pool_supported."""
+
+  def __init__(self, x, channels):
+    self.shape = (x.shape[0], x.shape[1], x.shape[2], channels)
+    self.is_meta = False
+
+  def dim(self):
+    return 4
+
+
 class ResNetBlock(object):
   """ResNet block with options for various normalizations (resnet_ops.py:70-182)."""
 
@@ -62,10 +73,18 @@ class ResNetBlock(object):
       raise ValueError("Unexpected number of input channels.")
     if scale not in ["up", "down", "none"]:
       raise ValueError("Scale: got {}, expected 'up', 'down', or 'none'.".format(scale))
+    name = "{}_{}".format("same" if scale == "none" else scale, suffix)
+    if (scale == "down" and pool and strides == (1, 1) and
+        ops.conv_pool_supported(inputs, out_channels, kernel_size[0], kernel_size[1])):
+      # convolution + 2x2 average pooling in one kernel; `residual` is at the POOLED resolution
+      return ops.conv2d(
+          inputs, output_dim=out_channels, k_h=kernel_size[0], k_w=kernel_size[1], d_h=1, d_w=1,
+          use_sn=self._spectral_norm, name=name, residual=residual, pool=True)
+    if scale == "down" and pool and residual is not None:
+      raise ValueError("a pooled residual needs the fused convolution (check conv_pool_supported)")
     outputs = ops.conv2d(
         inputs, output_dim=out_channels, k_h=kernel_size[0], k_w=kernel_size[1],
-        d_h=strides[0], d_w=strides[1], use_sn=self._spectral_norm,
-        name="{}_{}".format("same" if scale == "none" else scale, suffix),
+        d_h=strides[0], d_w=strides[1], use_sn=self._spectral_norm, name=name,
         upsample=(scale == "up"), residual=residual)
     if scale == "down" and pool:
       outputs = ops.avg_pool2(outputs)
@@ -76,16 +95,23 @@ class ResNetBlock(object):
       raise ValueError("Unexpected number of input channels.")
     with ops.variable_scope(self._name):
       # variables are created in the reference order: shortcut, bn1, conv1, bn2, conv2
+      down = self._scale == "down"
+      # discriminator "down" block with both poolings fused into their convolutions' epilogues:
+      # pool(conv2) + pool(shortcut), no full-resolution tensor written (resnet_ops.py:131-133)
+      fuse = (down and not inputs.is_meta and
+              ops.conv_pool_supported(inputs, self._out_channels, 3, 3) and
+              ops.conv_pool_supported(_Shape(inputs, self._out_channels), self._out_channels,
+                                      3, 3))
       shortcut = self._get_conv(inputs, self._in_channels, self._out_channels, self._scale,
-                                suffix="conv_shortcut", pool=False)
+                                suffix="conv_shortcut", pool=fuse)
       output = self.batch_norm_relu(inputs, z=z, y=y, is_training=is_training, name="bn1")
       output = self._get_conv(output, self._in_channels, self._out_channels, self._scale1,
                               suffix="conv1")
       output = self.batch_norm_relu(output, z=z, y=y, is_training=is_training, name="bn2")
       # conv2 + shortcut in one epilogue; pool(conv2) + pool(shortcut) == pool(conv2 + shortcut)
       output = self._get_conv(output, self._out_channels, self._out_channels, self._scale2,
-                              suffix="conv2", residual=shortcut, pool=False)
-      if self._scale == "down":
+                              suffix="conv2", residual=shortcut, pool=fuse)
+      if down and not fuse:
         output = ops.avg_pool2(output)
       return output
 

@@ -16,6 +16,13 @@ void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
                      int out_is_f32, const float* bias, const void* gate_in, const void* gate_out,
                      float slope_out, const void* residual, hipStream_t st);
 
+// 64 -> 64 channel 3x3 form with register-resident weights (persistent 128-pixel tiles)
+bool cg_hconv_rw_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                           float slope_in);
+void cg_hconv_rw_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                        int out_is_f32, const float* bias, const void* gate_in,
+                        const void* gate_out, float slope_out, const void* residual,
+                        hipStream_t st);
 // the same launch with the fused batch-norm prologue / statistics epilogue (cgConvFusion, cgamd.h)
 void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, void* out,
                            int out_is_f32, const float* bias, const void* gate_in,
@@ -56,6 +63,20 @@ size_t cg_wstem_wgrad_workspace_bytes(const cgConvGeom* g);
 void cg_wstem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
                            const void* dy, int want_bias, void* ws, int* splits_out,
                            hipStream_t st);
+
+// forms with a 2x2 average pooling fused behind the convolution (pooled output / pooled-resolution dy)
+void cg_hwgrad_launch_pooled(const cgConvGeom* g, const void* in, const void* gate_in,
+                             const void* dy, int dy_pooled, float* dw, int accumulate,
+                             float* dbias, void* ws, hipStream_t st);
+void cg_wstem_conv_launch_pool(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                               int out_is_f32, const float* bias, const void* gate_in,
+                               const void* gate_out, float slope_out, int pool, hipStream_t st);
+void cg_wstem_wgrad_launch_pooled(const cgConvGeom* g, const void* in, const void* gate_in,
+                                  const void* dy, int dy_pooled, int want_bias, void* ws,
+                                  int* splits_out, hipStream_t st);
+// strided partial reduce of the stem weight gradients (cg_conv_fast.hip)
+void cg_stem_partial_reduce(const cgConvGeom* g, const void* ws, int splits, float* dw,
+                            float* dbias, int accumulate, hipStream_t st);
 
 // image-like inputs (Ci <= 4): im2col-in-LDS stem kernels
 bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* out,

@@ -2591,6 +2591,16 @@ void cg_narrow_wgrad_launch(const cgConvGeom* g, const void* in, const void* dy,
   stem_wgrad_run(&t, dy, 0, in, dw, accumulate, nullptr, ws, 1, st);
 }
 
+void cg_stem_partial_reduce(const cgConvGeom* g, const void* ws, int splits, float* dw,
+                            float* dbias, int accumulate, hipStream_t st) {
+  const int64_t KC = (int64_t)g->kh * g->kw * g->Ci * g->Co, stride = KC + g->Co;
+  split_reduce_strided_kernel<<<cdiv(KC, 32), 32 * SR_ZL, 0, st>>>((const float*)ws, splits, stride,
+                                                                    KC, dw, accumulate);
+  if (dbias)
+    split_reduce_strided_kernel<<<cdiv(g->Co, 32), 32 * SR_ZL, 0, st>>>(
+        (const float*)ws + KC, splits, stride, g->Co, dbias, accumulate);
+}
+
 void cg_stem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
                           const void* dy, float* dw, int accumulate, float* dbias, void* ws,
                           hipStream_t st) {
@@ -2599,12 +2609,7 @@ void cg_stem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     CgProfScope prof(CG_PROF_STEM_WGRAD, g, st);
     int splits = 0;
     cg_wstem_wgrad_launch(g, in, gate_in, dy, dbias != nullptr, ws, &splits, st);
-    const int64_t KC = (int64_t)g->kh * g->kw * g->Ci * g->Co, stride = KC + g->Co;
-    split_reduce_strided_kernel<<<cdiv(KC, 32), 32 * SR_ZL, 0, st>>>((const float*)ws, splits,
-                                                                      stride, KC, dw, accumulate);
-    if (dbias)
-      split_reduce_strided_kernel<<<cdiv(g->Co, 32), 32 * SR_ZL, 0, st>>>(
-          (const float*)ws + KC, splits, stride, g->Co, dbias, accumulate);
+    cg_stem_partial_reduce(g, ws, splits, dw, dbias, accumulate, st);
     return;
   }
   stem_wgrad_run(g, in, gate_in != nullptr, dy, dw, accumulate, dbias, ws, 0, st);

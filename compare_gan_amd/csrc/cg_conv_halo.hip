@@ -62,6 +62,13 @@ struct HConvArgs {
   float bn_eps;
   int bn_per_sample;
   float* stats;
+  // 2x2 average pooling fused around the convolution (resnet_ops.py:131-133 and its gradient):
+  //  pool   : the output is pooled in the epilogue -> [N, Ho/2, Wo/2, Co] (bias before, residual
+  //           after the pooling); no output gates
+  //  in_up  : the input tensor is [N, Hin/2, Win/2, Ci] and read as its nearest-neighbour
+  //           up-sampling (the gradient of the pooling is that up-sampling times 1/4 = out_scale)
+  int pool, in_up;
+  float out_scale;
   FastDiv dNt, dTx, dTy;
 #ifdef CG_CONV_TIMING
   unsigned long long* tdbg;   // 8 stamps per workgroup (scripts/hconv_timeline.py)
@@ -95,7 +102,9 @@ __device__ __forceinline__ bf16x8_t hc_relu(bf16x8_t v) {
 }
 
 // BN: output channels per workgroup (128 or 64); TWL: log2 of the tile width (5: 8x32, 4: 16x16)
-template <int BN, bool RELU, int TWL>
+// FUSE: 0 = plain, 1 = batch-norm prologue / statistics epilogue, 2 = pooled epilogue (separate
+// instantiations: the fusions must not cost the plain kernel registers)
+template <int BN, bool RELU, int TWL, int FUSE>
 __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   constexpr int TW = 1 << TWL, TH = 256 >> TWL, PITCH = TW + 2;
   constexpr int TN = BN / 64;         // 32-channel MFMA tiles per wave (2 waves along channels)
@@ -168,7 +177,10 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       const int iy = iy0 + hy, ix = ix0 + hx;
       const bool ok = hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin &&
                       (unsigned)ix < (unsigned)a.Win;
-      hvoff[j] = ok ? (uint32_t)((((n * a.Hin + iy) * a.Win + ix) * a.Ci + c * 8) * 2) : HC_OOB;
+      const int us = a.in_up;   // 0 / 1: logical pixel (iy, ix) lives at (iy >> us, ix >> us)
+      hvoff[j] = ok ? (uint32_t)((((n * (a.Hin >> us) + (iy >> us)) * (a.Win >> us) + (ix >> us)) *
+                                      a.Ci + c * 8) * 2)
+                    : HC_OOB;
       hc8[j] = c * 8;
     }
   }
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   };
 
   // fused batch-norm prologue: per channel block, the coefficients of its 64 channels go to LDS ...
-  const bool bnp = a.bn_mean != nullptr;   // wave-uniform
+  const bool bnp = FUSE == 1 && a.bn_mean != nullptr;   // wave-uniform
   auto load_bn_table = [&](int cb) {
     if (bnp && tid < 64) {
       float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
@@ -356,6 +368,86 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
   }
   __syncthreads();
+  const float osc = a.out_scale;
+  if constexpr (FUSE == 2) {
+    // ---- pooled epilogue.  The wave's 64 pixels are two tile rows (8x32 tiles: rows wm*2 + i, so
+    // vertical neighbours are acc[0] / acc[1] of the SAME lane: summed in registers, one staging
+    // pass) or four half rows (16x16 tiles: staged rows r and r + 16 of a pass are vertical
+    // neighbours).  Every lane then finishes pooled pixels from 2 (4) staged rows: no cross-lane
+    // traffic.
+    constexpr int NPASS = TWL == 5 ? 1 : 2;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 t = make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
+                                 acc[i][j][q * 4 + 3]);
+          if (TWL == 5) {
+            t.x += acc[1][j][q * 4 + 0]; t.y += acc[1][j][q * 4 + 1];
+            t.z += acc[1][j][q * 4 + 2]; t.w += acc[1][j][q * 4 + 3];
+          }
+          *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q * 8 + 4 * half) * 4) = t;
+        }
+      __builtin_amdgcn_wave_barrier();
+      // items: (pooled pixel x2, channel group); 8x32: 16 x G8 per pass, 16x16: 8 x G8 per pass
+      constexpr int NPX = TWL == 5 ? 16 : 8;
+#pragma unroll
+      for (int it = lane; it < NPX * G8; it += 64) {
+        const int x2 = it / G8, gg = it - x2 * G8;
+        const unsigned char* r0 = Sw + (2 * x2) * SP + gg * 32;
+        float v[8];
+        {
+          const float4 a0 = *reinterpret_cast<const float4*>(r0);
+          const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16);
+          const float4 b0 = *reinterpret_cast<const float4*>(r0 + SP);
+          const float4 b1 = *reinterpret_cast<const float4*>(r0 + SP + 16);
+          v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
+          v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
+        }
+        if (TWL == 4) {
+          const float4 a0 = *reinterpret_cast<const float4*>(r0 + 16 * SP);
+          const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16 * SP + 16);
+          const float4 b0 = *reinterpret_cast<const float4*>(r0 + 17 * SP);
+          const float4 b1 = *reinterpret_cast<const float4*>(r0 + 17 * SP + 16);
+          v[0] += a0.x + b0.x; v[1] += a0.y + b0.y; v[2] += a0.z + b0.z; v[3] += a0.w + b0.w;
+          v[4] += a1.x + b1.x; v[5] += a1.y + b1.y; v[6] += a1.z + b1.z; v[7] += a1.w + b1.w;
+        }
+        const int cq = n0 + wn * WCO + gg * 8;
+        if (cq >= a.Co) continue;
+        const int y2 = TWL == 4 ? wm * 2 + i : wm;   // pooled row / column within the tile
+        const int oy = ((ty * TH) >> 1) + y2, ox = ((tx * TW) >> 1) + x2;
+        const int64_t o = ((int64_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Co + cq;
+        if (a.bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(a.bias + cq);
+          const float4 b1 = *reinterpret_cast<const float4*>(a.bias + cq + 4);
+          v[0] = 0.25f * v[0] + b0.x; v[1] = 0.25f * v[1] + b0.y; v[2] = 0.25f * v[2] + b0.z;
+          v[3] = 0.25f * v[3] + b0.w; v[4] = 0.25f * v[4] + b1.x; v[5] = 0.25f * v[5] + b1.y;
+          v[6] = 0.25f * v[6] + b1.z; v[7] = 0.25f * v[7] + b1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= 0.25f;
+        }
+        if (a.residual) {
+          float rv[8];
+          unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (a.out_f32) {
+          float* op = reinterpret_cast<float*>(a.out) + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    HC_STAMP(4);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -376,8 +468,8 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       const int y = p >> TWL, x = p & (TW - 1);
       const int oy = (ty * TH + y) * a.U + ph, ox = (tx * TW + x) * a.U + pw;
       const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
-      float v[8] = {lo.x + bv[0], lo.y + bv[1], lo.z + bv[2], lo.w + bv[3],
-                    hi.x + bv[4], hi.y + bv[5], hi.z + bv[6], hi.w + bv[7]};
+      float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
+                    hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
       if (a.self_gate) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -403,9 +495,9 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       } else {
         const uint4 pk = pack8_bf16(v);
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pk;
-        if (a.stats) unpack8_bf16(pk, v);   // the statistics are those of the STORED values
+        if (FUSE == 1 && a.stats) unpack8_bf16(pk, v);   // statistics of the STORED values
       }
-      if (a.stats) {
+      if (FUSE == 1 && a.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           s1[e] += v[e];
@@ -415,7 +507,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (a.stats) {   // wave-uniform
+  if (FUSE == 1 && a.stats) {   // wave-uniform
     // lanes with the same g8 hold partial sums of the same 8 channels: butterfly over the others,
     // then the 4 pixel-waves of a channel half are combined through LDS in a fixed order
 #pragma unroll
@@ -460,6 +552,185 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
 
 
 // -------------------------------------------------------------------------------------------
+// 64 -> 64 channel 3x3 convolutions (ResNet5 D block B0 / G block B5 at 128x128: 15 % of the D-step
+// FLOPs).  With one 64-channel block the K loop of hconv_kernel is only 9 slices, and its per-
+// workgroup set-up, first-load latency and epilogue cost as much as the loop (workgroup timeline in
+// profiles/r02_hconv_timeline.txt: 13 k of 26 k cycles).  Here the whole weight panel of a wave
+// (9 taps x 64 k x 32 out-channels = 36 KiB -> 144 VGPRs) stays in registers, so nothing but the
+// input window is staged: persistent 4-wave workgroups (2 per CU) walk 128-pixel tiles (4 x 32),
+// the next tile's window (26 KiB) is in flight while the current one is multiplied, one barrier per
+// tile, and the per-wave epilogue of one workgroup overlaps the MFMA work of the other.
+// -------------------------------------------------------------------------------------------
+constexpr int RW_PIECES = 26;             // 6 x 34 = 204 halo rows -> 26 pieces of 8 rows
+constexpr int RW_HB = RW_PIECES * 1024;   // one window buffer
+constexpr int RW_SLOTS = 7;               // pieces per wave (4 waves)
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
+  constexpr int TW = 32, TH = 4, PITCH = TW + 2, HROWS = (TH + 2) * PITCH;
+  constexpr int SP = 32 * 4 + 16;         // epilogue staging row pitch (32 channels fp32 + pad)
+  constexpr int STG = 4 * 32 * SP;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * RW_HB + STG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, half = lane >> 5;
+
+  // ---- this wave's weight panel: out-channels wn*32 + frow, all 9 taps x 64 k ----
+  bf16x8_t bw[9][4];
+  {
+    const bf16_t* wp = a.bt + (int64_t)(wn * 32 + frow) * a.Kp + half * 8;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        bw[t][kk] = *reinterpret_cast<const bf16x8_t*>(wp + t * 64 + kk * 16);
+  }
+  // ---- window staging descriptors, relative to the tile's window origin ----
+  uint32_t hrel[RW_SLOTS];
+  int hyx[RW_SLOTS];
+#pragma unroll
+  for (int j = 0; j < RW_SLOTS; ++j) {
+    const int row = (wave + 4 * j) * 8 + (lane >> 3);
+    const int hy = row / PITCH, hx = row - hy * PITCH;
+    const int c = (lane & 7) ^ ((hx >> 1) & 7);
+    hrel[j] = (uint32_t)(((hy * a.Win + hx) * 64 + c * 8) * 2);
+    hyx[j] = row < HROWS ? (hy | (hx << 16)) : 0x7fff7fff;
+  }
+  auto stage = [&](int buf, int t) {
+    const int q = (int)fdiv((uint32_t)t, a.dTx);
+    const int tx = t - q * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)q, a.dTy);
+    const int ty = q - n * a.tiles_y;
+    const int iy0 = ty * TH - a.pt, ix0 = tx * TW - a.pl;
+    const bf16_t* xo = a.in + (((int64_t)n * a.Hin + iy0) * a.Win + ix0) * 64;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)xo, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < RW_SLOTS; ++j) {
+      if (wave + 4 * j < RW_PIECES) {
+        const int hy = hyx[j] & 0xffff, hx = hyx[j] >> 16;
+        const bool ok = (unsigned)(iy0 + hy) < (unsigned)a.Hin &&
+                        (unsigned)(ix0 + hx) < (unsigned)a.Win;
+        hc_dma16(rx, ok ? hrel[j] : HC_OOB, 0, smem + buf * RW_HB + (wave + 4 * j) * 1024);
+      }
+    }
+  };
+  // ---- fragment addressing: pixel (y = wm*2 + i, x = frow); chunk swizzle by halo column ----
+  int colx[3][4];
+#pragma unroll
+  for (int si = 0; si < 3; ++si)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      colx[si][kk] = ((kk * 2 + half) ^ (((frow + si) >> 1) & 7)) << 4;
+  const int hb0 = ((wm * 2) * PITCH + frow) * 128;
+
+  // ---- epilogue constants (per-wave staging as in hconv_kernel: 32 channels per wave) ----
+  constexpr int G8 = 4, RPI = 16;
+  unsigned char* Sw = smem + 2 * RW_HB + wave * (32 * SP);
+  const int g8 = lane & (G8 - 1), rl = lane / G8;
+  const int co = wn * 32 + g8 * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  if (a.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+    bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+  }
+
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  int t = blockIdx.x;
+  if (t < ntiles) stage(0, t);
+  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    const int buf = it & 1;
+    // the window DMA of this tile was issued BEFORE the previous tile's output stores; vmcnt counts
+    // stores too and retires in order, so leaving exactly those stores outstanding (4 bf16 / 8 fp32
+    // store instructions per wave and tile) waits for the window without draining the stores
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (a.out_f32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");   // window landed; everyone is done with the other buffer
+    if (t + (int)gridDim.x < ntiles) stage(buf ^ 1, t + gridDim.x);
+    const unsigned char* Hb = smem + buf * RW_HB + hb0;
+
+    f32x16_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ri = tap / 3, si = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(
+              Hb + ((i + ri) * PITCH + si) * 128 + colx[si][kk]);
+          if (RELU) af = hc_relu(af);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][kk], af, acc[i], 0, 0, 0);
+        }
+      }
+      // fragment reads are not hoisted across taps: 144 of the 256 registers hold the weights
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue of this tile (wave-private staging: no workgroup barrier) ----
+    const int q = (int)fdiv((uint32_t)t, a.dTx);
+    const int tx = t - q * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)q, a.dTy);
+    const int ty = q - n * a.tiles_y;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+        *reinterpret_cast<float4*>(Sw + frow * SP + (qq * 8 + 4 * half) * 4) =
+            make_float4(acc[i][qq * 4 + 0], acc[i][qq * 4 + 1], acc[i][qq * 4 + 2],
+                        acc[i][qq * 4 + 3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 32 / RPI; ++k) {
+        const int row = rl + RPI * k;   // x within the tile row
+        const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
+        const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
+        const int oy = ty * TH + wm * 2 + i, ox = tx * TW + row;
+        const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
+        float v[8] = {lo.x + bv[0], lo.y + bv[1], lo.z + bv[2], lo.w + bv[3],
+                      hi.x + bv[4], hi.y + bv[5], hi.z + bv[6], hi.w + bv[7]};
+        if (a.self_gate) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+        }
+        if (a.gate_out) {
+          float gv[8];
+          unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!(gv[e] > 0.f)) v[e] *= a.slope_out;
+        }
+        if (a.residual) {
+          float rv[8];
+          unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (a.out_f32) {
+          float* op = reinterpret_cast<float*>(a.out) + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // Weight gradient of the same convolutions (3x3, unit stride, 'SAME'): dw[tap][ci][co] =
 // sum_pixels x[pixel + tap][ci] * dy[pixel][co]  (tf.gradients of arch_ops.conv2d w.r.t. the kernel,
 // arch_ops.py:559-573).  A workgroup owns a 64-channel x 64-out-channel block of ALL 9 taps and a
@@ -483,6 +754,8 @@ struct HWgradArgs {
   int K, ntiles;
   int tiles_x, tiles_y, nslices, slices_per_split;
   int accumulate;
+  int dy_up;         // dy is [N, H/2, W/2, Co]: the gradient of a 2x2 average pooling behind the
+  float out_scale;   // convolution (its nearest-neighbour up-sampling times out_scale = 1/4)
   FastDiv dNt, dTx, dTy;
 };
 
@@ -531,7 +804,10 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
     const int p = (wave * 4 + j) * 8 + (lane >> 3);
     const int y = p >> TWL, x = p & (TW - 1);
     const int c = (lane & 7) ^ (((p >> 1) & 1) << 2);
-    yrel[j] = (c0 + c * 8) < a.Co ? (uint32_t)(((y * a.Win + x) * a.Co + c0 + c * 8) * 2) : HC_OOB;
+    const int us = a.dy_up;
+    yrel[j] = (c0 + c * 8) < a.Co
+                  ? (uint32_t)((((y >> us) * (a.Win >> us) + (x >> us)) * a.Co + c0 + c * 8) * 2)
+                  : HC_OOB;
   }
   auto stage = [&](int buf, int sl) {
     // slice -> (image, tile row, tile column): wave-uniform
@@ -541,7 +817,9 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
     const int ty = t1 - n * a.tiles_y;
     const int iy0 = ty * TH - a.pt, ix0 = tx * TW - a.pl;
     const bf16_t* xo = a.in + (((int64_t)n * a.Hin + iy0) * a.Win + ix0) * a.Ci + cb * 64;
-    const bf16_t* yo = a.dy + (((int64_t)n * a.Hin + ty * TH) * a.Win + tx * TW) * a.Co;
+    const int us = a.dy_up;   // tile origins are even
+    const bf16_t* yo = a.dy + (((int64_t)n * (a.Hin >> us) + ((ty * TH) >> us)) * (a.Win >> us) +
+                               ((tx * TW) >> us)) * a.Co;
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc((void*)xo, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry =
@@ -637,16 +915,16 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
           if (ch >= a.Ci) continue;
           const int64_t o = ((int64_t)tap * a.Ci + ch) * a.Co + co;
           if (direct && a.accumulate)
-            outp[o] += acc[tt][v];
+            outp[o] += acc[tt][v] * a.out_scale;
           else
-            outp[o] = acc[tt][v];
+            outp[o] = acc[tt][v] * a.out_scale;
         }
       }
     }
     // every row of accb holds the column sums; row 0 lives in accb[0] of lanes 0..31
     if (want_bias && lane < 32) {
       float* bp = a.bias + (direct ? 0 : (int64_t)blockIdx.y * a.Co) + co;
-      *bp = (direct && a.accumulate) ? *bp + accb[0] : accb[0];
+      *bp = (direct && a.accumulate) ? *bp + accb[0] * a.out_scale : accb[0] * a.out_scale;
     }
   }
 }
@@ -672,6 +950,8 @@ struct WStemArgs {
   int tiles_x, tiles_y, ntiles, tiles_per_wg;
   int relu_in, out_f32, self_gate, want_bias;
   float slope_out;
+  int pool;    // forward: 2x2 average pooling of the output in the epilogue (Co = 64 / 128)
+  int dy_up;   // weight gradient: dy is the pooled-resolution gradient (see HWgradArgs)
   FastDiv dTx, dTy;
 };
 
@@ -768,6 +1048,78 @@ __global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
     }
     // epilogue: per-wave staging (see hconv_kernel), 32 pixels per pass
     unsigned char* Sw = stg + wave * (32 * SP);
+    if constexpr (64 % G8 == 0) {
+      if (a.pool) {
+        // pooled form (see hconv_kernel): x pairs in lanes G8 apart, y pairs in the other pass (8x32
+        // tiles) or NK/2 sweeps on (16x16 tiles); lanes with an even row finish the pixels
+        constexpr int RPI = 64 / G8, NK = 32 / RPI;
+        const int rl = lane / G8;
+        float keep[NK][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+              *reinterpret_cast<float4*>(Sw + frow * SP + (ct * 32 + qq * 8 + 4 * half) * 4) =
+                  make_float4(acc[i][ct][qq * 4 + 0], acc[i][ct][qq * 4 + 1],
+                              acc[i][ct][qq * 4 + 2], acc[i][ct][qq * 4 + 3]);
+          __builtin_amdgcn_wave_barrier();
+          float vv[NK][8];
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const int row = rl + RPI * k;
+            const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
+            const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
+            const float t8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float tq = t8[e] + bv[e];
+              vv[k][e] = tq + __shfl_xor(tq, G8, 64);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          constexpr int NST = TWL == 4 ? NK / 2 : NK;
+          if (TWL == 4) {
+#pragma unroll
+            for (int k = 0; k < NK / 2; ++k)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vv[k][e] += vv[k + NK / 2][e];
+          } else if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) keep[k][e] = vv[k][e];
+            continue;
+          } else {
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vv[k][e] += keep[k][e];
+          }
+          if (rl & 1) continue;
+#pragma unroll
+          for (int k = 0; k < NST; ++k) {
+            const int row = rl + RPI * k;
+            const int y2 = TWL == 4 ? wave * 2 + i : wave;
+            const int x2 = (TWL == 4 ? (row & 15) : row) >> 1;
+            const int64_t o = (((int64_t)n * (a.H >> 1) + ((ty * TH) >> 1) + y2) * (a.W >> 1) +
+                               ((tx * TW) >> 1) + x2) * a.Co + g8 * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.25f * vv[k][e];
+            if (a.out_f32) {
+              float* op = reinterpret_cast<float*>(a.out) + o;
+              *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+            }
+          }
+        }
+        continue;   // next tile
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -836,14 +1188,19 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
     const int p = (wave * 8 + j) * 8 + (lane >> 3);
     const int y = p >> TWL, x = p & (TW - 1);
     const int c = (lane & 7) ^ (((p >> 1) & 1) << 2);
-    yrel[j] = (c0 + c * 8) < a.Co ? (uint32_t)(((y * a.W + x) * a.Co + c0 + c * 8) * 2) : HC_OOB;
+    const int us = a.dy_up;
+    yrel[j] = (c0 + c * 8) < a.Co
+                  ? (uint32_t)((((y >> us) * (a.W >> us) + (x >> us)) * a.Co + c0 + c * 8) * 2)
+                  : HC_OOB;
   }
   auto stage = [&](int buf, int t) {
     const int q = (int)fdiv((uint32_t)t, a.dTx);
     const int tx = t - q * a.tiles_x;
     const int n = (int)fdiv((uint32_t)q, a.dTy);
     const int ty = q - n * a.tiles_y;
-    const bf16_t* yo = a.dy + (((int64_t)n * a.H + ty * TH) * a.W + tx * TW) * a.Co;
+    const int us = a.dy_up;
+    const bf16_t* yo = a.dy + (((int64_t)n * (a.H >> us) + ((ty * TH) >> us)) * (a.W >> us) +
+                               ((tx * TW) >> us)) * a.Co;
     const __amdgpu_buffer_rsrc_t ry =
         __builtin_amdgcn_make_buffer_rsrc((void*)yo, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -928,7 +1285,7 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[(w * 64 + lane) * 33 + j * 16 + v];
-        if (k < K && co < a.Co) outp[(int64_t)k * a.Co + co] = s;
+        if (k < K && co < a.Co) outp[(int64_t)k * a.Co + co] = a.dy_up ? 0.25f * s : s;
       }
     }
   } else if (wave == 1 && a.want_bias) {
@@ -936,7 +1293,7 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s += redb[(w * 2 + j) * 32 + (lane & 31)];
-    if (co < a.Co) outp[K_Co + co] = s;
+    if (co < a.Co) outp[K_Co + co] = a.dy_up ? 0.25f * s : s;
   }
 }
 
@@ -1007,6 +1364,9 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.bn_eps = fu ? fu->bn_eps : 0.f;
   a.bn_per_sample = fu ? fu->bn_per_sample : 0;
   a.stats = fu ? fu->stats_out : nullptr;
+  a.pool = fu ? fu->pool_out : 0;
+  a.in_up = fu ? fu->in_up : 0;
+  a.out_scale = (fu && fu->out_scale != 0.f) ? fu->out_scale : 1.f;
   a.in = (const bf16_t*)in;
   a.bt = (const bf16_t*)bt;
   a.out = out;
@@ -1019,7 +1379,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.U = g->U; a.pt = g->pt; a.pl = g->pl;
   a.Kp = (g->kh * g->kw * g->Ci + 7) & ~7;
   a.cblocks = cdiv(g->Ci, 64);
-  a.in_bytes = (uint32_t)((int64_t)g->N * g->Hin * g->Win * g->Ci * 2);
+  a.in_bytes = (uint32_t)(((int64_t)g->N * g->Hin * g->Win * g->Ci * 2) >> (a.in_up ? 2 : 0));
   a.bt_bytes = (uint32_t)((int64_t)g->Co * a.Kp * 2);
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   const int twl = hc_tile_log(Hp, Wp);
@@ -1039,10 +1399,16 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   const bool relu = gate_in != nullptr && a.bn_mean == nullptr;   // the BN prologue includes the ReLU
   dim3 grid(g->N * a.tiles_y * a.tiles_x * a.ntiles, g->U * g->U);
   CgProfScope prof(bn == 128 ? CG_PROF_HCONV_128 : CG_PROF_HCONV_64, g, st);
-#define HC_LAUNCH(BN_, TWL_)                                                        \
-  do {                                                                              \
-    if (relu) hconv_kernel<BN_, true, TWL_><<<grid, 512, 0, st>>>(a);               \
-    else hconv_kernel<BN_, false, TWL_><<<grid, 512, 0, st>>>(a);                   \
+#define HC_LAUNCH2(BN_, TWL_, FUSE_)                                                     \
+  do {                                                                                   \
+    if (relu) hconv_kernel<BN_, true, TWL_, FUSE_><<<grid, 512, 0, st>>>(a);             \
+    else hconv_kernel<BN_, false, TWL_, FUSE_><<<grid, 512, 0, st>>>(a);                 \
+  } while (0)
+#define HC_LAUNCH(BN_, TWL_)                                                             \
+  do {                                                                                   \
+    if (a.pool) HC_LAUNCH2(BN_, TWL_, 2);                                                \
+    else if (a.bn_mean || a.stats) HC_LAUNCH2(BN_, TWL_, 1);                             \
+    else HC_LAUNCH2(BN_, TWL_, 0);                                                       \
   } while (0)
   if (bn == 128) {
     if (twl == 5) HC_LAUNCH(128, 5);
@@ -1051,6 +1417,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
     if (twl == 5) HC_LAUNCH(64, 5);
     else HC_LAUNCH(64, 4);
   }
+#undef HC_LAUNCH2
 #undef HC_LAUNCH
 }
 
@@ -1103,8 +1470,16 @@ size_t cg_hwgrad_workspace_bytes(const cgConvGeom* g) {
 
 void cg_hwgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
                       float* dw, int accumulate, float* dbias, void* ws, hipStream_t st) {
+  cg_hwgrad_launch_pooled(g, in, gate_in, dy, 0, dw, accumulate, dbias, ws, st);
+}
+
+void cg_hwgrad_launch_pooled(const cgConvGeom* g, const void* in, const void* gate_in,
+                             const void* dy, int dy_pooled, float* dw, int accumulate,
+                             float* dbias, void* ws, hipStream_t st) {
   const HWgradPlan p = hwgrad_plan(g);
   HWgradArgs h;
+  h.dy_up = dy_pooled ? 1 : 0;
+  h.out_scale = dy_pooled ? 0.25f : 1.f;
   h.in = (const bf16_t*)in;
   h.dy = (const bf16_t*)dy;
   h.N = g->N; h.Hin = g->Hin; h.Win = g->Win; h.Ci = g->Ci; h.Co = g->Co;
@@ -1177,8 +1552,16 @@ bool cg_wstem_conv_supported(const cgConvGeom* g, const void* in, const void* ou
 void cg_wstem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
                           int out_is_f32, const float* bias, const void* gate_in,
                           const void* gate_out, float slope_out, hipStream_t st) {
+  cg_wstem_conv_launch_pool(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, 0, st);
+}
+
+void cg_wstem_conv_launch_pool(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                               int out_is_f32, const float* bias, const void* gate_in,
+                               const void* gate_out, float slope_out, int pool, hipStream_t st) {
   WStemArgs a;
   wstem_fill(g, &a);
+  a.pool = pool;
+  a.dy_up = 0;
   a.in = (const bf16_t*)in; a.bt = (const bf16_t*)bt; a.dy = nullptr; a.out = out; a.bias = bias;
   a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.self_gate = gate_out != nullptr;
   a.want_bias = 0; a.slope_out = slope_out;
@@ -1217,8 +1600,16 @@ size_t cg_wstem_wgrad_workspace_bytes(const cgConvGeom* g) {
 void cg_wstem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
                            const void* dy, int want_bias, void* ws, int* splits_out,
                            hipStream_t st) {
+  cg_wstem_wgrad_launch_pooled(g, in, gate_in, dy, 0, want_bias, ws, splits_out, st);
+}
+
+void cg_wstem_wgrad_launch_pooled(const cgConvGeom* g, const void* in, const void* gate_in,
+                                  const void* dy, int dy_pooled, int want_bias, void* ws,
+                                  int* splits_out, hipStream_t st) {
   WStemArgs a;
   wstem_fill(g, &a);
+  a.pool = 0;
+  a.dy_up = dy_pooled ? 1 : 0;
   int tps;
   const int splits = wstem_wgrad_splits(g, &tps);
   a.in = (const bf16_t*)in; a.bt = nullptr; a.dy = (const bf16_t*)dy; a.out = ws; a.bias = nullptr;
@@ -1229,4 +1620,51 @@ void cg_wstem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate
   if (hc_tile_log(g->Ho, g->Wo) == 5) wstem_wgrad_kernel<5><<<grid, 256, 0, st>>>(a);
   else wstem_wgrad_kernel<4><<<grid, 256, 0, st>>>(a);
   *splits_out = splits;
+}
+
+// ---- 64 -> 64 channel 3x3: register-resident weights ----
+bool cg_hconv_rw_supported(const cgConvGeom* g, const void* in, const void* gate_in,
+                           float slope_in) {
+  static const int enabled = hc_env("CGAMD_HCONV_RW", 1);
+  static const int min_tiles = hc_env("CGAMD_HCONV_RW_MIN", 512);
+  if (!enabled) return false;
+  if (g->S != 1 || g->U != 1 || g->kh != 3 || g->kw != 3 || g->Ci != 64 || g->Co != 64) return false;
+  if (g->Ho != g->Hin || g->Wo != g->Win || g->pt != 1 || g->pl != 1) return false;
+  if ((g->Wo % 32) != 0 || (g->Ho % 4) != 0) return false;
+  if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
+  if ((int64_t)6 * g->Win * 64 * 2 >= (1ll << 31)) return false;
+  return (int64_t)g->N * (g->Ho / 4) * (g->Wo / 32) >= min_tiles;
+}
+
+void cg_hconv_rw_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                        int out_is_f32, const float* bias, const void* gate_in,
+                        const void* gate_out, float slope_out, const void* residual,
+                        hipStream_t st) {
+  HConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = (const bf16_t*)in;
+  a.bt = (const bf16_t*)bt;
+  a.out = out;
+  a.bias = bias;
+  a.self_gate = (gate_out != nullptr && gate_out == out);
+  a.gate_out = a.self_gate ? nullptr : (const bf16_t*)gate_out;
+  a.residual = (const bf16_t*)residual;
+  a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
+  a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co; a.kh = 3; a.kw = 3;
+  a.U = 1; a.pt = g->pt; a.pl = g->pl;
+  a.Kp = 9 * 64;
+  a.cblocks = 1;
+  a.tiles_x = g->Wo / 32;
+  a.tiles_y = g->Ho / 4;
+  a.ntiles = 1;
+  a.out_f32 = out_is_f32;
+  a.slope_out = slope_out;
+  a.dNt = make_fastdiv(1);
+  a.dTx = make_fastdiv(a.tiles_x);
+  a.dTy = make_fastdiv(a.tiles_y);
+  const int ntiles = g->N * a.tiles_y * a.tiles_x;
+  const int grid = ntiles < 512 ? ntiles : 512;
+  CgProfScope prof(CG_PROF_HCONV_64, g, st);
+  if (gate_in) hconv_rw_kernel<true><<<grid, 256, 0, st>>>(a);
+  else hconv_rw_kernel<false><<<grid, 256, 0, st>>>(a);
 }

@@ -622,6 +622,13 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
     CG_CHECK_LAUNCH("cg_gconv(stem)");
     return CG_OK;
   }
+  if (cg_hconv_rw_supported(g, in, gate_in, slope_in)) {
+    hipStream_t fst = (hipStream_t)stream;
+    cg_hconv_rw_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
+                       fst);
+    CG_CHECK_LAUNCH("cg_gconv(halo-rw)");
+    return CG_OK;
+  }
   if (cg_hconv_supported(g, in, gate_in, slope_in)) {
     hipStream_t fst = (hipStream_t)stream;
     cg_hconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fst);
@@ -676,20 +683,71 @@ extern "C" int cg_gconv_fused_rows(const cgConvGeom* g) {
   return cg_hconv_stats_rows(g);
 }
 
+extern "C" int cg_gconv_pool_supported(const cgConvGeom* g) {
+  if (!g || check_geom(g, "cg_gconv_pool_supported")) return 0;
+  if ((g->Ho & 1) || (g->Wo & 1) || g->U != 1) return 0;
+  if (g->Ci == 3)
+    return cg_wstem_conv_supported(g, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr) &&
+                   (g->Co == 64 || g->Co == 128) &&
+                   cg_wstem_wgrad_supported(g, nullptr, nullptr, 0.f, nullptr)
+               ? 1 : 0;
+  return cg_hconv_geom_ok(g) && cg_hwgrad_workspace_bytes(g) > 0 ? 1 : 0;
+}
+
 extern "C" int cg_gconv_fused(const cgConvGeom* g, const void* in, const void* bt, void* out,
-                              int out_is_f32, const float* bias, const void* gate_out,
-                              float slope_out, const void* residual, const cgConvFusion* fu,
-                              cgStream stream) {
+                              int out_is_f32, const float* bias, const void* gate_in,
+                              float slope_in, const void* gate_out, float slope_out,
+                              const void* residual, const cgConvFusion* fu, cgStream stream) {
   int rc = check_geom(g, "cg_gconv_fused");
   if (rc) return rc;
   if (!in || !bt || !out || !fu) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_fused: null argument");
-  if (!cg_hconv_geom_ok(g)) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: geometry not covered");
+  if (gate_in && !(gate_in == in && slope_in == 0.f))
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: the input gate must be ReLU of the input itself");
   if ((fu->bn_mean == nullptr) != (fu->bn_var == nullptr))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_fused: bn_mean and bn_var go together");
+  if ((fu->pool_out || fu->in_up) && (g->U != 1 || (g->Ho & 1) || (g->Wo & 1)))
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: pooling needs an even unit-stride geometry");
+  if (fu->pool_out && gate_out)
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: no output gate on a pooled output");
   hipStream_t fst = (hipStream_t)stream;
-  cg_hconv_launch_fused(g, in, bt, out, out_is_f32, bias, nullptr, gate_out, slope_out, residual,
+  if (g->Ci == 3) {
+    // RGB-input convolution: only the pooled epilogue exists
+    if (!fu->pool_out || fu->bn_mean || fu->stats_out || fu->in_up || residual ||
+        !cg_gconv_pool_supported(g))
+      CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: RGB-input form only covers pool_out");
+    cg_wstem_conv_launch_pool(g, in, bt, out, out_is_f32, bias, gate_in, nullptr, 0.f, 1, fst);
+    CG_CHECK_LAUNCH("cg_gconv_fused(wstem)");
+    return CG_OK;
+  }
+  if (!cg_hconv_geom_ok(g)) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: geometry not covered");
+  cg_hconv_launch_fused(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
                         fu, fst);
   CG_CHECK_LAUNCH("cg_gconv_fused");
+  return CG_OK;
+}
+
+extern "C" int cg_gwgrad_pooled(const cgConvGeom* g, const void* in, const void* gate_in,
+                                float slope_in, const void* dy_pooled, float* dw, int accumulate,
+                                float* dbias, void* ws, size_t ws_bytes, cgStream stream) {
+  int rc = check_geom(g, "cg_gwgrad_pooled");
+  if (rc) return rc;
+  if (!in || !dy_pooled || !dw) CG_FAIL(CG_ERR_BAD_ARG, "cg_gwgrad_pooled: null tensor");
+  if (!cg_gconv_pool_supported(g))
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gwgrad_pooled: geometry not covered");
+  if (gate_in && !(gate_in == in && slope_in == 0.f))
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gwgrad_pooled: the input gate must be ReLU of the input itself");
+  if (!ws || ws_bytes < cg_gwgrad_workspace_bytes(g))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_gwgrad_pooled: workspace too small");
+  hipStream_t fst = (hipStream_t)stream;
+  if (g->Ci == 3) {
+    CgProfScope prof(CG_PROF_STEM_WGRAD, g, fst);
+    int splits = 0;
+    cg_wstem_wgrad_launch_pooled(g, in, gate_in, dy_pooled, 1, dbias != nullptr, ws, &splits, fst);
+    cg_stem_partial_reduce(g, ws, splits, dw, dbias, accumulate, fst);
+  } else {
+    cg_hwgrad_launch_pooled(g, in, gate_in, dy_pooled, 1, dw, accumulate, dbias, ws, fst);
+  }
+  CG_CHECK_LAUNCH("cg_gwgrad_pooled");
   return CG_OK;
 }
 

@@ -49,7 +49,8 @@ class PrepItem(ctypes.Structure):
 class ConvFusion(ctypes.Structure):
     """Mirror of cgConvFusion."""
     _fields_ = [("bn_mean", vp), ("bn_var", vp), ("bn_gamma", vp), ("bn_beta", vp),
-                ("bn_eps", c_f32), ("bn_per_sample", ctypes.c_int32), ("stats_out", vp)]
+                ("bn_eps", c_f32), ("bn_per_sample", ctypes.c_int32), ("stats_out", vp),
+                ("pool_out", ctypes.c_int32), ("in_up", ctypes.c_int32), ("out_scale", c_f32)]
 
 
 ADAM_CHUNK = 16384
@@ -67,7 +68,9 @@ SIGNATURES = {
     "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
     "cg_gconv_fused_rows": (c_int, [GP]),
-    "cg_gconv_fused": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, vp, vp]),
+    "cg_gconv_fused": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp, vp]),
+    "cg_gconv_pool_supported": (c_int, [GP]),
+    "cg_gwgrad_pooled": (c_int, [GP, vp, vp, c_f32, vp, vp, c_int, vp, vp, c_sz, vp]),
     "cg_bn_finalize": (c_int, [vp, c_int, c_int, c_i64, vp, vp, vp, vp, c_f32, vp]),
     "cg_gwgrad_workspace_bytes": (c_sz, [GP]),
     "cg_gwgrad": (c_int, [GP, vp, vp, c_f32, vp, vp, c_f32, vp, c_int, vp, vp, c_sz, vp]),

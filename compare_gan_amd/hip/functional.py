@@ -223,6 +223,77 @@ def gconv(x, w, bias=None, residual=None, gate_in=None, gate_out=None, spec=None
   return GConvFn.apply(x, w, bias, residual, gate_in, gate_out, spec, dx_f32, bt_pair)
 
 
+class ConvPoolFn(torch.autograd.Function):
+  """y = avgpool2x2(conv_spec(relu?(x), w) + bias) + residual_p: a discriminator block's
+  convolution with the down-sampling that follows it (resnet_ops.py:131-133) in ONE kernel -- the
+  full-resolution output never goes through HBM.  residual_p lives at the pooled resolution.
+
+  Backward: the pooling's gradient is the nearest-neighbour up-sampling of dy times 1/4; the
+  data-gradient and weight-gradient kernels read the pooled-resolution dy directly (in_up /
+  gwgrad_pooled).  Under create_graph (WGAN-GP) the backward is composed from the differentiable
+  Functions instead."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, residual_p, gate_in, spec, dx_f32, bt_pair=None):
+    x = x.contiguous()
+    bt = bt_pair[0] if bt_pair is not None else None
+    if bt is None:
+      bt, _ = K.weight_prep(w, want_fwd=True, want_bwd=False)
+    gi = gate_in if spec.slope_in is not None else None
+    y, _ = K.gconv_fused(spec.geom, x, bt, bias=bias, residual=residual_p, gate_in=gi, pool=True,
+                         out_f32=spec.out_f32)
+    ctx.spec, ctx.dx_f32, ctx.bt_pair = spec, dx_f32, bt_pair
+    ctx.has_bias, ctx.has_res = bias is not None, residual_p is not None
+    ctx.save_for_backward(x, w, gate_in)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w, gate_in = ctx.saved_tensors
+    spec = ctx.spec
+    dy16 = _bf16(dy)
+    need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+    if _SKIP_PARAM_GRADS[0]:
+      need_w = need_b = False
+    dx = dw = db = None
+    dr = dy16 if (need_r and ctx.has_res) else None
+    want_b = bool(need_b and ctx.has_bias)
+    if torch.is_grad_enabled():
+      # differentiable composition (second-order terms of a gradient penalty)
+      dyf = AvgPool2BwdFn.apply(dy16)
+      if need_x:
+        dx = GConvFn.apply(dyf, w, None, None, None, gate_in, spec.adjoint(out_f32=ctx.dx_f32),
+                           False, ctx.bt_pair)
+      if need_w:
+        dw = GWgradFn.apply(x, dyf, gate_in, None, spec)
+      if want_b:
+        db = K.colsum(dyf.reshape(-1, dyf.shape[-1]))
+      return dx, dw, db, dr, None, None, None, None
+    g = spec.geom
+    gi = gate_in if spec.slope_in is not None else None
+    if need_x:
+      ag = K.geom_adjoint(g)
+      bt_b = ctx.bt_pair[1] if ctx.bt_pair is not None else None
+      if bt_b is None:
+        _, bt_b = K.weight_prep(w, want_fwd=False, want_bwd=True)
+      if K.gconv_fused_rows(ag) > 0:
+        dx, _ = K.gconv_fused(ag, dy16, bt_b, gate_out=gi, slope_out=spec.slope_in or 0.0,
+                              in_up=True, out_scale=0.25, out_f32=ctx.dx_f32)
+      else:
+        dx = K.gconv(ag, K.avgpool2_bwd(dy16), bt_b, gate_out=gi, slope_out=spec.slope_in or 0.0,
+                     out_f32=ctx.dx_f32)
+    if need_w or want_b:
+      dw, db = K.gwgrad_pooled(g, x, dy16, gate_in=gi, want_dbias=want_b)
+      if not need_w:
+        dw = None
+    return dx, dw, db, dr, None, None, None, None
+
+
+def conv_pool(x, w, bias=None, residual_p=None, gate_in=None, spec=None, dx_f32=False,
+              bt_pair=None):
+  return ConvPoolFn.apply(x, w, bias, residual_p, gate_in, spec, dx_f32, bt_pair)
+
+
 # ------------------------------------------------------------------------------------------------
 # spectral norm
 # ------------------------------------------------------------------------------------------------

@@ -129,19 +129,33 @@ def gconv_fused_rows(geom):
     return int(lib().cg_gconv_fused_rows(ctypes.byref(geom)))
 
 
-def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, want_stats=False):
-    """cg_gconv_fused: convolution with the batch-norm + ReLU prologue `bn` = (mean, var, gamma,
-    beta, eps, per_sample) applied to its input in LDS and / or the per-channel partial sums of
-    its output (for the next batch norm).  Returns (out, partials or None)."""
+def gconv_pool_supported(geom):
+    """True when the pooled-output convolution (gconv_fused(pool=True)) and its pooled-gradient
+    weight gradient (gwgrad_pooled) cover `geom`."""
+    return bool(lib().cg_gconv_pool_supported(ctypes.byref(geom)))
+
+
+def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, want_stats=False,
+                gate_in=None, gate_out=None, slope_out=0.0, pool=False, in_up=False,
+                out_scale=1.0):
+    """cg_gconv_fused: the halo-staged convolution with its fusions --
+      bn = (mean, var, gamma, beta, eps, per_sample): batch norm + ReLU applied to the input in LDS;
+      want_stats: per-channel partial sums of the output (for the next batch norm);
+      pool: 2x2 average pooling of (conv + bias) in the epilogue, `residual` at the pooled size;
+      in_up: x is [N, Hin/2, Win/2, Ci], read as its nearest-neighbour up-sampling; out_scale
+             multiplies the convolution sum (pool gradient: in_up with out_scale = 0.25);
+      gate_in: ReLU of the input itself (must be x); gate_out / slope_out as gconv.
+    Returns (out, partials or None)."""
     from compare_gan_amd.hip._lib import ConvFusion
     _req(x, BF16, "x")
     _req(bt, BF16, "bt")
     _req(bias, F32, "bias", True)
     _req(residual, BF16, "residual", True)
-    rows = gconv_fused_rows(geom)
-    if rows <= 0:
-        raise ValueError("geometry %s is not covered by the fused kernel" % (geom.key(),))
-    if x.numel() != geom.N * geom.Hin * geom.Win * geom.Ci:
+    _req(gate_out, BF16, "gate_out", True)
+    if gate_in is not None and gate_in.data_ptr() != x.data_ptr():
+        raise ValueError("gconv_fused: gate_in must be the input itself")
+    us = 2 if in_up else 1
+    if x.numel() * us * us != geom.N * geom.Hin * geom.Win * geom.Ci:
         raise ValueError("x has %d elements, geometry expects %s" % (x.numel(), geom.key()))
     fu = ConvFusion()
     keep = []
@@ -161,15 +175,40 @@ def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, w
         keep = [mean, var, gamma, beta]
     stats = None
     if want_stats:
+        rows = gconv_fused_rows(geom)
+        if rows <= 0:
+            raise ValueError("geometry %s is not covered by the fused kernel" % (geom.key(),))
         stats = torch.empty((rows, 2 * geom.Co), dtype=F32, device=x.device)
         fu.stats_out = _p(stats)
-    out = torch.empty((geom.N, geom.Ho, geom.Wo, geom.Co), dtype=F32 if out_f32 else BF16,
-                      device=x.device)
+    fu.pool_out, fu.in_up, fu.out_scale = int(bool(pool)), int(bool(in_up)), float(out_scale)
+    ps = 2 if pool else 1
+    oshape = (geom.N, geom.Ho // ps, geom.Wo // ps, geom.Co)
+    if residual is not None and residual.numel() != oshape[0] * oshape[1] * oshape[2] * oshape[3]:
+        raise ValueError("residual has the wrong number of elements")
+    out = torch.empty(oshape, dtype=F32 if out_f32 else BF16, device=x.device)
     check(lib().cg_gconv_fused(ctypes.byref(geom), _p(x), _p(bt), _p(out), int(out_f32), _p(bias),
-                               None, 0.0, _p(residual), ctypes.byref(fu), _stream()),
-          "cg_gconv_fused")
+                               _p(gate_in), 0.0, _p(gate_out), float(slope_out), _p(residual),
+                               ctypes.byref(fu), _stream()), "cg_gconv_fused")
     del keep
     return out, stats
+
+
+def gwgrad_pooled(geom, x, dy_pooled, gate_in=None, want_dbias=False):
+    """dw (+ dbias) of a convolution whose output was 2x2 average-pooled; dy_pooled is the
+    gradient w.r.t. the pooled output [N, Ho/2, Wo/2, Co]."""
+    _req(x, BF16, "x")
+    _req(dy_pooled, BF16, "dy_pooled")
+    if gate_in is not None and gate_in.data_ptr() != x.data_ptr():
+        raise ValueError("gwgrad_pooled: gate_in must be the input itself")
+    if dy_pooled.numel() * 4 != geom.N * geom.Ho * geom.Wo * geom.Co:
+        raise ValueError("dy_pooled has the wrong number of elements for %s" % (geom.key(),))
+    dw = torch.empty((geom.kh, geom.kw, geom.Ci, geom.Co), dtype=F32, device=x.device)
+    dbias = torch.empty((geom.Co,), dtype=F32, device=x.device) if want_dbias else None
+    ws = _ws(lib().cg_gwgrad_workspace_bytes(ctypes.byref(geom)), x)
+    check(lib().cg_gwgrad_pooled(ctypes.byref(geom), _p(x), _p(gate_in), 0.0, _p(dy_pooled),
+                                 _p(dw), 0, _p(dbias), _p(ws), ws.numel(), _stream()),
+          "cg_gwgrad_pooled")
+    return dw, dbias
 
 
 def bn_finalize(partials, count, moving_mean=None, moving_var=None, decay=0.0):

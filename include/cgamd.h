@@ -122,11 +122,30 @@ typedef struct {
   float bn_eps;
   int32_t bn_per_sample;
   float* stats_out;
+  /* 2x2 average pooling fused around the convolution (resnet_ops.py:131-133: conv -> tf.nn.pool AVG):
+   *   pool_out != 0: out is [N, Ho/2, Wo/2, Co] = avgpool2(conv + bias) + residual (residual at the
+   *                  pooled resolution; no output gate);
+   *   in_up != 0   : `in` is [N, Hin/2, Win/2, Ci] and stands for its nearest-neighbour 2x
+   *                  up-sampling -- with out_scale = 1/4 this is the gradient of the pooling feeding
+   *                  the data-gradient convolution.  out_scale multiplies the convolution sum
+   *                  (0 = 1). */
+  int32_t pool_out;
+  int32_t in_up;
+  float out_scale;
 } cgConvFusion;
 int cg_gconv_fused_rows(const cgConvGeom* geom);
 int cg_gconv_fused(const cgConvGeom* geom, const void* in, const void* bt, void* out,
-                   int out_is_f32, const float* bias, const void* gate_out, float slope_out,
-                   const void* residual, const cgConvFusion* fusion, cgStream stream);
+                   int out_is_f32, const float* bias, const void* gate_in, float slope_in,
+                   const void* gate_out, float slope_out, const void* residual,
+                   const cgConvFusion* fusion, cgStream stream);
+/* 1 when cg_gconv_fused (pool_out) and cg_gwgrad_pooled cover `geom` (also RGB-input 3x3
+ * convolutions), else 0. */
+int cg_gconv_pool_supported(const cgConvGeom* geom);
+/* cg_gwgrad for a convolution whose output was 2x2 average-pooled: dy_pooled is
+ * [N, Ho/2, Wo/2, Co] (the gradient w.r.t. the pooled output); workspace as cg_gwgrad. */
+int cg_gwgrad_pooled(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
+                     const void* dy_pooled, float* dw, int accumulate, float* dbias, void* ws,
+                     size_t ws_bytes, cgStream stream);
 /* mean / var (and the moving averages, as cg_bn_stats) from `rows` rows of partial sums
  * [rows][2*C] over `count` values per channel. */
 int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean, float* var,

@@ -50,6 +50,10 @@ SHAPES = {
         (64, 64, 64, 192, 192, 3, 1, 1, 1), (64, 8, 8, 1536, 1536, 3, 1, 1, 1),
         (64, 4, 4, 1536, 1536, 3, 1, 1, 1), (32, 64, 64, 192, 96, 3, 1, 2, 0),
     ],
+    "c64": [
+        (128, 128, 128, 64, 64, 3, 1, 1, 1), (64, 128, 128, 64, 64, 3, 1, 1, 0),
+        (128, 64, 64, 64, 64, 3, 1, 1, 1),
+    ],
     "resnet128": [
         (128, 128, 128, 64, 64, 3, 1, 1, 1), (128, 64, 64, 64, 128, 3, 1, 1, 1),
         (128, 64, 64, 128, 128, 3, 1, 1, 1), (128, 32, 32, 128, 256, 3, 1, 1, 1),

@@ -89,6 +89,8 @@ CONV_CASES = [
     ("hc_up32_c64", 1, 32, 32, 64, 64, 3, 1, 2),
     ("hc_1x1", 2, 32, 32, 128, 136, 1, 1, 1),
     ("hc_c96", 2, 32, 32, 96, 160, 3, 1, 1),
+    # 64 -> 64 channels with register-resident weights (hconv_rw_kernel; "hconv_all" variant)
+    ("hc_rw", 3, 32, 64, 64, 64, 3, 1, 1),
     ("hc_c160_up", 1, 16, 16, 160, 96, 3, 1, 2),
     # window-staged RGB-input kernels (cg_conv_halo.hip: wstem_*): 8x32 and 16x16 tiles, 64 / 96 /
     # 128 output channels
@@ -230,6 +232,56 @@ def test_gconv_fused_batch_norm(K, dev, case):
     m3, _ = K.bn_finalize(part2, cnt)
     assert_close_f32(m3, out2.detach().float().cpu().double().mean(dim=(0, 1, 2)),
                      name + " stats-only mean", rtol=1e-4, abs_rms=1e-4)
+
+
+@pytest.mark.parametrize("case", [
+    # name, N, H, W, Ci, Co, relu_in, residual
+    ("pool_c64_128", 2, 32, 32, 64, 128, True, True),
+    ("pool_c128_64_16", 3, 16, 16, 128, 64, True, False),
+    ("pool_c64_64_16", 2, 16, 16, 64, 64, False, True),
+    ("pool_c96", 2, 32, 32, 96, 192, True, True),
+    ("pool_rgb_64", 2, 32, 32, 3, 64, True, False),
+    ("pool_rgb_128_16", 3, 16, 16, 3, 128, False, False),
+], ids=lambda c: c[0])
+def test_conv_pool_fused(K, dev, case):
+    """ConvPoolFn: avgpool2x2(conv3x3(relu?(x)) + b) + r in one kernel (resnet_ops.py:131-133,
+    165-181) and its gradients from the pooled-resolution dy (data gradient through the
+    nearest-neighbour-upsampled read, weight / bias gradients through cg_gwgrad_pooled), against
+    torch autograd on the fp64 oracle."""
+    from compare_gan_amd.hip import functional as Fn
+    name, N, H, W, Ci, Co, relu_in, with_res = case
+    g = _gen(sum(ord(c) for c in name))
+    x64, xb = rand_bf16((N, H, W, Ci), g)
+    w64, wb = rand_bf16((3, 3, Ci, Co), g, 1.0 / math.sqrt(9 * Ci))
+    bias = torch.randn(Co, generator=g, dtype=torch.float32)
+    r64, rb = rand_bf16((N, H // 2, W // 2, Co), g)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+    assert K.gconv_pool_supported(geom)
+    xr = x64.clone().requires_grad_(True)
+    wr = w64.clone().requires_grad_(True)
+    br = bias.double().clone().requires_grad_(True)
+    conv = _ref_conv(xr, wr, 1, 1, gate_slope=0.0 if relu_in else None) + br
+    ref = F.avg_pool2d(conv.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + r64
+    dy64, dyb = rand_bf16(tuple(ref.shape), g)
+    (ref * dy64).sum().backward()
+
+    xd = xb.to(dev).requires_grad_(True)
+    wd = wb.to(torch.float32).to(dev).requires_grad_(True)
+    bd = bias.to(dev).requires_grad_(True)
+    rd = rb.to(dev).requires_grad_(True) if with_res else None
+    spec = Fn.ConvSpec(geom, slope_in=0.0 if relu_in else None)
+    y = Fn.conv_pool(xd, wd, bd, rd, xd.detach() if relu_in else None, spec, Ci <= 4)
+    assert_close_bf16(y, ref.detach(), name + " fwd")
+    grads = torch.autograd.grad(y, [xd, wd, bd] + ([rd] if with_res else []),
+                                grad_outputs=dyb.to(dev))
+    if Ci > 4:
+        assert_close_bf16(grads[0], xr.grad, name + " dx", ulps=2.0, abs_rms=2.0 ** -7)
+    assert_close_f32(grads[1], wr.grad, name + " dw", rtol=2e-4, abs_rms=2e-4)
+    assert_close_f32(grads[2], br.grad, name + " db", rtol=2e-4, abs_rms=2e-4)
+    if with_res:
+        assert torch.equal(grads[3].cpu().double(), dy64)
 
 
 @pytest.mark.parametrize("size", [12, 32])
@@ -636,8 +688,8 @@ CONV_VARIANT_ENVS = [
     ("halo_forward", {"CGAMD_HALO": "1"}),             # experimental halo-staged forward kernel
     ("one_tap_wgrad", {"CGAMD_NO_HALO_WGRAD": "1"}),   # one-tap-per-workgroup weight gradient
     # halo-staged forward / weight-gradient kernels wherever they apply
-    ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1"}),
-    ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0", "CGAMD_WSTEM": "0"}),
+    ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1", "CGAMD_HCONV_RW_MIN": "1"}),
+    ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0", "CGAMD_WSTEM": "0", "CGAMD_HCONV_RW": "0"}),
     # round 2: fast_conv_w8_kernel (8 waves, 256x128 tiles) was written after the GPU budget of
     # round 1 was spent and has never run; verify it with this entry, then A/B it:
     # ("w8_tiles", {"CGAMD_CONV_W8": "1", "CGAMD_CONV_T128_MIN": "1"}),
