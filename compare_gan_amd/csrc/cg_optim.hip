@@ -287,6 +287,56 @@ inline int grid_cap(int64_t work) {
 
 }  // namespace
 
+
+// ---- sums for the DRAGAN / L2 penalties (penalty_lib.py:33-56,85-102): two-stage, deterministic ----
+constexpr int MOM_BLOCKS = 512;
+__global__ __launch_bounds__(256) void moments_part_kernel(const float* __restrict__ x, int64_t n,
+                                                           float* __restrict__ part) {
+  __shared__ float sm[4];
+  float s = 0.f, q = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    s += v;
+    q += v * v;
+  }
+  s = block_sum_256(s, sm);
+  q = block_sum_256(q, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = s;
+    part[blockIdx.x * 2 + 1] = q;
+  }
+}
+__global__ __launch_bounds__(256) void moments_final_kernel(const float* __restrict__ part, int nb,
+                                                            float* __restrict__ out) {
+  __shared__ float sm[4];
+  float s = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    s += part[i * 2];
+    q += part[i * 2 + 1];
+  }
+  s = block_sum_256(s, sm);
+  q = block_sum_256(q, sm);
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    out[1] = q;
+  }
+}
+// x_noisy = clip(x + std * (u - 0.5), 0, 1) * a + b -> bf16; std from the global sums (biased
+// variance over ALL elements, tf.nn.moments over every axis)
+__global__ void dragan_perturb_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                      const float* __restrict__ sums, float inv_n, float a, float b,
+                                      int64_t n, bf16_t* __restrict__ out) {
+  const float mean = sums[0] * inv_n;
+  const float var = fmaxf(sums[1] * inv_n - mean * mean, 0.f);
+  const float sd = sqrtf(var);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = x[i] + sd * (u[i] - 0.5f);
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = f2bf(v * a + b);
+  }
+}
+
 extern "C" int cg_gan_loss(int kind, const float* logits, int B, float* losses, float* dlogits_d,
                            float* dlogits_g, cgStream stream) {
   if (!logits || !losses || B <= 0 || kind < 0 || kind > 3)
@@ -389,5 +439,31 @@ extern "C" int cg_random_labels(int K, uint64_t seed, uint32_t op_id, uint32_t s
   random_labels_kernel<<<grid_cap((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(
       K, seed, op_id, stream_id, step_ptr, out, n);
   CG_CHECK_LAUNCH("cg_random_labels");
+  return CG_OK;
+}
+
+extern "C" size_t cg_moments_workspace_bytes(void) { return MOM_BLOCKS * 2 * sizeof(float); }
+
+extern "C" int cg_moments_f32(const float* x, int64_t n, float* sums, void* ws, size_t ws_bytes,
+                              cgStream stream) {
+  if (!x || !sums || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_moments_f32: bad argument");
+  if (!ws || ws_bytes < cg_moments_workspace_bytes())
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_moments_f32: workspace too small");
+  int nb = (int)((n + 255) / 256);
+  if (nb > MOM_BLOCKS) nb = MOM_BLOCKS;
+  hipStream_t st = (hipStream_t)stream;
+  moments_part_kernel<<<nb, 256, 0, st>>>(x, n, (float*)ws);
+  moments_final_kernel<<<1, 256, 0, st>>>((const float*)ws, nb, sums);
+  CG_CHECK_LAUNCH("cg_moments_f32");
+  return CG_OK;
+}
+
+extern "C" int cg_dragan_perturb(const float* x, const float* u, const float* sums, int64_t n,
+                                 float a, float b, void* out_bf16, cgStream stream) {
+  if (!x || !u || !sums || !out_bf16 || n <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_dragan_perturb: bad argument");
+  dragan_perturb_kernel<<<grid_cap(n), 256, 0, (hipStream_t)stream>>>(x, u, sums, 1.0f / (float)n,
+                                                                      a, b, n, (bf16_t*)out_bf16);
+  CG_CHECK_LAUNCH("cg_dragan_perturb");
   return CG_OK;
 }

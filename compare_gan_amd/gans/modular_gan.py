@@ -288,7 +288,7 @@ class ModularGAN(AbstractGAN):
   def _preprocess(self, images, labels, sub_step):
     """Feature dictionary of one sub-step (modular_gan.py:393-408): real images, z, sampled
     labels; names are unique per sub-step so every sub-step draws fresh noise."""
-    features = {"images": images,
+    features = {"images": images, "_sub_step": sub_step,
                 "z": self.z_generator([images.shape[0], self._z_dim], name="z/%d" % sub_step)}
     if self.conditional:
       if self._fit_label_distribution:
@@ -325,6 +325,7 @@ class ModularGAN(AbstractGAN):
     self.d_loss, _, _, self.g_loss = loss_lib.get_losses(
         d_real=d_real, d_fake=d_fake, d_real_logits=d_real_logits, d_fake_logits=d_fake_logits)
     self.penalty_loss = None
+    tpu_random.set_sub_step(features.get("_sub_step", 0))
     if torch.is_grad_enabled() and not features.get("_generator_step", False):
       penalty_loss = penalty_lib.get_penalty_loss(
           x=images, x_fake=generated, y=y, is_training=is_training,

@@ -128,6 +128,9 @@ SIGNATURES = {
     "cg_interpolate": (c_int, [vp, vp, vp, c_int, c_i64, vp, vp]),
     "cg_gradient_penalty": (c_int, [vp, c_int, c_i64, vp, vp, vp]),
     "cg_gradient_penalty_bwd": (c_int, [vp, vp, vp, c_int, c_i64, vp, vp]),
+    "cg_moments_workspace_bytes": (c_sz, []),
+    "cg_moments_f32": (c_int, [vp, c_i64, vp, vp, c_sz, vp]),
+    "cg_dragan_perturb": (c_int, [vp, vp, vp, c_i64, c_f32, c_f32, vp, vp]),
     "cg_adam_multi": (c_int, [vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, vp, c_f32,
                               c_i64, vp]),
     "cg_counter_add": (c_int, [vp, c_i64, vp]),

@@ -678,6 +678,36 @@ def add_f32(a, b, alpha=1.0, beta=1.0):
   return AddF32Fn.apply(a, b, alpha, beta)
 
 
+class ScaleF32Fn(torch.autograd.Function):
+  """s * x on fp32 (linear, hence differentiable to any order through itself)."""
+
+  @staticmethod
+  def forward(ctx, x, s):
+    ctx.s = s
+    return K.scale_f32(x.contiguous(), None, s)
+
+  @staticmethod
+  def backward(ctx, d):
+    return ScaleF32Fn.apply(d.contiguous() if d.dtype == F32 else K.cast_bf16_to_f32(d.contiguous()),
+                            ctx.s), None
+
+
+class HalfSumSqFn(torch.autograd.Function):
+  """tf.nn.l2_loss(w) = sum(w^2) / 2 of an fp32 tensor (penalty_lib.py:99-102)."""
+
+  @staticmethod
+  def forward(ctx, w):
+    w = w.contiguous()
+    ctx.save_for_backward(w)
+    return ScaleF32Fn.apply(K.moments_f32(w)[1:2], 0.5).reshape(())
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, up):
+    w, = ctx.saved_tensors
+    return K.scale_f32(w, up.reshape(1).to(F32).contiguous()).reshape(w.shape)
+
+
 class AttentionFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, theta, phi, g):

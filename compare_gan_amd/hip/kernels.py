@@ -751,6 +751,29 @@ def interpolate(x, x_fake, alpha):
     return out
 
 
+def moments_f32(x):
+    """[sum x, sum x^2] of an fp32 tensor (device tensor of 2 floats)."""
+    _req(x, F32, "x")
+    sums = torch.empty((2,), dtype=F32, device=x.device)
+    ws = _ws(lib().cg_moments_workspace_bytes(), x)
+    check(lib().cg_moments_f32(_p(x), x.numel(), _p(sums), _p(ws), ws.numel(), _stream()),
+          "cg_moments_f32")
+    return sums
+
+
+def dragan_perturb(x, u, sums, a=1.0, b=0.0):
+    """clip(x + std(x) * (u - 0.5), 0, 1) * a + b -> bf16 (penalty_lib.py:46-49)."""
+    _req(x, F32, "x")
+    _req(u, F32, "u")
+    _req(sums, F32, "sums")
+    if u.numel() != x.numel():
+        raise ValueError("dragan_perturb: u has the wrong number of elements")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib().cg_dragan_perturb(_p(x), _p(u), _p(sums), x.numel(), float(a), float(b), _p(out),
+                                  _stream()), "cg_dragan_perturb")
+    return out
+
+
 def gradient_penalty(g):
     _req(g, F32, "g")
     B = g.shape[0]

@@ -11,7 +11,7 @@ import hashlib
 from compare_gan_amd.hip import kernels as K
 from compare_gan_amd.tpu import tpu_ops
 
-_STATE = {"seed": 0, "step": None}
+_STATE = {"seed": 0, "step": None, "sub_step": 0}
 
 
 def _op_id(name):
@@ -24,6 +24,18 @@ def set_random_offset(seed, step_tensor):
   (device int64 tensor) and the run seed used by subsequent calls."""
   _STATE["seed"] = int(seed)
   _STATE["step"] = step_tensor
+
+
+def set_sub_step(index):
+  """Index of the sub-step being built inside one unrolled training step: random ops without a
+  per-sub-step name of their own (the penalties' draws) append it, so that every sub-step has its
+  own op id -- the reference's unrolled graph holds one random op per sub-step
+  (modular_gan.py:568-584 + tpu_random.py:81-86)."""
+  _STATE["sub_step"] = int(index)
+
+
+def sub_step():
+  return _STATE["sub_step"]
 
 
 def uniform(shape, name, minval=0.0, maxval=1.0, device=None):

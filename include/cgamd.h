@@ -380,6 +380,17 @@ int cg_gradient_penalty(const float* g, int B, int64_t per, float* slopes, float
 int cg_gradient_penalty_bwd(const float* g, const float* slopes, const float* upstream, int B,
                             int64_t per, void* dg_bf16, cgStream stream);
 
+/* sums[0] = sum x, sums[1] = sum x^2 over n fp32 values (two-stage, deterministic): the global
+ * variance of DRAGAN (penalty_lib.py:46 tf.nn.moments over all axes) and tf.nn.l2_loss of a kernel
+ * (penalty_lib.py:99-102).  ws >= cg_moments_workspace_bytes(). */
+size_t cg_moments_workspace_bytes(void);
+int cg_moments_f32(const float* x, int64_t n, float* sums, void* ws, size_t ws_bytes,
+                   cgStream stream);
+/* x_noisy = clip(x + std * (u - 0.5), 0, 1) * a + b as bf16 (penalty_lib.py:47-49; a, b: the
+ * discriminator's input affine), std = sqrt(sums[1]/n - (sums[0]/n)^2) from cg_moments_f32 of x. */
+int cg_dragan_perturb(const float* x, const float* u, const float* sums, int64_t n, float a,
+                      float b, void* out_bf16, cgStream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser: tf.train.AdamOptimizer (TF1 epsilon placement) + tf.train.ExponentialMovingAverage
  * (modular_gan.py:480-483,494-508) over a list of tensors in ONE launch.

@@ -50,6 +50,9 @@ class OracleGAN(object):
   def d_vars(self):
     return [self.vs.vars[n] for n in self.vs.trainable if n.startswith("discriminator")]
 
+  def d_var_names(self):
+    return [n for n in self.vs.trainable if n.startswith("discriminator")]
+
   def create_loss(self, images, generated, labels, sampled_labels, alpha=None, with_penalty=True):
     """modular_gan.py:618-670 -> (d_loss, g_loss, d_all_logits)."""
     if self.conditional:
@@ -66,6 +69,13 @@ class OracleGAN(object):
       pen = ogan.wgangp_penalty(lambda x, yy, t: self.D(x, yy, t), images, generated.detach(), y,
                                 True, alpha.reshape(-1, 1, 1, 1))
       d_loss = d_loss + self.lamba * pen                                 # :670
+    elif with_penalty and self.penalty == "dragan_penalty":
+      # `alpha` carries the U[0,1) noise of the images' shape (penalty_lib.py:47)
+      pen = ogan.dragan_penalty(lambda x, yy, t: self.D(x, yy, t), images, y, True, alpha)
+      d_loss = d_loss + self.lamba * pen
+    elif with_penalty and self.penalty == "l2_penalty":
+      kernels = [v for n, v in zip(self.d_var_names(), self.d_vars()) if n.endswith("/kernel")]
+      d_loss = d_loss + self.lamba * ogan.l2_penalty(kernels)
     return d_loss, g_loss, d_all_logits
 
   def _ensure_opts(self):
