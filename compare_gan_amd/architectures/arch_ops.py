@@ -523,14 +523,13 @@ def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_forma
     mean, var = stats
   else:
     accu_mean, accu_var, accu_counter, update_accus = stats
-    if int(update_accus.item()) == 1:      # eval_gan_lib.py:65-92 fills the accumulators
+    # the fill switch is mirrored on the host by eval_gan_lib._update_bn_accumulators (the
+    # `update_accus` variable keeps the reference's name for checkpoints): no device read per call
+    if getattr(current_store(), "accu_fill", False):      # eval_gan_lib.py:65-92 fills the accumulators
       n, c = inputs.shape[0], inputs.shape[-1]
       bmean, bvar = K.bn_stats(inputs.contiguous().reshape(n, -1, c))
-      accu_mean.copy_(K.axpby_f32(accu_mean, 1.0, bmean, 1.0))
-      accu_var.copy_(K.axpby_f32(accu_var, 1.0, bvar, 1.0))
-      accu_counter.fill_(float(accu_counter.item()) + 1.0)
-    inv = 1.0 / float(accu_counter.item())  # arch_ops.py:191 accu / accu_counter
-    mean, var = K.axpby_f32(accu_mean, inv), K.axpby_f32(accu_var, inv)
+      K.bn_accumulate(accu_mean, accu_var, accu_counter.reshape(1), bmean, bvar)
+    mean, var = K.bn_accumulated_moments(accu_mean, accu_var, accu_counter.reshape(1))  # :191
   out, _, _ = Fn.batch_norm_act(inputs, gamma, beta, mean.contiguous(), var.contiguous(), epsilon,
                                 per_sample, relu, None)
   return out

@@ -483,6 +483,50 @@ extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, floa
   return CG_OK;
 }
 
+// accumulator statistics (arch_ops.py:122-191): accu += batch moments, counter += 1; and their read
+// side accu / counter -- all on the device, no host round trip per batch norm call
+__global__ void bn_accu_add_kernel(float* __restrict__ am, float* __restrict__ av,
+                                   float* __restrict__ cnt, const float* __restrict__ mean,
+                                   const float* __restrict__ var, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    am[c] += mean[c];
+    av[c] += var[c];
+  }
+  if (c == 0) *cnt += 1.f;
+}
+__global__ void bn_accu_read_kernel(const float* __restrict__ am, const float* __restrict__ av,
+                                    const float* __restrict__ cnt, float* __restrict__ mean,
+                                    float* __restrict__ var, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float n = *cnt;
+    mean[c] = am[c] / n;
+    var[c] = av[c] / n;
+  }
+}
+
+extern "C" int cg_bn_accumulate(float* accu_mean, float* accu_var, float* accu_counter,
+                                const float* mean, const float* var, int C, cgStream stream) {
+  if (!accu_mean || !accu_var || !accu_counter || !mean || !var || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_accumulate: bad argument");
+  bn_accu_add_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(accu_mean, accu_var,
+                                                                    accu_counter, mean, var, C);
+  CG_CHECK_LAUNCH("cg_bn_accumulate");
+  return CG_OK;
+}
+
+extern "C" int cg_bn_accumulated_moments(const float* accu_mean, const float* accu_var,
+                                         const float* accu_counter, float* mean, float* var,
+                                         int C, cgStream stream) {
+  if (!accu_mean || !accu_var || !accu_counter || !mean || !var || C <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_accumulated_moments: bad argument");
+  bn_accu_read_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(accu_mean, accu_var,
+                                                                     accu_counter, mean, var, C);
+  CG_CHECK_LAUNCH("cg_bn_accumulated_moments");
+  return CG_OK;
+}
+
 extern "C" int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean,
                               float* var, float* moving_mean, float* moving_var, float decay,
                               cgStream stream) {

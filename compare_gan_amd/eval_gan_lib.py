@@ -35,10 +35,14 @@ def _update_bn_accumulators(gan, generate_fn, batch_size, num_accu_examples):
     return False
   for v in switches:
     v.fill_(1)
-  for _ in range(num_accu_examples // batch_size):
-    generate_fn()
-  for v in switches:
-    v.fill_(0)
+  gan.store.accu_fill = True    # host mirror of the switch (arch_ops.standardize_batch)
+  try:
+    for _ in range(num_accu_examples // batch_size):
+      generate_fn()
+  finally:
+    gan.store.accu_fill = False
+    for v in switches:
+      v.fill_(0)
   return True
 
 

@@ -94,6 +94,8 @@ SIGNATURES = {
     "cg_bn_backward_apply": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_f32, vp, c_int,
                                      c_int, c_int, vp, vp, vp]),
     "cg_bn_moments_convert": (c_int, [vp, vp, c_int, c_int, c_f32, vp]),
+    "cg_bn_accumulate": (c_int, [vp, vp, vp, vp, vp, c_int, vp]),
+    "cg_bn_accumulated_moments": (c_int, [vp, vp, vp, vp, vp, c_int, vp]),
     "cg_bn_update_moving": (c_int, [vp, vp, vp, vp, c_int, c_f32, vp]),
     "cg_lrelu": (c_int, [vp, c_f32, vp, c_i64, vp]),
     "cg_lrelu_bwd": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),

@@ -466,6 +466,26 @@ def bn_backward(x3, y3, dy3, mean, var, eps, gamma=None, per_sample=False, relu=
     return dx, dgamma, dbeta
 
 
+def bn_accumulate(accu_mean, accu_var, accu_counter, mean, var):
+    """accu_mean += mean; accu_var += var; accu_counter += 1 (in place, on the device)."""
+    for t, nm in ((accu_mean, "accu_mean"), (accu_var, "accu_var"), (accu_counter, "accu_counter"),
+                  (mean, "mean"), (var, "var")):
+        _req(t, F32, nm)
+    check(lib().cg_bn_accumulate(_p(accu_mean), _p(accu_var), _p(accu_counter), _p(mean), _p(var),
+                                 mean.numel(), _stream()), "cg_bn_accumulate")
+
+
+def bn_accumulated_moments(accu_mean, accu_var, accu_counter):
+    """(accu_mean / accu_counter, accu_var / accu_counter) without a host round trip."""
+    for t, nm in ((accu_mean, "accu_mean"), (accu_var, "accu_var"), (accu_counter, "accu_counter")):
+        _req(t, F32, nm)
+    mean, var = torch.empty_like(accu_mean), torch.empty_like(accu_var)
+    check(lib().cg_bn_accumulated_moments(_p(accu_mean), _p(accu_var), _p(accu_counter), _p(mean),
+                                          _p(var), accu_mean.numel(), _stream()),
+          "cg_bn_accumulated_moments")
+    return mean, var
+
+
 def bn_moments_convert(mean, second, to_variance, scale=1.0):
     _req(mean, F32, "mean")
     _req(second, F32, "second")

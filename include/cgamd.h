@@ -273,6 +273,15 @@ int cg_bn_backward_apply(const void* x, const void* y, const void* dy, int N, in
  * to_variance == 1: mean *= scale; second *= scale; second <- second - mean^2. */
 int cg_bn_moments_convert(float* mean, float* second, int C, int to_variance, float scale,
                           cgStream stream);
+/* Accumulator statistics for inference (arch_ops.py:122-191, filled by eval_gan_lib.py:65-92):
+ *   cg_bn_accumulate          accu_mean += mean; accu_var += var; *accu_counter += 1
+ *   cg_bn_accumulated_moments mean = accu_mean / *accu_counter; var = accu_var / *accu_counter
+ * (accu_counter is a device scalar initialised to 1e-12, arch_ops.py:166.) */
+int cg_bn_accumulate(float* accu_mean, float* accu_var, float* accu_counter, const float* mean,
+                     const float* var, int C, cgStream stream);
+int cg_bn_accumulated_moments(const float* accu_mean, const float* accu_var,
+                              const float* accu_counter, float* mean, float* var, int C,
+                              cgStream stream);
 /* Moving averages m <- m - (1-decay) * (m - batch)  (arch_ops.py:105-114), both vectors [C]. */
 int cg_bn_update_moving(float* moving_mean, float* moving_var, const float* mean,
                         const float* var, int C, float decay, cgStream stream);
