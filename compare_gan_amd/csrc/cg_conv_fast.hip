@@ -457,358 +457,6 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
   }
 }
 
-// UNVERIFIED ON THE GPU (written after the round's GPU budget was spent; never dispatched unless
-// CGAMD_CONV_W8=1): the 4-wave kernel above with 8 waves on a 256-pixel tile.  A K-slice of a
-// 256x128 tile stages 48 KiB for 32 MFMAs per wave-pair instead of 32 KiB for 16: 25 % fewer
-// LDS-DMA bytes per MFMA, which is what bounds the 128x128 form.  NS = 1 keeps
-// two workgroups (16 waves) per CU.  Round 2: run test_conv_kernel_variants with the switch, A/B it.
-template <int BM, int BN, bool RELU, int NS>
-__global__ __launch_bounds__(512, NS == 1 ? 2 : 1) void fast_conv_w8_kernel(FastConvArgs a) {
-  constexpr int NW = 8;                   // waves per workgroup
-  constexpr int WN = BN >= 128 ? 2 : 1;   // waves along the channel dimension
-  constexpr int WM = NW / WN;
-  constexpr int AJ = BM / (8 * NW);       // A staging instructions per wave (8 rows of 128 B each)
-  constexpr int BJ = BN / (8 * NW);       // B staging instructions per wave
-  static_assert(AJ >= 1 && BJ >= 1 && AJ * 8 * NW == BM && BJ * 8 * NW == BN, "tile / wave split");
-  constexpr int TM = BM / WM / 32;        // 32-pixel MFMA tiles per wave
-  constexpr int TN = BN / WN / 32;        // 32-channel MFMA tiles per wave
-  constexpr int A_ELEMS = BM * 64, B_ELEMS = BN * 64;
-  // NS = 1: one buffer, two barriers per K-slice, three workgroups per CU overlap each other;
-  // the staged epilogue needs (BM / WM) x (BN + 4) floats
-  constexpr int EPI_ELEMS = (BM / WM) * (BN + 4) * 2;
-  constexpr int RING_ELEMS = NS * (A_ELEMS + B_ELEMS);
-  __shared__ __attribute__((aligned(1024)))
-  bf16_t smem[RING_ELEMS > EPI_ELEMS || NS > 1 ? RING_ELEMS : EPI_ELEMS];
-  constexpr int LOADS = AJ + BJ;   // LDS-DMA instructions per thread per stage
-  constexpr int D = NS - 1;        // prefetch distance
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = (int)fdiv((uint32_t)wg, a.dNt);
-  const int nt = wg - mt * a.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  // ---- phase geometry (wave-uniform) ----
-  const int phase = blockIdx.y;
-  int r0 = 0, s0 = 0, nr = a.kh, ns = a.kw, bh = -a.pt, bw = -a.pl, ph = 0, pw = 0;
-  if (a.U == 2) {
-    ph = phase >> 1;
-    pw = phase & 1;
-    r0 = (a.pt + ph) & 1;
-    s0 = (a.pl + pw) & 1;
-    nr = (a.kh - r0 + 1) >> 1;
-    ns = (a.kw - s0 + 1) >> 1;
-    bh = (ph - a.pt + r0) >> 1;  // exact: the numerator is even
-    bw = (pw - a.pl + s0) >> 1;
-  }
-  const int nk = nr * ns * a.cblocks;
-
-  // ---- per-thread staging descriptors ----
-  // instruction group g = wave*AJ + j stages rows g*8 .. g*8+7; lane -> row g*8 + (lane >> 3),
-  // LDS slot (lane & 7) which must hold source chunk (lane & 7) ^ ((row >> 1) & 7)
-  int a_off[AJ], a_ih[AJ], a_iw[AJ], a_c8[AJ];
-  bool a_ok[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int g = wave * AJ + j;
-    const int row = g * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    a_c8[j] = c * 8;
-    const int m = m0 + row;
-    a_ok[j] = m < a.Mp;
-    const uint32_t mm = a_ok[j] ? (uint32_t)m : 0u;
-    const uint32_t t1 = fdiv(mm, a.dWp);
-    const int owp = (int)(mm - t1 * a.Wp);
-    const uint32_t n = fdiv(t1, a.dHp);
-    const int ohp = (int)(t1 - n * a.Hp);
-    a_ih[j] = (a.U == 2) ? ohp + bh : ohp * a.S + bh;
-    a_iw[j] = (a.U == 2) ? owp + bw : owp * a.S + bw;
-    a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.Ci + c * 8;
-  }
-  int b_off[BJ], b_c8[BJ];
-  bool b_ok[BJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    const int g = wave * BJ + j;
-    const int row = g * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    b_c8[j] = c * 8;
-    b_ok[j] = (n0 + row) < a.Co;
-    b_off[j] = (n0 + row) * a.Kp + c * 8;
-  }
-
-  auto Abuf = [&](int buf) { return smem + buf * (A_ELEMS + B_ELEMS); };
-  auto Bbuf = [&](int buf) { return smem + buf * (A_ELEMS + B_ELEMS) + A_ELEMS; };
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
-
-  // tap iteration state of the NEXT slice to stage (all scalar)
-  int st_ri = 0, st_si = 0, st_cb = 0;
-  auto stage = [&](int buf) {
-    const int tapoff = (st_ri * a.Win + st_si) * a.Ci + st_cb * 64;
-    const int koff = ((r0 + a.U * st_ri) * a.kw + (s0 + a.U * st_si)) * a.Ci + st_cb * 64;
-    bf16_t* Ab = Abuf(buf) + (wave * AJ) * 512;
-    bf16_t* Bb = Bbuf(buf) + (wave * BJ) * 512;
-    const int crem = a.Ci - st_cb * 64;   // channels left in this block (< 64 only for the last
-                                          // block of a channel count that is not a multiple of 64)
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const bool ok = a_ok[j] && a_c8[j] < crem &&
-                      (unsigned)(a_ih[j] + st_ri) < (unsigned)a.Hin &&
-                      (unsigned)(a_iw[j] + st_si) < (unsigned)a.Win;
-      const bf16_t* p = ok ? a.in + (int64_t)(a_off[j] + tapoff) : zero;
-      glds16(p, Ab + j * 512);
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const bf16_t* p = (b_ok[j] && b_c8[j] < crem) ? a.bt + (int64_t)(b_off[j] + koff) : zero;
-      glds16(p, Bb + j * 512);
-    }
-    if (++st_cb == a.cblocks) {
-      st_cb = 0;
-      if (++st_si == ns) {
-        st_si = 0;
-        ++st_ri;
-      }
-    }
-  };
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-  // fragment addressing: row = base + (lane & 31), chunk = kk*2 + (lane >> 5), swizzled
-  const int frow = lane & 31;
-  const int swz = (frow >> 1) & 7;
-  int koffs[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) koffs[kk] = (((kk * 2 + (lane >> 5)) ^ swz) << 3);
-  const int arow0 = (wm * (BM / WM) + frow) * 64;
-  const int brow0 = (wn * (BN / WN) + frow) * 64;
-
-  int staged = 0;
-  for (; staged < D && staged < nk; ++staged) stage(staged % NS);
-
-  if constexpr (NS == 1) {
-    for (int it = 0; it < nk; ++it) {
-      stage(0);
-      wait_vmcnt<0>();
-      __syncthreads();
-      const bf16_t* Ab = Abuf(0);
-      const bf16_t* Bb = Bbuf(0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
-          if (RELU) af[i] = relu_bf16x8(af[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-  } else
-  for (int it = 0; it < nk; ++it) {
-    // wait for slice `it` (the oldest in flight), then barrier: every wave's share of it has landed
-    // and every wave has finished reading the buffer that is restaged below (slice it - 1's)
-    const int ahead = staged - it - 1;
-    if (D >= 3 && ahead >= 2) wait_vmcnt<2 * LOADS>();
-    else if (D >= 2 && ahead == 1) wait_vmcnt<LOADS>();
-    else wait_vmcnt<0>();
-    asm volatile("s_barrier" ::: "memory");
-    if (staged < nk) {
-      stage(staged % NS);
-      ++staged;
-    }
-    const int buf = it % NS;
-    const bf16_t* Ab = Abuf(buf);
-    const bf16_t* Bb = Bbuf(buf);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
-        if (RELU) af[i] = relu_bf16x8(af[i]);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue, coalesced form (Co % 8 == 0): the accumulators (+ bias, self-activation) go
-  // through LDS in WM passes of BM/WM rows, then every thread finishes 8 consecutive channels of
-  // one pixel: gate / residual are read and the result is written as 16-byte (bf16) or 2 x 16-byte
-  // (fp32) pieces, whole rows contiguous across the lanes.  (The direct form below issues 8-byte
-  // stores 256 B apart; measured, the output write was ~20 us of a 67 us launch.)
-  if ((a.Co & 7) == 0) {
-    constexpr int RP = BM / WM;          // rows per pass
-    constexpr int LDC = BN + 4;          // floats per LDS row (+16 B: conflict-free b128 writes)
-    constexpr int C8 = BN / 8;           // 8-channel items per row
-    float* Cs = reinterpret_cast<float*>(smem);
-    for (int h = 0; h < WM; ++h) {
-      __syncthreads();
-      if (wm == h) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int col = wn * (BN / WN) + j * 32 + q * 8 + 4 * (lane >> 5);
-              float4 v = make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1],
-                                     acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-              if (a.bias && n0 + col < a.Co) {
-                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + col);
-                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-              }
-              if (a.self_gate) {
-                if (!(v.x > 0.f)) v.x *= a.slope_out;
-                if (!(v.y > 0.f)) v.y *= a.slope_out;
-                if (!(v.z > 0.f)) v.z *= a.slope_out;
-                if (!(v.w > 0.f)) v.w *= a.slope_out;
-              }
-              *reinterpret_cast<float4*>(Cs + (i * 32 + frow) * LDC + col) = v;
-            }
-      }
-      __syncthreads();
-      for (int t = tid; t < RP * C8; t += 64 * NW) {
-        const int row = t / C8, c8 = t - row * C8;
-        const int m = m0 + h * RP + row;
-        const int co = n0 + c8 * 8;
-        if (m >= a.Mp || co >= a.Co) continue;
-        const uint32_t t1 = fdiv((uint32_t)m, a.dWp);
-        const int owp = m - (int)t1 * a.Wp;
-        const uint32_t n = fdiv(t1, a.dHp);
-        const int ohp = (int)t1 - (int)n * a.Hp;
-        const int64_t o =
-            ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + co;
-        const float4 lo = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8 + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (a.gate_out) {
-          union { uint4 q; bf16_t h8[8]; } g;
-          g.q = *reinterpret_cast<const uint4*>(a.gate_out + o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (!(bf2f(g.h8[e]) > 0.f)) v[e] *= a.slope_out;
-        }
-        if (a.residual) {
-          union { uint4 q; bf16_t h8[8]; } r;
-          r.q = *reinterpret_cast<const uint4*>(a.residual + o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bf2f(r.h8[e]);
-        }
-        if (a.out_f32) {
-          float* op = reinterpret_cast<float*>(a.out) + o;
-          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          union { uint4 q; bf16_t h8[8]; } w;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w.h8[e] = f2bf(v[e]);
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = w.q;
-        }
-      }
-    }
-    return;
-  }
-
-  // ---- epilogue: lane owns pixel (lane & 31) of each M sub-tile and, per 8-channel group q, the
-  // 4 consecutive channels 8*q + 4*(lane >> 5) + {0..3}
-  const bool vec4 = (a.Co & 3) == 0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / WM) + i * 32 + frow;
-    if (m >= a.Mp) continue;
-    const uint32_t t1 = fdiv((uint32_t)m, a.dWp);
-    const int owp = m - (int)t1 * a.Wp;
-    const uint32_t n = fdiv(t1, a.dHp);
-    const int ohp = (int)t1 - (int)n * a.Hp;
-    const int64_t opix =
-        ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + wn * (BN / WN) + j * 32 + q * 8 + 4 * (lane >> 5);
-        if (co >= a.Co) continue;
-        float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
-                      acc[i][j][q * 4 + 3]};
-        const int64_t o = opix + co;
-        if (vec4) {
-          if (a.bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
-            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-          }
-          if (a.self_gate) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (!(v[e] > 0.f)) v[e] *= a.slope_out;
-          } else if (a.gate_out) {
-            const uint2 g2 = *reinterpret_cast<const uint2*>(a.gate_out + o);
-            if (!(bf2f((bf16_t)(g2.x & 0xffff)) > 0.f)) v[0] *= a.slope_out;
-            if (!(bf2f((bf16_t)(g2.x >> 16)) > 0.f)) v[1] *= a.slope_out;
-            if (!(bf2f((bf16_t)(g2.y & 0xffff)) > 0.f)) v[2] *= a.slope_out;
-            if (!(bf2f((bf16_t)(g2.y >> 16)) > 0.f)) v[3] *= a.slope_out;
-          }
-          if (a.residual) {
-            const uint2 r2 = *reinterpret_cast<const uint2*>(a.residual + o);
-            v[0] += bf2f((bf16_t)(r2.x & 0xffff));
-            v[1] += bf2f((bf16_t)(r2.x >> 16));
-            v[2] += bf2f((bf16_t)(r2.y & 0xffff));
-            v[3] += bf2f((bf16_t)(r2.y >> 16));
-          }
-          if (a.out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) =
-                make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 w2;
-            w2.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            w2.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o) = w2;
-          }
-        } else {
-          // channel counts that are not a multiple of 4 (RGB outputs): element-wise tail
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (co + e >= a.Co) continue;
-            float val = v[e] + (a.bias ? a.bias[co + e] : 0.f);
-            if (a.self_gate) {
-              if (!(val > 0.f)) val *= a.slope_out;
-            } else if (a.gate_out && !(bf2f(a.gate_out[o + e]) > 0.f)) {
-              val *= a.slope_out;
-            }
-            if (a.residual) val += bf2f(a.residual[o + e]);
-            if (a.out_f32)
-              reinterpret_cast<float*>(a.out)[o + e] = val;
-            else
-              reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val);
-          }
-        }
-      }
-    }
-  }
-}
-
 // Intra-workgroup split-K form for grids of at most about one workgroup per CU: 8 waves = two groups
 // of 4, each the 4-wave kernel above on every other K-slice with its own LDS ring; the groups hide
 // each other's LDS-DMA issue time and load latency (what a co-resident workgroup does on large
@@ -2446,25 +2094,6 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     const char* e = getenv("CGAMD_CONV_T128_MIN");
     return e ? atoi(e) : 513;
   }();
-  static const int w8_env = [] {
-    const char* e = getenv("CGAMD_CONV_W8");
-    return e ? atoi(e) : 0;
-  }();
-  if (w8_env && tiles128 >= 2 * t128_min) {
-    // unverified 8-wave 256x128 form (see fast_conv_w8_kernel): opt-in only
-    a.mtiles = cdiv(a.Mp, 256);
-    dim3 grid(a.mtiles * a.ntiles, phases);
-    CgProfScope prof(CG_PROF_FAST_CONV_128x128, g, st);
-    const int blocks = grid.x * grid.y;
-    if (blocks >= 512) {
-      if (a.relu_in) fast_conv_w8_kernel<256, 128, true, 1><<<grid, 512, 0, st>>>(a);
-      else fast_conv_w8_kernel<256, 128, false, 1><<<grid, 512, 0, st>>>(a);
-    } else {
-      if (a.relu_in) fast_conv_w8_kernel<256, 128, true, 2><<<grid, 512, 0, st>>>(a);
-      else fast_conv_w8_kernel<256, 128, false, 2><<<grid, 512, 0, st>>>(a);
-    }
-    return;
-  }
   if (tiles128 >= t128_min) {
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles * a.ntiles, phases);

@@ -392,3 +392,60 @@ extern "C" int cg_inception_score_f64(const float* logits, int64_t n, int k, dou
   CG_CHECK_LAUNCH("cg_inception_score_f64(final)");
   return CG_OK;
 }
+
+// ---- KID (metrics/kid_score.py:44-149): sum and trace of the cubic polynomial kernel
+// (gram / dim + 1)^3 of one block, fp64, two-stage deterministic reduction ----
+constexpr int KID_BLOCKS = 256;
+__global__ __launch_bounds__(256) void poly3_part_kernel(const double* __restrict__ g, int m, int n,
+                                                         double inv_dim, double* __restrict__ part) {
+  __shared__ double sm[2][4];
+  double s = 0.0, t = 0.0;
+  const int64_t total = (int64_t)m * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const double k1 = g[i] * inv_dim + 1.0;
+    const double k3 = k1 * k1 * k1;
+    s += k3;
+    const int64_t r = i / n, c = i - r * n;
+    if (r == c) t += k3;
+  }
+  s = wave_sum_d(s);
+  t = wave_sum_d(t);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][w] = s;
+    sm[1][w] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    part[blockIdx.x * 2 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+  }
+}
+__global__ void poly3_final_kernel(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0, t = 0.0;
+    for (int i = 0; i < nb; ++i) {
+      s += part[i * 2];
+      t += part[i * 2 + 1];
+    }
+    out[0] = s;
+    out[1] = t;
+  }
+}
+
+extern "C" size_t cg_poly3_kernel_workspace_bytes(void) { return KID_BLOCKS * 2 * sizeof(double); }
+
+extern "C" int cg_poly3_kernel_sums_f64(const double* gram, int m, int n, double inv_dim,
+                                        double* out2, void* ws, size_t ws_bytes, cgStream stream) {
+  if (!gram || !out2 || m <= 0 || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_poly3_kernel_sums_f64: bad argument");
+  if (!ws || ws_bytes < cg_poly3_kernel_workspace_bytes())
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_poly3_kernel_sums_f64: workspace too small");
+  const int64_t total = (int64_t)m * n;
+  int nb = (int)((total + 255) / 256);
+  if (nb > KID_BLOCKS) nb = KID_BLOCKS;
+  hipStream_t st = (hipStream_t)stream;
+  poly3_part_kernel<<<nb, 256, 0, st>>>(gram, m, n, inv_dim, (double*)ws);
+  poly3_final_kernel<<<1, 64, 0, st>>>((const double*)ws, nb, out2);
+  CG_CHECK_LAUNCH("cg_poly3_kernel_sums_f64");
+  return CG_OK;
+}

@@ -121,6 +121,10 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
       result_statistics[key + "_std"] = np.std(scores_for_key)
       result_statistics[key + "_list"] = "_".join([str(x) for x in scores_for_key])
     result_dict.update(result_statistics)
+  # trained Inception weights cannot be fetched offline: results computed on the seeded synthetic
+  # extractor are tagged so they are never mistaken for numbers comparable with published FIDs
+  result_dict["inception_weights_synthetic"] = float(
+      eval_utils.inception_weights_are_synthetic(device))
   timing["stats"] = tick() - t1
   LAST_TIMING.clear()
   LAST_TIMING.update(timing)

@@ -3,9 +3,13 @@
 EvalDataSample, NanFoundError, get_real_images, sample_fake_dataset and the batched Inception
 transform.  Image sets stay on the GPU as fp32 tensors in [0, 255] (the reference round-trips
 them through NumPy: SURVEY.md section 8a row a14)."""
+import os
+import warnings
+
 import numpy as np
 import torch
 
+from compare_gan_amd import gin
 from compare_gan_amd import inception as inception_lib
 
 _INCEPTION = {}
@@ -73,11 +77,46 @@ def sample_fake_dataset(generate_fn, num_batches):
   return _to_three_channels(K.scale_f32(fake_images.contiguous(), None, 255.0))
 
 
+def _load_inception_weight_file(path):
+  """{name: tensor} from a .npz / .safetensors / torch file in inception.py's layouts
+  (HWIO conv kernels, biases, logits/kernel [2048, 1008])."""
+  if path.endswith(".npz"):
+    with np.load(path) as z:
+      return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+  if path.endswith(".safetensors"):
+    from safetensors.torch import load_file
+    return load_file(path)
+  return torch.load(path, map_location="cpu")
+
+
+@gin.configurable("inception_weights")
+def inception_weights_path(path=None):
+  """File with the trained weights of the 2015 Inception graph (eval_utils.py:41-49 downloads
+  the frozen graph; offline it has to be supplied).  gin: inception_weights.path, or the
+  CGAMD_INCEPTION_WEIGHTS environment variable."""
+  return path or os.environ.get("CGAMD_INCEPTION_WEIGHTS") or None
+
+
 def get_inception(device):
   key = str(device)
   if key not in _INCEPTION:
-    _INCEPTION[key] = inception_lib.InceptionV3(device)
+    path = inception_weights_path()
+    if path:
+      _INCEPTION[key] = inception_lib.InceptionV3(device, _load_inception_weight_file(path))
+      _INCEPTION[key].synthetic_weights = False
+    else:
+      warnings.warn(
+          "Inception weights are SYNTHETIC (seeded He-normal draws): no trained weight file was "
+          "given (gin `inception_weights.path` / CGAMD_INCEPTION_WEIGHTS).  FID / IS / KID values "
+          "are self-consistent but NOT comparable with published numbers; results carry "
+          "inception_weights_synthetic = 1.", RuntimeWarning, stacklevel=2)
+      _INCEPTION[key] = inception_lib.InceptionV3(device)
+      _INCEPTION[key].synthetic_weights = True
   return _INCEPTION[key]
+
+
+def inception_weights_are_synthetic(device="cuda:0"):
+  return bool(getattr(get_inception(device), "synthetic_weights", True))
 
 
 def inception_transform(inputs):

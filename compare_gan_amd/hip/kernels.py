@@ -960,6 +960,17 @@ def gemm_f64(a, b, ta=False, tb=False):
     return c
 
 
+def poly3_kernel_sums_f64(gram, dim):
+    """[sum, trace] of (gram / dim + 1)^3 for an fp64 Gram block (device tensor of 2 doubles)."""
+    _req(gram, F64, "gram")
+    m, n = gram.shape
+    out = torch.empty((2,), dtype=F64, device=gram.device)
+    ws = _ws(lib().cg_poly3_kernel_workspace_bytes(), gram)
+    check(lib().cg_poly3_kernel_sums_f64(_p(gram), m, n, 1.0 / float(dim), _p(out), _p(ws),
+                                         ws.numel(), _stream()), "cg_poly3_kernel_sums_f64")
+    return out
+
+
 def rowscale_f64(a, scale):
     _req(a, F64, "a")
     _req(scale, F64, "scale")

@@ -467,6 +467,12 @@ int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
 size_t cg_syevj_workspace_bytes(int d);
 int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,
                  size_t ws_bytes, cgStream stream);
+/* KID (metrics/kid_score.py:129-136): out2[0] = sum, out2[1] = trace of the cubic polynomial kernel
+ * (gram / dim + 1)^3 of an [m, n] fp64 Gram block (cg_gemm_f64 of two activation blocks).
+ * ws >= cg_poly3_kernel_workspace_bytes(). */
+size_t cg_poly3_kernel_workspace_bytes(void);
+int cg_poly3_kernel_sums_f64(const double* gram, int m, int n, double inv_dim, double* out2,
+                             void* ws, size_t ws_bytes, cgStream stream);
 /* Inception score pieces: logits [n,k] fp32 -> exp(mean_i KL(p_i || mean_j p_j)) in fp64. */
 size_t cg_inception_score_workspace_bytes(int64_t n, int k);
 int cg_inception_score_f64(const float* logits, int64_t n, int k, double* score, void* ws,

@@ -87,3 +87,34 @@ def inception_preprocess(images_0_255, size=299):
   """tfgan.eval.preprocess_image: resize_bilinear to 299x299 then (x - 128) / 128
   (eval_utils.py:165-175)."""
   return (resize_bilinear_tf1(images_0_255, size, size) - 128.0) / 128.0
+
+
+def kid(fake_activations, real_activations, max_batch_size=1024):
+  """Restatement of metrics/kid_score.py:44-149 in NumPy fp64 (block estimator, cubic polynomial
+  kernel, including the reference's use of the REAL block size for both normalisers and of
+  bins_r[0] when trimming both bin arrays).  No golden value exists in the reference
+  (kid_score has no test): parity unpinned, checked by the estimator's closed form on tiny inputs
+  in tests/test_oracle_pins.py."""
+  import math
+  real = np.asarray(real_activations, dtype=np.float64)
+  fake = np.asarray(fake_activations, dtype=np.float64)
+  n_real, dim = real.shape
+  n_gen, _ = fake.shape
+  n_bins = int(math.ceil(max(n_real, n_gen) / max_batch_size))
+  bins_r = np.full(n_bins, int(math.ceil(n_real / n_bins)))
+  bins_g = np.full(n_bins, int(math.ceil(n_gen / n_bins)))
+  bins_r[:(n_bins * bins_r[0]) - n_real] -= 1
+  bins_g[:(n_bins * bins_r[0]) - n_gen] -= 1
+  inds_r = np.r_[0, np.cumsum(bins_r)]
+  inds_g = np.r_[0, np.cumsum(bins_g)]
+  ests = []
+  for i in range(n_bins):
+    r = real[inds_r[i]:inds_r[i + 1]]
+    g = fake[inds_g[i]:inds_g[i + 1]]
+    m = n = float(r.shape[0])
+    k_rr = (r @ r.T / dim + 1) ** 3
+    k_rg = (r @ g.T / dim + 1) ** 3
+    k_gg = (g @ g.T / dim + 1) ** 3
+    ests.append(-2 * k_rg.mean() + (k_rr.sum() - np.trace(k_rr)) / (m * (m - 1)) +
+                (k_gg.sum() - np.trace(k_gg)) / (n * (n - 1)))
+  return float(np.mean(ests))

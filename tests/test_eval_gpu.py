@@ -39,6 +39,23 @@ def test_fid_matches_oracle(dev, n, d):
     assert abs(same) <= 1e-6 * float(np.trace(np.cov(a.T))), same
 
 
+@pytest.mark.parametrize("n_real,n_gen,d,mbs", [(64, 64, 32, 1024), (300, 257, 64, 100),
+                                                (2048, 2048, 2048, 1024)])
+def test_kid_matches_oracle(dev, n_real, n_gen, d, mbs):
+    """metrics/kid_score.py:44-149 -- device fp64 block estimator vs the NumPy restatement,
+    ragged block sizes included.  Tolerance: 1e-9 relative (fp64 GEMM summation order)."""
+    from compare_gan_amd.metrics import kid_score
+    rng = np.random.RandomState(n_real + d)
+    real = rng.rand(n_real, d).astype(np.float32)
+    gen = (rng.rand(n_gen, d) * 1.1 + 0.05).astype(np.float32)
+    want = ofid.kid(gen, real, max_batch_size=mbs)
+    got = kid_score.kid(torch.from_numpy(gen).to(dev), torch.from_numpy(real).to(dev),
+                        max_batch_size=mbs, device=dev)
+    assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (got, want)
+    got2, err = kid_score.kid(gen, real, max_batch_size=mbs, return_stderr=True, device=dev)
+    assert got2 == got and (np.isnan(err) if n_real // mbs < 5 else err >= 0)
+
+
 def test_inception_score_matches_oracle(dev):
     from compare_gan_amd.metrics import inception_score
     rng = np.random.RandomState(3)
@@ -73,11 +90,16 @@ def test_evaluate_gan_small(dev):
     """evaluate_gan end to end on a freshly initialised ResNet-CIFAR GAN with 128 test examples:
     keys and aggregation of eval_gan_lib.py:196-212, determinism of the evaluation noise."""
     from compare_gan_amd import eval_gan_lib
-    from compare_gan_amd.metrics import fid_score, inception_score
+    from compare_gan_amd.metrics import fid_score, inception_score, kid_score
     gan, options, dataset = U.build_product("resnet_cifar10.gin", 8, dev, seed=3)
-    tasks = [inception_score.InceptionScoreTask(), fid_score.FIDScoreTask()]
-    r1 = eval_gan_lib.evaluate_gan(gan, tasks, num_averaging_runs=2, num_test_examples=128)
-    for key in ("inception_score", "fid_score"):
+    tasks = [inception_score.InceptionScoreTask(), fid_score.FIDScoreTask(),
+             kid_score.KIDScoreTask()]
+    with pytest.warns(RuntimeWarning, match="SYNTHETIC") if not eval_gan_lib.eval_utils._INCEPTION \
+            else __import__("contextlib").nullcontext():
+        r1 = eval_gan_lib.evaluate_gan(gan, tasks, num_averaging_runs=2, num_test_examples=128)
+    assert r1["inception_weights_synthetic"] == 1.0     # no trained weight file offline: tagged
+    assert np.isfinite(r1["kid_score_mean"])
+    for key in ("inception_score", "fid_score", "kid_score"):
         for suffix in ("_mean", "_std", "_list"):
             assert key + suffix in r1
     assert r1["inception_score_mean"] >= 1.0 - 1e-6 and np.isfinite(r1["fid_score_mean"])

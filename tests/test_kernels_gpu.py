@@ -690,9 +690,6 @@ CONV_VARIANT_ENVS = [
     # halo-staged forward / weight-gradient kernels wherever they apply
     ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1", "CGAMD_HCONV_RW_MIN": "1"}),
     ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0", "CGAMD_WSTEM": "0", "CGAMD_HCONV_RW": "0"}),
-    # round 2: fast_conv_w8_kernel (8 waves, 256x128 tiles) was written after the GPU budget of
-    # round 1 was spent and has never run; verify it with this entry, then A/B it:
-    # ("w8_tiles", {"CGAMD_CONV_W8": "1", "CGAMD_CONV_T128_MIN": "1"}),
 ]
 
 
