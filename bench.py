@@ -217,13 +217,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dp = os.environ.get("CGAMD_FORCE_DP", "") == "1"   # exercise the RCCL path on 1 GPU
-    if world > 1 or force_dp:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    # one process per GPU: joins the RCCL group and switches batch norm to cross-replica
+    # statistics (the reference's data-parallel semantics, arch_ops.py:258-263)
+    from compare_gan_amd.tpu import tpu_ops
+    tpu_ops.init_replicas(dev)
 
     from compare_gan_amd import datasets, gin, runner_lib
     from compare_gan_amd import eval_gan_lib  # noqa: F401  (registers eval_z)

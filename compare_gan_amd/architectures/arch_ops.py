@@ -100,20 +100,29 @@ class VariableStore(object):
 _STORE = [None]
 
 
+def _store_cell():
+  """The one-element list holding the active store; a thread attached to an in-process replica
+  set (tpu_ops.InProcessReplicas) has its own."""
+  ts = tpu_ops.thread_state()
+  return _STORE if ts is None else ts.setdefault("store", [None])
+
+
 @contextlib.contextmanager
 def use_store(store):
-  old = _STORE[0]
-  _STORE[0] = store
+  cell = _store_cell()
+  old = cell[0]
+  cell[0] = store
   try:
     yield store
   finally:
-    _STORE[0] = old
+    cell[0] = old
 
 
 def current_store():
-  if _STORE[0] is None:
+  store = _store_cell()[0]
+  if store is None:
     raise RuntimeError("No VariableStore is active (wrap the call in arch_ops.use_store(...)).")
-  return _STORE[0]
+  return store
 
 
 def variable_scope(name):
@@ -505,16 +514,25 @@ def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_forma
   inputs = _to_bf16(inputs)
   if is_training:
     moving = (stats[0], stats[1], decay) if use_moving_averages else None
-    if (_FUSED_BN and not torch.is_grad_enabled() and relu and sync_fn is None and
-        inputs.dim() == 4):
+    if _FUSED_BN and not torch.is_grad_enabled() and relu and inputs.dim() == 4:
       # no autograd graph: statistics now (from the producer convolution's partial sums when it
-      # emitted them), normalisation + ReLU inside the consumer convolution (PendingBN)
+      # emitted them), normalisation + ReLU inside the consumer convolution (PendingBN).  Under
+      # data parallelism the local moments cross the replicas before they are used, and the
+      # moving averages are updated from the global ones.
       mm, mv, dc = moving if moving is not None else (None, None, 0.0)
+      if sync_fn is not None:
+        mm_, mv_, dc_ = None, None, 0.0
+      else:
+        mm_, mv_, dc_ = mm, mv, dc
       if partials is not None:
-        mean, var = K.bn_finalize(partials[0], partials[1], mm, mv, dc)
+        mean, var = K.bn_finalize(partials[0], partials[1], mm_, mv_, dc_)
       else:
         n, c = inputs.shape[0], inputs.shape[-1]
-        mean, var = K.bn_stats(inputs.contiguous().reshape(n, -1, c), mm, mv, dc)
+        mean, var = K.bn_stats(inputs.contiguous().reshape(n, -1, c), mm_, mv_, dc_)
+      if sync_fn is not None:
+        mean, var = sync_fn.forward_sync(mean, var)
+        if mm is not None:
+          K.bn_update_moving(mm, mv, mean, var, dc)
       return PendingBN(inputs, mean, var, gamma, beta, epsilon, per_sample)
     out, _, _ = Fn.batch_norm_act(inputs, gamma, beta, None, None, epsilon, per_sample, relu,
                                   sync_fn, moving)

@@ -60,7 +60,7 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
   device = gan.device
   # the same latent variables for each evaluation: a dedicated counter-based stream, seed 42
   eval_step = torch.zeros((), dtype=torch.int64, device=device)
-  saved = (tpu_random._STATE["seed"], tpu_random._STATE["step"])  # pylint: disable=protected-access
+  saved = (tpu_random._st()["seed"], tpu_random._st()["step"])  # pylint: disable=protected-access
   tpu_random.set_random_offset(42, eval_step)
   counter = [0]
 

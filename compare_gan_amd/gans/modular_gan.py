@@ -12,6 +12,8 @@ Step semantics = the reference's *unrolled* graph (modular_gan.py:533-584, SURVE
 `disc_iters` discriminator sub-steps, each on a fresh sub-batch (real images, z, sampled labels)
 and a fresh G forward, followed by one generator sub-step on another fresh sub-batch.
 """
+import os
+
 import torch
 
 from compare_gan_amd import gin
@@ -60,6 +62,15 @@ random_normal = gin.external_configurable(_random_normal, name="normal", module=
 random_uniform = gin.external_configurable(_random_uniform, name="uniform", module="tf.random")
 
 
+# Where the bucket's all-reduce + update run: on a communication stream (overlapping the next
+# generator forward) for buckets of at least _DP_OVERLAP_MIN_BYTES, on the main stream below that
+# -- a forked branch costs two cross-stream dependencies per update (measured on a one-rank RCCL
+# group, resnet_cifar10: 6 forks add 0.6 ms to a 10.2 ms step), more than a 4 MiB all-reduce
+# takes.  CGAMD_DP_OVERLAP=1 / 0 forces it on / off.
+_DP_OVERLAP = os.environ.get("CGAMD_DP_OVERLAP", "auto")
+_DP_OVERLAP_MIN_BYTES = 32 << 20
+
+
 class _OptimizerState(object):
   """Adam slots (+ EMA shadows) for one network and the fused update."""
 
@@ -76,6 +87,8 @@ class _OptimizerState(object):
     self.reserved = []
     self.flat = None
     self.device = device
+    self._comm = None
+    self._inflight = None
 
   def _ensure(self, grads):
     if torch.cuda.is_current_stream_capturing():
@@ -100,8 +113,14 @@ class _OptimizerState(object):
     self.reserved = [torch.empty(nbytes, dtype=torch.uint8, device=self.device) for _ in range(n)]
 
   def apply_gradients(self, step, ema_decay=0.0, ema_start=0, grads=None):
-    """All-reduce (data parallel) + fused Adam(+EMA).  step: device int64 update counter.
-    grads: one tensor per variable (defaults to the variables' .grad fields)."""
+    """All-reduce (data parallel) + fused Adam(+EMA) + step += 1.  step: device int64 counter.
+    grads: one tensor per variable (defaults to the variables' .grad fields).
+
+    Data parallel: the network's gradients are gathered into ONE flat fp32 bucket (xGMI rings are
+    per-link bound: one large message per network beats many small ones), summed across replicas
+    and applied with scale 1/world -- all three on the communication stream, so that work which
+    does not read this network's weights (the next sub-step's generator forward after a D update)
+    overlaps with the collective; join() is the dependency edge for the next reader."""
     Fn.join_wgrad_stream()   # weight gradients may still be in flight on the side stream
     if grads is None:
       grads = [p.grad for p in self.params]
@@ -110,25 +129,53 @@ class _OptimizerState(object):
       if g is None:
         raise RuntimeError("variable %s received no gradient" % n)
       grads[i] = g.contiguous()
+    o = self.opt
+    ema = ema_decay if self.ema is not None else 0.0
+    if not tpu_ops.data_parallel():
+      self._ensure(grads).adam(o.learning_rate, o.beta1, o.beta2, o.epsilon, 1.0, step,
+                               ema_decay=ema, ema_start=ema_start)
+      K.counter_add(step, 1)
+      return
     world = tpu_ops.num_replicas()
-    scale = 1.0
-    if world > 1 or tpu_ops.force_data_parallel():
-      if self.flat is None:
-        self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32,
-                                device=self.device)
-        self.flat_views = []
-        off = 0
-        for g in grads:
-          self.flat_views.append(self.flat[off:off + g.numel()].view(g.shape))
-          off += g.numel()
+    if self.flat is None:
+      self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32,
+                              device=self.device)
+      self.flat_views = []
+      off = 0
+      for g in grads:
+        self.flat_views.append(self.flat[off:off + g.numel()].view(g.shape))
+        off += g.numel()
+    self.join()                  # the bucket of the previous update must have been consumed
+    main = torch.cuda.current_stream()
+    overlap = _DP_OVERLAP == "1" or (_DP_OVERLAP == "auto" and
+                                     self.flat.numel() * 4 >= _DP_OVERLAP_MIN_BYTES)
+    comm = self._comm_stream() if overlap else main
+    if comm is not main:
+      comm.wait_stream(main)
+    with torch.cuda.stream(comm):
       K.flatten_multi(grads, self.flat)          # one bucket per network
       tpu_ops.cross_replica_sum_(self.flat)      # CrossShardOptimizer: gradient mean
-      grads = self.flat_views
-      scale = 1.0 / world
-    table = self._ensure(grads)
-    o = self.opt
-    table.adam(o.learning_rate, o.beta1, o.beta2, o.epsilon, scale, step,
-                    ema_decay=ema_decay if self.ema is not None else 0.0, ema_start=ema_start)
+      self._ensure(self.flat_views).adam(o.learning_rate, o.beta1, o.beta2, o.epsilon,
+                                         1.0 / world, step, ema_decay=ema, ema_start=ema_start)
+      K.counter_add(step, 1)     # same stream as its reader (the update above)
+    if comm is not main:
+      # the gradient tensors were allocated on the main stream: keep them alive until the main
+      # stream has waited for the communication stream (join), or the allocator may hand their
+      # memory to a later main-stream kernel while the flatten still reads it
+      self._inflight = grads
+
+  def _comm_stream(self):
+    if self._comm is None:
+      self._comm = torch.cuda.Stream(device=self.device)
+    return self._comm
+
+  def join(self):
+    """Makes the current stream wait for an update in flight on the communication stream: called
+    before anything reads this network's variables (its forward pass, EMA readers, checkpoints)
+    and at the end of a step (a hipGraph capture has to rejoin every forked stream)."""
+    if self._inflight is not None:
+      torch.cuda.current_stream().wait_stream(self._comm)
+      self._inflight = None
 
 
 @gin.configurable(blacklist=["dataset", "parameters", "model_dir"])
@@ -311,6 +358,7 @@ class ModularGAN(AbstractGAN):
     else:
       y = sampled_y = all_y = None
     a, b = getattr(self.discriminator, "input_affine", (1.0, 0.0))
+    self.d_opt.join()    # a D update may still be in flight on the communication stream
     if self._deprecated_split_disc_calls:
       d_real, d_real_logits, _ = self.discriminator(
           Fn.stage_images(images, None, a, b), y=y, is_training=is_training)
@@ -353,7 +401,6 @@ class ModularGAN(AbstractGAN):
     grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
                                 allow_unused=True)
     self.d_opt.apply_gradients(self.global_step_disc, grads=self._fill_unused(self.d_opt, grads))
-    K.counter_add(self.global_step_disc, 1)
     self.d_loss = self.d_loss.detach()
     if self.penalty_loss is not None:
       self.penalty_loss = self.penalty_loss.detach()
@@ -370,6 +417,7 @@ class ModularGAN(AbstractGAN):
       sampled_y = None
       if self.conditional:
         sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+      self.g_opt.join()
       features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
     grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
@@ -377,7 +425,6 @@ class ModularGAN(AbstractGAN):
     self.g_opt.apply_gradients(self.global_step, ema_decay=self._ema_decay,
                                ema_start=self._ema_start_step,
                                grads=self._fill_unused(self.g_opt, grads))
-    K.counter_add(self.global_step, 1)
     self._set_requires_grad(self.d_opt, True)
     self.g_loss = self.g_loss.detach()
     self.d_loss = self.d_loss.detach()
@@ -430,7 +477,12 @@ class ModularGAN(AbstractGAN):
       for i in range(self._disc_iters):
         d_losses.append(self._disc_sub_step(fs[i], ls[i]))
       g_loss = self._train_generator(fs[-1], ls[-1])
+    self._join_updates()
     return {"d_losses": d_losses, "g_loss": g_loss}
+
+  def _join_updates(self):
+    self.d_opt.join()
+    self.g_opt.join()
 
   def _disc_sub_step(self, features, labels):
     """G forward (no gradient) on the sub-step's z + one D update (modular_gan.py:465-485)."""
@@ -438,6 +490,7 @@ class ModularGAN(AbstractGAN):
       sampled_y = None
       if self.conditional:
         sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+      self.g_opt.join()
       features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
     return self._train_discriminator(features, labels)
 
@@ -449,7 +502,9 @@ class ModularGAN(AbstractGAN):
       raise RuntimeError("call build() first")
     f, l = self._preprocess(images, labels, 0)
     with ops.use_store(self.store):
-      return {"d_loss": self._disc_sub_step(f, l)}
+      out = {"d_loss": self._disc_sub_step(f, l)}
+    self._join_updates()
+    return out
 
   # -- hipGraph capture of the whole step ---------------------------------------------------------------
   def capture_train_step(self, num_warmup=2):
@@ -464,13 +519,16 @@ class ModularGAN(AbstractGAN):
     return self._capture(self.disc_step, 1, 1, 0, num_warmup)
 
   def _capture(self, step, nsub, d_updates, g_updates, num_warmup):
-    import os
     # weight gradients become a parallel branch of the graph (CGAMD_NO_WGRAD_STREAM=1: A/B switch)
     Fn.enable_wgrad_stream(os.environ.get("CGAMD_WGRAD_STREAM", "") == "1")
     shape = (nsub * self.batch_size,) + tuple(self._dataset.image_shape)
     self._static_images = torch.zeros(shape, dtype=torch.float32, device=self.device)
     self._static_labels = torch.zeros((shape[0],), dtype=torch.int32, device=self.device)
 
+    # the warm-up steps run for real (on the zero-filled static inputs): everything they touch --
+    # variables, Adam slots, EMA shadows, step counters -- is put back afterwards, in place, so
+    # that capturing leaves the training state exactly as it found it
+    snapshot = self.state_dict()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -480,6 +538,14 @@ class ModularGAN(AbstractGAN):
     torch.cuda.synchronize()
     self.d_opt.reserve_tables(d_updates)
     self.g_opt.reserve_tables(g_updates)
+    if tpu_ops.data_parallel() and tpu_ops.thread_state() is None:
+      # The process group's watchdog thread polls the end events of the warm-up's eager
+      # collectives every 100 ms until it has seen them complete.  Once the captured collectives
+      # below pull RCCL's internal stream into the capture, such a query fails with
+      # hipErrorCapturedEvent and the watchdog aborts the process (seen about one run in three
+      # with a capture that reaches its first collective within 100 ms): let it drain first.
+      import time
+      time.sleep(0.5)
     self._graph = torch.cuda.CUDAGraph()
     graph_kwargs = {}
     if tpu_ops.num_replicas() > 1 or tpu_ops.force_data_parallel():
@@ -492,6 +558,9 @@ class ModularGAN(AbstractGAN):
     for opt in (self.g_opt, self.d_opt):
       for t in opt.captured_tables:
         t.flush()
+    self.load_state_dict(snapshot)
+    del snapshot
+    torch.cuda.synchronize()
 
     def run(images, labels):
       self._static_images.copy_(images, non_blocking=True)

@@ -77,7 +77,7 @@ class TaskManager(object):
     row.update(_parse_gin_config(os.path.join(
         self.model_dir, "operative_config-{}.gin".format(step))))
     row.update(result_dict)
-    path = os.path.join(self.model_dir, self._RESULTS_FILE)
+    path = self._score_path()
     rows = []
     if os.path.exists(path):
       with open(path) as f:
@@ -89,8 +89,11 @@ class TaskManager(object):
       w.writeheader()
       w.writerows(rows)
 
+  def _score_path(self):
+    return os.path.join(self.model_dir, self._RESULTS_FILE)
+
   def get_checkpoints_with_results(self):
-    path = os.path.join(self.model_dir, self._RESULTS_FILE)
+    path = self._score_path()
     if not os.path.exists(path):
       return set()
     with open(path) as f:
@@ -109,6 +112,18 @@ class TaskManager(object):
       if eval_every_steps and _step_of(path) % eval_every_steps:
         continue
       yield path
+
+
+class TaskManagerWithCsvResults(TaskManager):
+  """Task manager that writes results to a CSV file of the caller's choice
+  (runner_lib.py:186-232)."""
+
+  def __init__(self, model_dir, score_file=None):
+    super(TaskManagerWithCsvResults, self).__init__(model_dir)
+    self._score_file = score_file or os.path.join(model_dir, "scores.csv")
+
+  def _score_path(self):
+    return self._score_file
 
 
 def _step_of(checkpoint_path):
@@ -159,11 +174,16 @@ def _run_eval(gan, checkpoint_path, task_manager, options, num_averaging_runs, d
   eval_tasks = [inception_score_lib.InceptionScoreTask(), fid_score_lib.FIDScoreTask()]
   sd = torch.load(checkpoint_path, map_location=device)
   gan.load_state_dict(sd)
+  from compare_gan_amd.tpu import tpu_ops
+  in_context = tpu_ops._STATE["enabled"]  # pylint: disable=protected-access
+  tpu_ops.enable_cross_replica(False)     # evaluation runs on replica 0 alone: no collectives
   try:
     result_dict = eval_gan_lib.evaluate_gan(gan, eval_tasks, num_averaging_runs)
   except eval_utils.NanFoundError as nan_found_error:
     result_dict = {}
     print("NanFoundError:", nan_found_error)
+  finally:
+    tpu_ops.enable_cross_replica(in_context)
   default_value = eval_gan_lib.NAN_DETECTED
   task_manager.add_eval_result(checkpoint_path, result_dict, default_value)
   return result_dict
@@ -188,6 +208,7 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
   gan = options["gan_class"](dataset=dataset, parameters=options,
                              model_dir=run_config.model_dir)
   from compare_gan_amd.tpu import tpu_ops
+  tpu_ops.init_replicas(device)      # no-op unless launched with WORLD_SIZE > 1
   world = tpu_ops.num_replicas()
   if options["batch_size"] % world:
     raise ValueError("batch_size {} is not divisible by {} replicas".format(

@@ -14,6 +14,14 @@ from compare_gan_amd.tpu import tpu_ops
 _STATE = {"seed": 0, "step": None, "sub_step": 0}
 
 
+def _st():
+  """The module state; an in-process replica thread (tpu_ops.InProcessReplicas) has its own."""
+  ts = tpu_ops.thread_state()
+  if ts is None:
+    return _STATE
+  return ts.setdefault("tpu_random", {"seed": 0, "step": None, "sub_step": 0})
+
+
 def _op_id(name):
   """tpu_random.py:81-86: sha512(name) mod (2^31 - 1)."""
   return int(hashlib.sha512(name.encode("utf-8")).hexdigest(), 16) % (2 ** 31 - 1)
@@ -22,8 +30,8 @@ def _op_id(name):
 def set_random_offset(seed, step_tensor):
   """The analogue of set_random_offset_from_features (tpu_random.py:54-78): binds the step counter
   (device int64 tensor) and the run seed used by subsequent calls."""
-  _STATE["seed"] = int(seed)
-  _STATE["step"] = step_tensor
+  _st()["seed"] = int(seed)
+  _st()["step"] = step_tensor
 
 
 def set_sub_step(index):
@@ -31,26 +39,29 @@ def set_sub_step(index):
   per-sub-step name of their own (the penalties' draws) append it, so that every sub-step has its
   own op id -- the reference's unrolled graph holds one random op per sub-step
   (modular_gan.py:568-584 + tpu_random.py:81-86)."""
-  _STATE["sub_step"] = int(index)
+  _st()["sub_step"] = int(index)
 
 
 def sub_step():
-  return _STATE["sub_step"]
+  return _st()["sub_step"]
 
 
 def uniform(shape, name, minval=0.0, maxval=1.0, device=None):
-  step = _STATE["step"]
-  return K.random(0, minval, maxval, _STATE["seed"], _op_id(name), tpu_ops.replica_id(), step,
+  st = _st()
+  step = st["step"]
+  return K.random(0, minval, maxval, st["seed"], _op_id(name), tpu_ops.random_stream_id(), step,
                   tuple(shape), device if device is not None else step.device)
 
 
 def normal(shape, name, mean=0.0, stddev=1.0, device=None):
-  step = _STATE["step"]
-  return K.random(1, mean, stddev, _STATE["seed"], _op_id(name), tpu_ops.replica_id(), step,
+  st = _st()
+  step = st["step"]
+  return K.random(1, mean, stddev, st["seed"], _op_id(name), tpu_ops.random_stream_id(), step,
                   tuple(shape), device if device is not None else step.device)
 
 
 def labels(n, num_classes, name, device=None):
-  step = _STATE["step"]
-  return K.random_labels(num_classes, _STATE["seed"], _op_id(name), tpu_ops.replica_id(), step, n,
+  st = _st()
+  step = st["step"]
+  return K.random_labels(num_classes, st["seed"], _op_id(name), tpu_ops.random_stream_id(), step, n,
                          device if device is not None else step.device)

@@ -1,0 +1,101 @@
+"""Worker of test_data_parallel_gpu.test_force_dp_one_rank_group_matches_single_replica.
+
+In one process: (1) a resnet_cifar10 GAN, batch 8, two hipGraph-replayed steps without data
+parallelism; (2) CGAMD_FORCE_DP=1 + tpu_ops.init_replicas (one-rank RCCL group): the same model
+again -- per-replica batch norm: every variable bit-identical to (1); cross-replica batch norm
+(SyncMoments: var -> E[x^2] -> all-reduce -> var, the default under data parallelism): the weight
+UPDATES agree with (1) to cosine >= 0.999 (the moment conversion re-rounds the variance, and
+Adam's normalised first steps amplify last-bit differences of tiny gradients).
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tests import gan_util as U  # noqa: E402
+
+
+def run(dev, bindings, steps=2, bs=8, capture=True):
+    gan, options, dataset = U.build_product("resnet_cifar10.gin", bs, dev, seed=3,
+                                            bindings=bindings)
+    init = {k: v.detach().clone() for k, v in gan.store.vars.items()}
+    nsub = options["disc_iters"] + 1
+    it = dataset.train_batches(bs * nsub, seed=11)
+    step = gan.capture_train_step() if capture else gan.train_step
+    for _ in range(steps):
+        images, labels = next(it)
+        step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+    torch.cuda.synchronize()
+    return init, {k: v.detach().clone() for k, v in gan.store.vars.items()}, gan
+
+
+def stage(msg):
+    sys.stdout.write("STAGE " + msg + "\n")
+    sys.stdout.flush()
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "local"
+    from compare_gan_amd.tpu import tpu_ops
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    local_bn = ("standardize_batch.use_cross_replica_mean = False",)
+    assert not tpu_ops.data_parallel()
+    # mode sync: the single-replica baseline steps eagerly -- a hipGraph capture with
+    # autograd-thread collectives (cross-replica batch norm backward) AFTER an earlier capture in
+    # the same process made the group's watchdog thread query a captured event
+    # (hipErrorCapturedEvent, torch 2.10 / RCCL 2.26); launchers capture once, group up first
+    init, base, gan = run(dev, local_bn, capture=(mode == "local"))
+    stage("single replica done")
+    assert gan.d_opt.flat is None          # no bucket without data parallelism
+    del gan
+
+    os.environ["CGAMD_FORCE_DP"] = "1"
+    rank, world = tpu_ops.init_replicas(dev)
+    assert (rank, world) == (0, 1) and tpu_ops.data_parallel() and tpu_ops.in_replica_context()
+    stage("one-rank group up")
+    worst = 1.0
+    if mode == "local":
+        _, forced, gan = run(dev, local_bn)
+        stage("one-rank data parallel, per-replica batch norm done")
+        assert gan.d_opt.flat is not None and gan.g_opt.flat is not None   # the bucket path ran
+        bad = [k for k in base if not torch.equal(base[k], forced[k])]
+        assert not bad, "one-rank data parallel differs from single replica: %s" % bad[:5]
+        del gan
+    if mode == "sync":
+        # default bindings: cross-replica batch norm through SyncMoments on the one-rank group
+        _, synced, gan = run(dev, ())
+        stage("one-rank data parallel, cross-replica batch norm done")
+        # cosine of the two-step weight updates: per variable for everything whose gradient is
+        # not numerically zero (a bias feeding a batch norm has a zero gradient, Adam turns its
+        # rounding noise into full-size steps), and over all variables together
+        num = den_u = den_v = 0.0
+        low = []
+        for k in gan.store.trainable:
+            du = (base[k] - init[k]).double().flatten()
+            dv = (synced[k] - init[k]).double().flatten()
+            num += float(torch.dot(du, dv))
+            den_u += float(du.norm() ** 2)
+            den_v += float(dv.norm() ** 2)
+            if float(du.norm()) == 0.0:
+                continue
+            cos = float(torch.dot(du, dv) / (du.norm() * dv.norm()))
+            if cos < 0.99:
+                low.append((k, round(cos, 4)))
+        worst = num / (den_u * den_v) ** 0.5
+        stage("low-cosine variables: %s" % (low,))
+        assert worst >= 0.995, (worst, low)
+        assert all("bias" in k or "beta" in k for k, _ in low), low
+    import torch.distributed as dist
+    dist.barrier()
+    torch.cuda.synchronize()
+    print("DP_FORCE_OK worst update cosine %.6f" % worst)
+    sys.stdout.flush()
+    os._exit(0)   # skip RCCL / graph destructors (same reason as bench.py)
+
+
+if __name__ == "__main__":
+    main()

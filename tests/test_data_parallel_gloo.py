@@ -199,3 +199,97 @@ def test_gradient_mean_equals_global_batch_world2():
 
 def test_per_replica_streams_world2():
   _run("_body_per_replica_streams")
+
+
+def _body_launcher_init(rank):
+  """What bench.py / runner_lib / compare_gan_amd.main call per process: the group is already
+  up here (init_replicas must not re-initialise it), cross-replica batch norm is switched on."""
+  from compare_gan_amd.tpu import tpu_ops
+  os.environ["WORLD_SIZE"] = str(WORLD)
+  os.environ["RANK"] = str(rank)
+  tpu_ops.enable_cross_replica(False)
+  assert not tpu_ops.in_replica_context()
+  assert tpu_ops.init_replicas(None) == (rank, WORLD)
+  assert tpu_ops.data_parallel() and tpu_ops.in_replica_context()
+  assert tpu_ops.random_stream_id() == rank
+  tpu_ops.enable_cross_replica(False)
+
+
+def test_launcher_init_world2():
+  _run("_body_launcher_init")
+
+
+def test_init_replicas_single_process_is_a_no_op():
+  from compare_gan_amd.tpu import tpu_ops
+  env = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "CGAMD_FORCE_DP")}
+  try:
+    assert tpu_ops.init_replicas(None) == (0, 1)
+    assert not dist.is_initialized() and not tpu_ops.data_parallel()
+    assert not tpu_ops.in_replica_context()
+  finally:
+    for k, v in env.items():
+      if v is not None:
+        os.environ[k] = v
+
+
+def test_in_process_replicas_all_reduce():
+  """tpu_ops.InProcessReplicas (the single-GPU stand-in for two RCCL ranks, used by
+  tests/test_data_parallel_gpu.py): baton order, rank-ordered sums, several collectives per
+  thread, per-thread state, and error propagation."""
+  import threading
+  from compare_gan_amd.tpu import tpu_ops
+  world = 3
+  replicas = tpu_ops.InProcessReplicas(world)
+  out, errs, running = {}, [], []
+
+  def body(rank):
+    try:
+      replicas.attach(rank)
+      assert tpu_ops.num_replicas() == world and tpu_ops.replica_id() == rank
+      assert tpu_ops.data_parallel() and tpu_ops.random_stream_id() == rank
+      tpu_ops.thread_state()["mine"] = rank
+      vals = []
+      for k in range(4):
+        running.append(rank)
+        t = torch.full((5,), float((rank + 1) * 10 ** k), dtype=torch.float64)
+        res, n = tpu_ops.cross_replica_sum_(t)
+        assert n == world and tpu_ops.thread_state()["mine"] == rank
+        vals.append(float(res[0]))
+      out[rank] = vals
+      replicas.finish(rank)
+    except BaseException:  # pylint: disable=broad-except
+      errs.append(traceback.format_exc())
+      replicas.finish(rank, error="rank %d" % rank)
+
+  threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(60)
+  assert not errs, "\n".join(errs)
+  for r in range(world):
+    assert out[r] == [6.0 * 10 ** k for k in range(4)]
+  assert tpu_ops.num_replicas() == 1 and tpu_ops.thread_state() is None
+
+  # a failing replica releases the others instead of leaving them waiting for the baton
+  replicas = tpu_ops.InProcessReplicas(2)
+  seen = []
+
+  def failing(rank):
+    try:
+      replicas.attach(rank)
+      if rank == 1:
+        raise ValueError("boom")
+      tpu_ops.cross_replica_sum_(torch.zeros(2))
+      replicas.finish(rank)
+    except BaseException as e:  # pylint: disable=broad-except
+      seen.append(type(e).__name__)
+      replicas.finish(rank, error=repr(e))
+
+  threads = [threading.Thread(target=failing, args=(r,)) for r in range(2)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(60)
+  assert not any(t.is_alive() for t in threads)
+  assert sorted(seen) == ["RuntimeError", "ValueError"]

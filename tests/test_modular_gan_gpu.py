@@ -458,3 +458,34 @@ def test_penalties_against_oracle(dev, config, bsz, penalty):
             penalty, name, c, r)
         checked += 1
     assert checked >= 4
+
+
+@pytest.mark.parametrize("config,bsz", [("resnet_cifar10.gin", 8), ("biggan_imagenet128.gin", 2)])
+def test_captured_step_matches_eager(dev, config, bsz):
+    """capture_train_step(): (1) capturing -- warm-up steps included -- leaves every variable,
+    optimizer slot and step counter as it found them; (2) replaying the hipGraph is the eager
+    step bit for bit (same kernels in the same order, nothing atomic), also for the EMA shadows
+    and the spectral-norm vectors."""
+    bindings = ("options.batch_size = %d" % bsz,)
+    if config.startswith("biggan"):
+        bindings += ("resnet_biggan.Generator.ch = 32", "resnet_biggan.Discriminator.ch = 32")
+    eager, options, dataset = U.build_product(config, bsz, dev, seed=5, bindings=bindings)
+    graph, _, _ = U.build_product(config, bsz, dev, seed=5, bindings=bindings)
+    nsub = options["disc_iters"] + 1
+    it = dataset.train_batches(bsz * nsub, seed=21)
+    batches = [next(it) for _ in range(2)]
+    before = graph.state_dict()
+    run = graph.capture_train_step()
+    after = graph.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), "capture changed %s" % k
+    for images, labels in batches:
+        x, y = torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev)
+        oe = eager.train_step(x, y)
+        og = run(x, y)
+        assert torch.equal(oe["g_loss"], og["g_loss"])
+    torch.cuda.synchronize()
+    se, sg = eager.state_dict(), graph.state_dict()
+    assert int(sg["global_step"]) == 2
+    bad = [k for k in se if not torch.equal(se[k], sg[k])]
+    assert not bad, bad[:8]
