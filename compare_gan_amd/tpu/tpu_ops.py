@@ -166,6 +166,7 @@ def init_replicas(device=None, backend=None):
       os.environ.setdefault("MASTER_PORT", "29517")
       os.environ.setdefault("RANK", "0")
       os.environ.setdefault("WORLD_SIZE", "1")
+      backend = backend or os.environ.get("CGAMD_DIST_BACKEND") or None
       if backend is None:
         backend = "nccl" if device is not None and torch.device(device).type == "cuda" else "gloo"
       kwargs = {}
@@ -206,6 +207,13 @@ def cross_replica_sum_(tensor, group_size=None):
     local[0].all_reduce_sum_(local[1], tensor)
     return tensor, local[0].world
   group, n = _group(group_size)
+  if tensor.is_cuda and dist.get_backend(group) == "gloo":
+    # debugging backend (CGAMD_DIST_BACKEND=gloo): replicas that cannot form an RCCL group --
+    # e.g. two processes sharing one GPU in tests/test_data_parallel_gpu.py -- sum through the host
+    host = tensor.detach().cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    tensor.copy_(host)
+    return tensor, n
   dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
   return tensor, n
 

@@ -12,6 +12,10 @@ Two RCCL ranks cannot share a device, so the N > 1 arithmetic is exercised two w
     all-reduce -- identical inputs must reproduce the single-replica weights bit for bit
     ((g + g) / 2 == g), different shards must leave both replicas with identical weights that
     differ from a single replica's.
+  * two PROCESSES sharing the GPU, summing through the host (`gloo`, CGAMD_DIST_BACKEND): the
+    complete product path including cross-replica batch norm forward and backward, checked
+    against ONE replica training on the concatenated global batch with the concatenated random
+    draws (tests/dp_two_process_worker.py).
 The world_size-2 `gloo` tests of the host logic are in test_data_parallel_gloo.py."""
 import os
 import subprocess
@@ -121,3 +125,113 @@ def test_two_in_process_replicas(dev, config, bs):
         moved += int(not torch.equal(diff[0][name], single[name]))
     assert moved >= len(gan0.store.trainable) // 2
     assert tpu_ops.num_replicas() == 1 and tpu_ops.thread_state() is None
+
+
+def test_two_processes_match_one_replica_on_the_global_batch(dev, tmp_path):
+    """modular_gan.py:606-616 + arch_ops.py:258-263: two replicas with batch B each, gradient mean
+    and cross-replica batch norm, ARE one replica with batch 2B -- provided that replica sees the
+    concatenation of the shards and of the replicas' random draws (tpu_random.py: every replica
+    has its own stream).  Tolerance: the reductions run in a different order (per-replica partial
+    sums) and bf16 activations re-round; Adam runs with epsilon = 1 (see the worker) so that the
+    update is linear in the gradient: cosine of the two-step update over all variables >= 0.999
+    and norm ratio within 0.5 % (a missing 1/world would show here); per variable the distance
+    from the reference may not exceed 3x the distance between two reference runs that only
+    differ in the order of the shards (+ 2e-3); the replicas themselves agree bit for bit."""
+    import socket
+    from compare_gan_amd.tpu import tpu_ops, tpu_random
+    from tests import dp_two_process_worker as W
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out_path = str(tmp_path / "vars.pt")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_two_process_worker.py"),
+                               str(r), str(world), port, out_path], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+
+    # meanwhile: the single replica on the global batch, its random draws the concatenation of
+    # the two replicas' streams -- twice, with the shards in either order: the difference between
+    # those two runs (same mathematics, other summation order) is the rounding-noise floor the
+    # data-parallel result is held against
+    stream = [0]
+    saved = (tpu_ops.random_stream_id, tpu_random.uniform, tpu_random.normal, tpu_random.labels)
+
+    def run_reference(order):
+        gan, options, dataset = U.build_product(W.CONFIG, world * W.BS, dev, seed=W.SEED,
+                                                bindings=W.BINDINGS)
+        init = {k: v.detach().cpu().clone() for k, v in gan.store.vars.items()}
+        nsub = options["disc_iters"] + 1
+
+        def halves(fn):
+            def draw(shape, name, *a, **kw):
+                parts = []
+                for r in order:
+                    stream[0] = r
+                    parts.append(fn((shape[0] // world,) + tuple(shape[1:]), name, *a, **kw))
+                return torch.cat(parts, dim=0)
+            return draw
+
+        def labels(n, num_classes, name, device=None):
+            parts = []
+            for r in order:
+                stream[0] = r
+                parts.append(saved[3](n // world, num_classes, name, device=device))
+            return torch.cat(parts, dim=0)
+
+        try:
+            tpu_ops.random_stream_id = lambda: stream[0]
+            tpu_random.uniform, tpu_random.normal = halves(saved[1]), halves(saved[2])
+            tpu_random.labels = labels
+            for per_rank in W.global_batches(dataset, world, nsub):
+                imgs, labs = [], []
+                for i in range(nsub):       # sub-step i of the global batch = the shards' sub-step i
+                    for r in order:
+                        imgs.append(per_rank[r][0][i * W.BS:(i + 1) * W.BS])
+                        labs.append(per_rank[r][1][i * W.BS:(i + 1) * W.BS])
+                gan.train_step(torch.from_numpy(np.concatenate(imgs)).to(dev),
+                               torch.from_numpy(np.concatenate(labs)).to(dev))
+            torch.cuda.synchronize()
+        finally:
+            (tpu_ops.random_stream_id, tpu_random.uniform, tpu_random.normal,
+             tpu_random.labels) = saved
+        final = {k: v.detach().cpu().clone() for k, v in gan.store.vars.items()}
+        return init, final, list(gan.store.trainable)
+
+    init, ref_a, trainable = run_reference((0, 1))
+    _, ref_b, _ = run_reference((1, 0))
+    outs = [p.communicate(timeout=600)[0].decode("utf-8", "replace") for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and "DP_WORKER_OK" in outs[r], outs[r][-3000:]
+    reps = [torch.load("%s.%d" % (out_path, r)) for r in range(world)]
+    for name in trainable:
+        assert torch.equal(reps[0][name], reps[1][name]), name
+
+    def compare(other):
+        """Update cosine / norm ratio against ref_a: {name: (cos, ratio)} and the global pair."""
+        per, num, den_a, den_b = {}, 0.0, 0.0, 0.0
+        for name in trainable:
+            da = (ref_a[name] - init[name]).double().flatten()
+            db = (other[name] - init[name]).double().flatten()
+            num += float(torch.dot(da, db))
+            den_a += float(da.norm() ** 2)
+            den_b += float(db.norm() ** 2)
+            if float(da.norm()) > 0 and float(db.norm()) > 0:
+                per[name] = (float(torch.dot(da, db) / (da.norm() * db.norm())),
+                             float(db.norm() / da.norm()))
+        return per, num / (den_a * den_b) ** 0.5, (den_b / den_a) ** 0.5
+
+    noise, noise_cos, _ = compare(ref_b)
+    dp, dp_cos, dp_ratio = compare(reps[0])
+    worse = []
+    for name, (cos, ratio) in dp.items():
+        floor = 1.0 - noise[name][0]
+        if (1.0 - cos) > 3.0 * floor + 2e-3 or abs(ratio - 1.0) > 3.0 * abs(noise[name][1] - 1.0) + 0.02:
+            worse.append((name, round(cos, 4), round(noise[name][0], 4), round(ratio, 4)))
+    print("two-process data parallel vs global batch: update cosine %.5f (shard-order noise %.5f), "
+          "norm ratio %.5f, beyond noise: %s" % (dp_cos, noise_cos, dp_ratio, worse))
+    assert dp_cos >= 0.999 and abs(dp_ratio - 1.0) <= 0.005, (dp_cos, dp_ratio)
+    assert not worse, worse
