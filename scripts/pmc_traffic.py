@@ -11,6 +11,11 @@ import collections, csv, glob, json, os, re, sys
 
 FAMILIES = [
     (r"halo_conv_kernel", "halo_conv_kernel<*>"),
+    (r"hconv_kernel<128", "hconv_kernel<128, *>"),
+    (r"hconv(_rw)?_kernel", "hconv_kernel<64, *>"),
+    (r"hwgrad_kernel", "hwgrad_kernel<*>"),
+    (r"wstem_fwd_kernel", "stem_fwd_kernel<*>"),
+    (r"wstem_wgrad_kernel", "stem_wgrad_kernel<*>"),
     (r"fast_conv(_sk)?_kernel<128, 128", "fast_conv_kernel<128, 128, *>"),
     (r"fast_conv(_sk)?_kernel<64, 128", "fast_conv_kernel<64, 128, *>"),
     (r"fast_conv(_sk)?_kernel<128, 64", "fast_conv_kernel<128, 64, *>"),
