@@ -85,10 +85,10 @@ def cpu_baseline(config, batch, budget_s=20.0):
 
 
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r01_pmc_traffic.json")
+                                "r02_pmc_traffic.json")
 PMC_TRAFFIC_NOTE = ("HBM bytes per launch of this kernel family = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                     "from two rocprofv3 --pmc passes of this workload (scripts/pmc_traffic.py -> "
-                    "profiles/r01_pmc_traffic.json); null when that summary is absent")
+                    "profiles/r02_pmc_traffic.json); null when that summary is absent")
 
 
 def pmc_traffic(family):

@@ -48,12 +48,16 @@ def test_pmc_traffic_summary(tmp_path):
     assert conv["hbm_bytes_per_launch"] == int((2 * 200.0 + 20.0) * 1024)
     assert fam["bn_apply_vec_kernel"]["hbm_bytes_per_launch"] == int((2 * 50.0 + 50.0) * 1024)
     assert pt.family("void (anonymous namespace)::halo_wgrad_kernel<true, false>(x)") == "halo_wgrad_kernel<*>"
+    assert pt.family("void (anonymous namespace)::hconv_kernel<128, false, 5, 1>(x)") == "hconv_kernel<128, *>"
+    assert pt.family("void (anonymous namespace)::hconv_rw_kernel<true>(x)") == "hconv_kernel<64, *>"
+    assert pt.family("void (anonymous namespace)::hwgrad_kernel<true, 5>(x)") == "hwgrad_kernel<*>"
+    assert pt.family("void (anonymous namespace)::wstem_fwd_kernel<4, 5>(x)") == "stem_fwd_kernel<*>"
 
 
 def test_bench_reads_the_committed_traffic_summary():
     bench = _load(os.path.join(ROOT, "bench.py"), "bench_module")
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-    for family in ("fast_conv_kernel<64, 128, *>", "fast_conv_kernel<128, 128, *>",
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+    for family in ("fast_conv_kernel<64, 128, *>", "hconv_kernel<128, *>", "hwgrad_kernel<*>",
                    "halo_wgrad_kernel<*>"):
         assert bench.pmc_traffic(family) == summary["families"][family]["hbm_bytes_per_launch"] > 0
     assert bench.pmc_traffic("no_such_kernel") is None
