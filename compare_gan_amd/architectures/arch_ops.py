@@ -239,6 +239,28 @@ class PendingBN(object):
 # set by AbstractGenerator.__call__: convolutions of a no-gradient training-mode forward pass emit
 # the partial sums of their output for the batch norm that follows (cg_gconv_fused)
 _EMIT_BN_STATS = [False]
+# > 1 inside statistics_groups(): the batch of the current no-gradient forward pass is `groups`
+# consecutive sub-batches that stand for separate network calls, each with its own batch statistics
+_BN_GROUPS = [1]
+
+
+class statistics_groups(object):
+  """Context for ONE batched generator call that replaces `groups` calls on the same weights (the
+  generator forwards of the discriminator sub-steps, modular_gan.py:464-467): every batch norm
+  computes its training statistics per group of consecutive samples -- the arithmetic of the
+  separate calls -- and updates the moving averages once per group, in order."""
+
+  def __init__(self, groups):
+    self.groups = int(groups)
+
+  def __enter__(self):
+    self._old = _BN_GROUPS[0]
+    _BN_GROUPS[0] = self.groups
+
+  def __exit__(self, *exc):
+    _BN_GROUPS[0] = self._old
+
+
 import os as _os
 _FUSED_BN = _os.environ.get("CGAMD_FUSED_BN", "1") != "0"   # A/B switch (read once)
 _FUSED_POOL = _os.environ.get("CGAMD_FUSED_POOL", "1") != "0"
@@ -366,7 +388,8 @@ def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f3
         bn=None if pending_bn is None else pending_bn.bn_tuple(),
         want_stats=_EMIT_BN_STATS[0] and not out_f32)
     if partials is not None:
-      out._cg_bn_partials = (partials, spec_geom.N * spec_geom.Ho * spec_geom.Wo)   # pylint: disable=protected-access
+      out._cg_bn_partials = (partials, spec_geom.N * spec_geom.Ho * spec_geom.Wo,   # pylint: disable=protected-access
+                             spec_geom.U * spec_geom.U)
     return out
   if pending_bn is not None:
     x = pending_bn.materialize()
@@ -514,6 +537,9 @@ def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_forma
   inputs = _to_bf16(inputs)
   if is_training:
     moving = (stats[0], stats[1], decay) if use_moving_averages else None
+    if _BN_GROUPS[0] > 1:
+      return _standardize_groups(inputs, partials, _BN_GROUPS[0], moving, sync_fn, gamma, beta,
+                                 epsilon, per_sample, relu)
     if _FUSED_BN and not torch.is_grad_enabled() and relu and inputs.dim() == 4:
       # no autograd graph: statistics now (from the producer convolution's partial sums when it
       # emitted them), normalisation + ReLU inside the consumer convolution (PendingBN).  Under
@@ -551,6 +577,36 @@ def standardize_batch(inputs, is_training, decay=0.999, epsilon=1e-3, data_forma
   out, _, _ = Fn.batch_norm_act(inputs, gamma, beta, mean.contiguous(), var.contiguous(), epsilon,
                                 per_sample, relu, None)
   return out
+
+
+def _standardize_groups(inputs, partials, groups, moving, sync_fn, gamma, beta, epsilon,
+                        per_sample, relu):
+  """Training-mode standardize_batch of a batched no-gradient call (statistics_groups): moments
+  [groups, C], one set per group of consecutive samples."""
+  if torch.is_grad_enabled():
+    raise RuntimeError("statistics groups exist for no-gradient forward passes only")
+  n, c = inputs.shape[0], inputs.shape[-1]
+  if n % groups:
+    raise ValueError("batch of %d does not split into %d statistics groups" % (n, groups))
+  mm, mv, dc = moving if moving is not None else (None, None, 0.0)
+  local = sync_fn is None
+  if partials is not None:
+    mean, var = K.bn_finalize(partials[0], partials[1], mm if local else None,
+                              mv if local else None, dc, groups=groups, phases=partials[2])
+  else:
+    mean, var = K.bn_stats(inputs.contiguous().reshape(n, -1, c), mm if local else None,
+                           mv if local else None, dc, groups=groups)
+  if sync_fn is not None:
+    gm, gv = sync_fn.forward_sync(mean.reshape(-1), var.reshape(-1))
+    mean, var = gm.reshape(groups, c), gv.reshape(groups, c)
+    if mm is not None:
+      for g in range(groups):      # one moving-average update per call the group stands for
+        K.bn_update_moving(mm, mv, mean[g], var[g], dc)
+  if _FUSED_BN and relu and inputs.dim() == 4:
+    return PendingBN(inputs, mean, var, gamma, beta, epsilon, per_sample)
+  y3 = K.bn_apply(inputs.contiguous().reshape(n, -1, c), mean, var, epsilon, gamma, beta,
+                  per_sample, relu)
+  return y3.reshape(inputs.shape)
 
 
 @gin.configurable(blacklist=["inputs"])

@@ -13,16 +13,20 @@ union V8 {
 
 // ---- statistics ------------------------------------------------------------------------------
 // grid (ceil(CV/32), splits); thread (cg = tid%32, rl = tid/32) accumulates rows rl, rl+8, ...
+// Statistics groups (cg_bn_stats_groups): the rows form `groups` consecutive blocks of group_rows
+// rows with independent statistics; every group is cut into spg splits (groups = 1: spg = splits,
+// group_rows = rows).
 __global__ __launch_bounds__(256) void bn_stats_part_kernel(const bf16_t* __restrict__ x,
-                                                            int64_t rows, int C,
+                                                            int64_t group_rows, int spg, int C,
                                                             int64_t rows_per_split,
                                                             float* __restrict__ part) {
   __shared__ float sm[8][32][17];
   const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int cv = blockIdx.x * 32 + cg;
   const int CV = C / 8;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
-  const int64_t r1 = min(rows, r0 + rows_per_split);
+  const int grp = blockIdx.y / spg, sl = blockIdx.y - grp * spg;
+  const int64_t r0 = grp * group_rows + (int64_t)sl * rows_per_split;
+  const int64_t r1 = min((grp + 1) * group_rows, r0 + rows_per_split);
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
@@ -61,14 +65,15 @@ __global__ __launch_bounds__(256) void bn_stats_part_kernel(const bf16_t* __rest
 }
 // scalar fallback (C % 8 != 0): grid (ceil(C/64), splits), 4 waves split rows.
 __global__ __launch_bounds__(256) void bn_stats_part_scalar_kernel(const bf16_t* __restrict__ x,
-                                                                   int64_t rows, int C,
-                                                                   int64_t rows_per_split,
+                                                                   int64_t group_rows, int spg,
+                                                                   int C, int64_t rows_per_split,
                                                                    float* __restrict__ part) {
   __shared__ float sm[2][4][64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + l;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
-  const int64_t r1 = min(rows, r0 + rows_per_split);
+  const int grp = blockIdx.y / spg, sl = blockIdx.y - grp * spg;
+  const int64_t r0 = grp * group_rows + (int64_t)sl * rows_per_split;
+  const int64_t r1 = min((grp + 1) * group_rows, r0 + rows_per_split);
   float s = 0.f, q = 0.f;
   if (c < C)
     for (int64_t r = r0 + w; r < r1; r += 4) {
@@ -126,6 +131,53 @@ __global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_kernel(const float*
     }
   }
 }
+// The same finalisation for `groups` independent statistics groups: partial row (ph, t) = ph * T + t
+// with T = rows / phases rows per phase (the U*U output phases of an up-sampling producer conv,
+// cg_gconv_fused stats_out) and group g owning t in [g * T / groups, (g + 1) * T / groups).
+// mean / var are [groups][C].  The moving averages take the groups' updates in order, as the
+// separate network calls they stand for would have applied them (arch_ops.py:105-114).
+__global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_groups_kernel(
+    const float* __restrict__ part, int rows, int C, int groups, int phases, float inv_count,
+    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ mm,
+    float* __restrict__ mv, float decay) {
+  __shared__ float sm[2][BN_ZL][33];
+  const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int T = rows / phases, tg = T / groups, per_group = tg * phases;
+  float mmc = 0.f, mvc = 0.f;
+  if (mm && zl == 0 && c < C) { mmc = mm[c]; mvc = mv[c]; }
+  for (int g = 0; g < groups; ++g) {
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+#pragma unroll 4
+      for (int z = zl; z < per_group; z += BN_ZL) {
+        const int ph = z / tg, t = z - ph * tg;
+        const int64_t row = (int64_t)ph * T + g * tg + t;
+        s += part[row * 2 * C + c];
+        q += part[row * 2 * C + C + c];
+      }
+    }
+    __syncthreads();
+    sm[0][zl][cl] = s;
+    sm[1][zl][cl] = q;
+    __syncthreads();
+    if (zl == 0 && c < C) {
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int r = 0; r < BN_ZL; ++r) {
+        ss += sm[0][r][cl];
+        qq += sm[1][r][cl];
+      }
+      const float m = ss * inv_count;
+      const float v = qq * inv_count - m * m;
+      mean[(int64_t)g * C + c] = m;
+      var[(int64_t)g * C + c] = v;
+      mmc -= (1.f - decay) * (mmc - m);
+      mvc -= (1.f - decay) * (mvc - v);
+    }
+  }
+  if (mm && zl == 0 && c < C) { mm[c] = mmc; mv[c] = mvc; }
+}
 inline int stats_splits(int64_t rows, int C) {
   const int ct = (C % 8 == 0) ? cdiv(C / 8, 32) : cdiv(C, 64);
   int s = cdiv(1024, ct);
@@ -142,19 +194,22 @@ inline int stats_splits(int64_t rows, int C) {
 __global__ __launch_bounds__(256) void bn_apply_vec_kernel(
     const bf16_t* __restrict__ x, int HW, int C, int hw_per_chunk, const float* __restrict__ mean,
     const float* __restrict__ var, float eps, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int per_sample, int relu, bf16_t* __restrict__ y) {
+    const float* __restrict__ beta, int per_sample, int stat_group, int relu,
+    bf16_t* __restrict__ y) {
   const int cv = blockIdx.x * 32 + (threadIdx.x & 31);
   if (cv * 8 >= C) return;
   const int rl = threadIdx.x >> 5;
   const int n = blockIdx.z;
   const int c0 = cv * 8;
+  // stat_group > 0: mean / var are [N / stat_group][C], one set per stat_group consecutive samples
+  const int64_t sb = stat_group > 0 ? (int64_t)(n / stat_group) * C : 0;
   // the reference's operation order (x - mean) * rstd [* gamma] [+ beta] is kept: folding it into
   // one multiply-add cancels catastrophically where x ~ mean (tiny batches, arch_ops.py:306-312)
   float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    mu[e] = mean[c0 + e];
-    rs[e] = rsqrtf(var[c0 + e] + eps);
+    mu[e] = mean[sb + c0 + e];
+    rs[e] = rsqrtf(var[sb + c0 + e] + eps);
     const int64_t pidx = per_sample ? (int64_t)n * C + c0 + e : c0 + e;
     gm[e] = gamma ? gamma[pidx] : 1.f;
     bt[e] = beta ? beta[pidx] : 0.f;
@@ -180,15 +235,16 @@ __global__ void bn_apply_scalar_kernel(const bf16_t* __restrict__ x, int HW, int
                                        int64_t total, const float* __restrict__ mean,
                                        const float* __restrict__ var, float eps,
                                        const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, int per_sample, int relu,
-                                       bf16_t* __restrict__ y) {
+                                       const float* __restrict__ beta, int per_sample,
+                                       int stat_group, int relu, bf16_t* __restrict__ y) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int c = (int)(i % C);
     const int64_t n = i / ((int64_t)HW * C);
     const int64_t pidx = per_sample ? n * C + c : c;
-    const float rstd = rsqrtf(var[c] + eps);
-    float t = (bf2f(x[i]) - mean[c]) * rstd;
+    const int64_t sidx = stat_group > 0 ? (n / stat_group) * C + c : c;
+    const float rstd = rsqrtf(var[sidx] + eps);
+    float t = (bf2f(x[i]) - mean[sidx]) * rstd;
     if (gamma) t *= gamma[pidx];
     if (beta) t += beta[pidx];
     if (relu) t = fmaxf(t, 0.f);
@@ -470,16 +526,69 @@ extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, floa
   hipStream_t st = (hipStream_t)stream;
   if (C % 8 == 0) {
     dim3 grid(cdiv(C / 8, 32), splits);
-    bn_stats_part_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, C, rps, (float*)ws);
+    bn_stats_part_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, splits, C, rps, (float*)ws);
   } else {
     dim3 grid(cdiv(C, 64), splits);
-    bn_stats_part_scalar_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, C, rps, (float*)ws);
+    bn_stats_part_scalar_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, splits, C, rps,
+                                                      (float*)ws);
   }
   CG_CHECK_LAUNCH("cg_bn_stats(part)");
   bn_stats_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>((const float*)ws, splits, C,
                                                      1.0f / (float)rows, mean, var, moving_mean,
                                                      moving_var, decay);
   CG_CHECK_LAUNCH("cg_bn_stats(final)");
+  return CG_OK;
+}
+
+// `groups` consecutive blocks of rows / groups rows with independent statistics: the batch norm of
+// several network calls run as one batched call (modular_gan.py:464-467: the generator forwards of
+// all sub-steps share the generator's weights).  mean / var [groups][C].
+extern "C" size_t cg_bn_stats_groups_workspace_bytes(int64_t rows, int C, int groups) {
+  if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups) return 0;
+  return align_up((size_t)groups * stats_splits(rows / groups, C) * 2 * C * sizeof(float), 256);
+}
+
+extern "C" int cg_bn_stats_groups(const void* x, int64_t rows, int C, int groups, float* mean,
+                                  float* var, float* moving_mean, float* moving_var, float decay,
+                                  void* ws, size_t ws_bytes, cgStream stream) {
+  if (!x || !mean || !var || rows <= 0 || C <= 0 || groups <= 0 || rows % groups ||
+      ((moving_mean == nullptr) != (moving_var == nullptr)))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_stats_groups: bad argument");
+  if (!ws || ws_bytes < cg_bn_stats_groups_workspace_bytes(rows, C, groups))
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_bn_stats_groups: workspace too small");
+  const int64_t grows = rows / groups;
+  const int spg = stats_splits(grows, C);
+  const int64_t rps = (grows + spg - 1) / spg;
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 8 == 0) {
+    dim3 grid(cdiv(C / 8, 32), groups * spg);
+    bn_stats_part_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, grows, spg, C, rps, (float*)ws);
+  } else {
+    dim3 grid(cdiv(C, 64), groups * spg);
+    bn_stats_part_scalar_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, grows, spg, C, rps,
+                                                      (float*)ws);
+  }
+  CG_CHECK_LAUNCH("cg_bn_stats_groups(part)");
+  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(
+      (const float*)ws, groups * spg, C, groups, 1, 1.0f / (float)grows, mean, var, moving_mean,
+      moving_var, decay);
+  CG_CHECK_LAUNCH("cg_bn_stats_groups(final)");
+  return CG_OK;
+}
+
+extern "C" int cg_bn_finalize_groups(const float* partials, int rows, int C, int64_t count,
+                                     int groups, int phases, float* mean, float* var,
+                                     float* moving_mean, float* moving_var, float decay,
+                                     cgStream stream) {
+  if (!partials || !mean || !var || rows <= 0 || C <= 0 || count <= 0 || groups <= 0 ||
+      phases <= 0 || rows % phases || (rows / phases) % groups ||
+      ((moving_mean == nullptr) != (moving_var == nullptr)))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_finalize_groups: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(
+      partials, rows, C, groups, phases, 1.0f / (float)count, mean, var, moving_mean, moving_var,
+      decay);
+  CG_CHECK_LAUNCH("cg_bn_finalize_groups");
   return CG_OK;
 }
 
@@ -541,22 +650,38 @@ extern "C" int cg_bn_finalize(const float* partials, int rows, int C, int64_t co
   return CG_OK;
 }
 
+extern "C" int cg_bn_apply_groups(const void* x, int N, int HW, int C, const float* mean,
+                                  const float* var, float eps, const float* gamma,
+                                  const float* beta, int per_sample, int stat_group, int relu,
+                                  void* y, cgStream stream);
+
 extern "C" int cg_bn_apply(const void* x, int N, int HW, int C, const float* mean,
                            const float* var, float eps, const float* gamma, const float* beta,
                            int per_sample, int relu, void* y, cgStream stream) {
-  if (!x || !y || !mean || !var || N <= 0 || HW <= 0 || C <= 0)
+  return cg_bn_apply_groups(x, N, HW, C, mean, var, eps, gamma, beta, per_sample, 0, relu, y,
+                            stream);
+}
+
+// stat_group > 0: mean / var are [N / stat_group][C] (cg_bn_stats_groups); 0: [C]
+extern "C" int cg_bn_apply_groups(const void* x, int N, int HW, int C, const float* mean,
+                                  const float* var, float eps, const float* gamma,
+                                  const float* beta, int per_sample, int stat_group, int relu,
+                                  void* y, cgStream stream) {
+  if (!x || !y || !mean || !var || N <= 0 || HW <= 0 || C <= 0 || stat_group < 0 ||
+      (stat_group > 0 && N % stat_group))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_apply: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (C % 8 == 0) {
     const int ch = hw_chunks(N, HW, C);
     dim3 grid(cdiv(C / 8, 32), ch, N);
     bn_apply_vec_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, HW, C, cdiv(HW, ch), mean, var,
-                                              eps, gamma, beta, per_sample, relu, (bf16_t*)y);
+                                              eps, gamma, beta, per_sample, stat_group, relu,
+                                              (bf16_t*)y);
   } else {
     const int64_t units = (int64_t)N * HW * C;
     bn_apply_scalar_kernel<<<grid_cap(units), 256, 0, st>>>((const bf16_t*)x, HW, C, units, mean,
                                                             var, eps, gamma, beta, per_sample,
-                                                            relu, (bf16_t*)y);
+                                                            stat_group, relu, (bf16_t*)y);
   }
   CG_CHECK_LAUNCH("cg_bn_apply");
   return CG_OK;

@@ -61,6 +61,7 @@ struct HConvArgs {
   const float* bn_beta;
   float bn_eps;
   int bn_per_sample;
+  int bn_stat_group;   // > 0: bn_mean / bn_var are [N / bn_stat_group][Ci]
   float* stats;
   // 2x2 average pooling fused around the convolution (resnet_ops.py:131-133 and its gradient):
   //  pool   : the output is pooled in the epilogue -> [N, Ho/2, Wo/2, Co] (bias before, residual
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
       const int ch = min(cb * 64 + tid, a.Ci - 1);   // (a ragged last block only uses its first half)
       const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
-      tab[tid] = a.bn_mean[ch];
-      tab[64 + tid] = rsqrtf(a.bn_var[ch] + a.bn_eps);
+      const int64_t sidx = a.bn_stat_group > 0 ? (int64_t)(n / a.bn_stat_group) * a.Ci + ch : ch;
+      tab[tid] = a.bn_mean[sidx];
+      tab[64 + tid] = rsqrtf(a.bn_var[sidx] + a.bn_eps);
       tab[128 + tid] = a.bn_gamma ? a.bn_gamma[pidx] : 1.f;
       tab[192 + tid] = a.bn_beta ? a.bn_beta[pidx] : 0.f;
     }
@@ -1363,6 +1365,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.bn_beta = fu ? fu->bn_beta : nullptr;
   a.bn_eps = fu ? fu->bn_eps : 0.f;
   a.bn_per_sample = fu ? fu->bn_per_sample : 0;
+  a.bn_stat_group = fu ? fu->bn_stat_group : 0;
   a.stats = fu ? fu->stats_out : nullptr;
   a.pool = fu ? fu->pool_out : 0;
   a.in_up = fu ? fu->in_up : 0;

@@ -30,7 +30,15 @@ def _run(kind, d_real_logits, d_fake_logits, d_real, d_fake):
   if d_real_logits.is_meta:
     z = d_real_logits.new_empty(())
     return z, z, z, z
-  all_logits = torch.cat([d_real_logits, d_fake_logits], dim=0)   # data movement only
+  joined = getattr(d_real_logits, "_cg_joined", None)
+  if (joined is not None and joined is getattr(d_fake_logits, "_cg_joined", None) and
+      joined.shape[0] == d_real_logits.shape[0] + d_fake_logits.shape[0]):
+    # the halves are views of ONE discriminator call's logits (modular_gan.py:660-661): the kernel
+    # reads that tensor directly -- no concatenation forward, no zero-fill / copy / add of the two
+    # slice gradients backward
+    all_logits = joined
+  else:
+    all_logits = torch.cat([d_real_logits, d_fake_logits], dim=0)   # data movement only
   return Fn.GanLossFn.apply(all_logits, K.LOSS_KINDS[kind])
 
 

@@ -68,6 +68,7 @@ random_uniform = gin.external_configurable(_random_uniform, name="uniform", modu
 # group, resnet_cifar10: 6 forks add 0.6 ms to a 10.2 ms step), more than a 4 MiB all-reduce
 # takes.  CGAMD_DP_OVERLAP=1 / 0 forces it on / off.
 _DP_OVERLAP = os.environ.get("CGAMD_DP_OVERLAP", "auto")
+_JOINT_G = os.environ.get("CGAMD_JOINT_G", "1") != "0"   # batched generator forwards (A/B switch)
 _DP_OVERLAP_MIN_BYTES = 32 << 20
 
 
@@ -370,6 +371,8 @@ class ModularGAN(AbstractGAN):
       bsz = images.shape[0]
       d_real, d_fake = d_all[:bsz], d_all[bsz:]
       d_real_logits, d_fake_logits = d_all_logits[:bsz], d_all_logits[bsz:]
+      if not d_all_logits.is_meta:
+        d_real_logits._cg_joined = d_fake_logits._cg_joined = d_all_logits   # loss_lib._run
     self.d_loss, _, _, self.g_loss = loss_lib.get_losses(
         d_real=d_real, d_fake=d_fake, d_real_logits=d_real_logits, d_fake_logits=d_fake_logits)
     self.penalty_loss = None
@@ -474,6 +477,7 @@ class ModularGAN(AbstractGAN):
       ls.append(l)
     d_losses = []
     with ops.use_store(self.store):
+      self._generate_for_disc(fs)
       for i in range(self._disc_iters):
         d_losses.append(self._disc_sub_step(fs[i], ls[i]))
       g_loss = self._train_generator(fs[-1], ls[-1])
@@ -484,14 +488,45 @@ class ModularGAN(AbstractGAN):
     self.d_opt.join()
     self.g_opt.join()
 
-  def _disc_sub_step(self, features, labels):
-    """G forward (no gradient) on the sub-step's z + one D update (modular_gan.py:465-485)."""
+  def _generate_for_disc(self, fs):
+    """The generator forwards of all discriminator sub-steps as ONE batched call -- none of them
+    sees a generator update (modular_gan.py:444-467 builds them all before the first D update).
+
+    experimental_joint_gen_for_disc = True is the reference's own option (modular_gan.py:444-458):
+    batch norm statistics over the joint batch.  Otherwise the calls are batched only when that
+    is the same arithmetic as the separate calls: batch norm keeps one set of statistics per
+    sub-step (ops.statistics_groups), and the generator must carry no per-call state besides the
+    batch-norm moving averages -- a spectrally normalised generator runs one power iteration per
+    call (arch_ops.py:479-535), so it keeps its separate calls."""
+    n = self._disc_iters
+    joint = self._experimental_joint_gen_for_disc
+    if n < 2:
+      return
+    if not joint:
+      if not _JOINT_G or self.store.sn_registry.get(self.generator.name):
+        return
     with torch.no_grad():
+      z = torch.cat([f["z"] for f in fs[:n]], dim=0)
       sampled_y = None
       if self.conditional:
-        sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+        sampled_y = self._get_one_hot_labels(
+            torch.cat([f["sampled_labels"] for f in fs[:n]], dim=0))
       self.g_opt.join()
-      features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
+      with ops.statistics_groups(1 if joint else n):
+        generated = self.generator(z, y=sampled_y, is_training=True)
+    bsz = z.shape[0] // n
+    for i in range(n):
+      fs[i]["generated"] = generated[i * bsz:(i + 1) * bsz]
+
+  def _disc_sub_step(self, features, labels):
+    """G forward (no gradient) on the sub-step's z + one D update (modular_gan.py:465-485)."""
+    if "generated" not in features:
+      with torch.no_grad():
+        sampled_y = None
+        if self.conditional:
+          sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+        self.g_opt.join()
+        features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
     return self._train_discriminator(features, labels)
 
   def disc_step(self, images, labels):

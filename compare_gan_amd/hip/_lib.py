@@ -50,7 +50,8 @@ class ConvFusion(ctypes.Structure):
     """Mirror of cgConvFusion."""
     _fields_ = [("bn_mean", vp), ("bn_var", vp), ("bn_gamma", vp), ("bn_beta", vp),
                 ("bn_eps", c_f32), ("bn_per_sample", ctypes.c_int32), ("stats_out", vp),
-                ("pool_out", ctypes.c_int32), ("in_up", ctypes.c_int32), ("out_scale", c_f32)]
+                ("pool_out", ctypes.c_int32), ("in_up", ctypes.c_int32), ("out_scale", c_f32),
+                ("bn_stat_group", ctypes.c_int32)]
 
 
 ADAM_CHUNK = 16384
@@ -85,6 +86,12 @@ SIGNATURES = {
     "cg_weight_prep_multi": (c_int, [vp, c_int, vp]),
     "cg_flatten_multi": (c_int, [vp, vp, c_int, vp, vp]),
     "cg_scale_f32": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
+    "cg_bn_finalize_groups": (c_int, [vp, c_int, c_int, c_i64, c_int, c_int, vp, vp, vp, vp, c_f32,
+                                     vp]),
+    "cg_bn_stats_groups_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
+    "cg_bn_stats_groups": (c_int, [vp, c_i64, c_int, c_int, vp, vp, vp, vp, c_f32, vp, c_sz, vp]),
+    "cg_bn_apply_groups": (c_int, [vp, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, c_int, c_int,
+                                  c_int, vp, vp]),
     "cg_bn_stats_workspace_bytes": (c_sz, [c_i64, c_int]),
     "cg_bn_stats": (c_int, [vp, c_i64, c_int, vp, vp, vp, vp, c_f32, vp, c_sz, vp]),
     "cg_bn_apply": (c_int, [vp, c_int, c_int, c_int, vp, vp, c_f32, vp, vp, c_int, c_int, vp, vp]),

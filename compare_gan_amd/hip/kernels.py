@@ -163,8 +163,9 @@ def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, w
         mean, var, gamma, beta, eps, per_sample = bn
         for t, nm in ((mean, "bn mean"), (var, "bn var")):
             _req(t, F32, nm)
-            if t.numel() != geom.Ci:
-                raise ValueError("%s has the wrong number of elements" % nm)
+        fu.bn_stat_group = stat_group_of(mean, geom.N, geom.Ci)   # [Ci] or [groups, Ci]
+        if var.numel() != mean.numel():
+            raise ValueError("bn var has the wrong number of elements")
         want = geom.N * geom.Ci if per_sample else geom.Ci
         for t, nm in ((gamma, "bn gamma"), (beta, "bn beta")):
             _req(t, F32, nm, True)
@@ -211,12 +212,21 @@ def gwgrad_pooled(geom, x, dy_pooled, gate_in=None, want_dbias=False):
     return dw, dbias
 
 
-def bn_finalize(partials, count, moving_mean=None, moving_var=None, decay=0.0):
+def bn_finalize(partials, count, moving_mean=None, moving_var=None, decay=0.0, groups=1, phases=1):
     """mean / var [C] from partial sums [rows][2C] over `count` values per channel; optionally the
-    moving-average update of cg_bn_stats."""
+    moving-average update of cg_bn_stats.  groups > 1: mean / var [groups, C] over count / groups
+    values each (rows = [phases][rows / phases], each phase split in order over the groups)."""
     _req(partials, F32, "partials")
     rows, c2 = partials.shape
     c = c2 // 2
+    if groups > 1:
+        mean = torch.empty((groups, c), dtype=F32, device=partials.device)
+        var = torch.empty((groups, c), dtype=F32, device=partials.device)
+        check(lib().cg_bn_finalize_groups(_p(partials), int(rows), int(c), int(count) // groups,
+                                          int(groups), int(phases), _p(mean), _p(var),
+                                          _p(moving_mean), _p(moving_var), float(decay), _stream()),
+              "cg_bn_finalize_groups")
+        return mean, var
     mean = torch.empty((c,), dtype=F32, device=partials.device)
     var = torch.empty((c,), dtype=F32, device=partials.device)
     check(lib().cg_bn_finalize(_p(partials), int(rows), int(c), int(count), _p(mean), _p(var),
@@ -413,12 +423,24 @@ def scale_f32(x, scale_dev=None, scale_host=1.0):
 # ------------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------------
-def bn_stats(x3, moving_mean=None, moving_var=None, decay=0.0):
-    """x3 [N, HW, C] bf16 -> mean, var fp32 [C]; optionally updates the moving averages."""
+def bn_stats(x3, moving_mean=None, moving_var=None, decay=0.0, groups=1):
+    """x3 [N, HW, C] bf16 -> mean, var fp32 [C]; optionally updates the moving averages.
+    groups > 1: independent statistics for `groups` consecutive blocks of N / groups samples ->
+    mean, var [groups, C]; the moving averages take the groups' updates in order."""
     _req(x3, BF16, "x")
     _req(moving_mean, F32, "moving_mean", True)
     _req(moving_var, F32, "moving_var", True)
     N, HW, C = x3.shape
+    if groups > 1:
+        if N % groups:
+            raise ValueError("bn_stats: %d samples do not split into %d groups" % (N, groups))
+        mean = torch.empty((groups, C), dtype=F32, device=x3.device)
+        var = torch.empty((groups, C), dtype=F32, device=x3.device)
+        ws = _ws(lib().cg_bn_stats_groups_workspace_bytes(N * HW, C, groups), x3)
+        check(lib().cg_bn_stats_groups(_p(x3), N * HW, C, groups, _p(mean), _p(var),
+                                       _p(moving_mean), _p(moving_var), float(decay), _p(ws),
+                                       ws.numel(), _stream()), "cg_bn_stats_groups")
+        return mean, var
     mean = torch.empty((C,), dtype=F32, device=x3.device)
     var = torch.empty((C,), dtype=F32, device=x3.device)
     ws = _ws(lib().cg_bn_stats_workspace_bytes(N * HW, C), x3)
@@ -427,7 +449,19 @@ def bn_stats(x3, moving_mean=None, moving_var=None, decay=0.0):
     return mean, var
 
 
+def stat_group_of(mean, n, c):
+    """Samples per statistics group for mean / var of shape [C] (0) or [groups, C]."""
+    if mean.numel() == c:
+        return 0
+    groups = mean.numel() // c
+    if groups * c != mean.numel() or n % groups:
+        raise ValueError("statistics of %d elements do not fit %d samples x %d channels" % (
+            mean.numel(), n, c))
+    return n // groups
+
+
 def bn_apply(x3, mean, var, eps, gamma=None, beta=None, per_sample=False, relu=False):
+    """mean / var [C], or [groups, C] for group statistics (bn_stats(groups=...))."""
     _req(x3, BF16, "x")
     N, HW, C = x3.shape
     for t, nm in ((mean, "mean"), (var, "var")):
@@ -435,8 +469,9 @@ def bn_apply(x3, mean, var, eps, gamma=None, beta=None, per_sample=False, relu=F
     _req(gamma, F32, "gamma", True)
     _req(beta, F32, "beta", True)
     y = torch.empty_like(x3)
-    check(lib().cg_bn_apply(_p(x3), N, HW, C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta),
-                            int(per_sample), int(relu), _p(y), _stream()), "cg_bn_apply")
+    check(lib().cg_bn_apply_groups(_p(x3), N, HW, C, _p(mean), _p(var), float(eps), _p(gamma),
+                                   _p(beta), int(per_sample), stat_group_of(mean, N, C),
+                                   int(relu), _p(y), _stream()), "cg_bn_apply")
     return y
 
 

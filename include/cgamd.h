@@ -132,6 +132,9 @@ typedef struct {
   int32_t pool_out;
   int32_t in_up;
   float out_scale;
+  /* > 0: bn_mean / bn_var are [N / bn_stat_group][Ci] -- one set of statistics per bn_stat_group
+   * consecutive samples (cg_bn_stats_groups: several network calls batched into one); 0: [Ci]. */
+  int32_t bn_stat_group;
 } cgConvFusion;
 int cg_gconv_fused_rows(const cgConvGeom* geom);
 int cg_gconv_fused(const cgConvGeom* geom, const void* in, const void* bt, void* out,
@@ -150,6 +153,13 @@ int cg_gwgrad_pooled(const cgConvGeom* geom, const void* in, const void* gate_in
  * [rows][2*C] over `count` values per channel. */
 int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean, float* var,
                    float* moving_mean, float* moving_var, float decay, cgStream stream);
+/* The same for `groups` statistics groups of consecutive samples (see cg_bn_stats_groups): the
+ * rows are [phases][rows / phases] (phases = U*U of the producing convolution), the rows of one
+ * phase split evenly and in order over the groups; `count` values per channel and group;
+ * mean / var [groups][C]. */
+int cg_bn_finalize_groups(const float* partials, int rows, int C, int64_t count, int groups,
+                          int phases, float* mean, float* var, float* moving_mean,
+                          float* moving_var, float decay, cgStream stream);
 
 /* Weight gradient of the same primitive (tf.gradients of arch_ops.conv2d / deconv2d / linear
  * w.r.t. the kernel):
@@ -247,12 +257,25 @@ int cg_scale_f32(const float* x, const float* scale_dev, float scale_host, float
 size_t cg_bn_stats_workspace_bytes(int64_t rows, int C);
 int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, float* var, float* moving_mean,
                 float* moving_var, float decay, void* ws, size_t ws_bytes, cgStream stream);
+/* Statistics of `groups` consecutive blocks of rows / groups rows each, mean / var [groups][C]:
+ * the batch norm of several network calls that were batched into one call.  The reference runs
+ * the generator once per sub-step on the same weights (modular_gan.py:464-467); one batched call
+ * with per-call statistics is the same arithmetic.  The moving averages receive the groups'
+ * updates in order (arch_ops.py:105-114 once per call).  ws >= cg_bn_stats_groups_workspace_bytes. */
+size_t cg_bn_stats_groups_workspace_bytes(int64_t rows, int C, int groups);
+int cg_bn_stats_groups(const void* x, int64_t rows, int C, int groups, float* mean, float* var,
+                       float* moving_mean, float* moving_var, float decay, void* ws,
+                       size_t ws_bytes, cgStream stream);
 /* y = act( (x - mean) * rsqrt(var + eps) * gamma + beta ), act = relu if relu != 0.
  * gamma/beta: fp32 [C] (per_sample == 0) or [N,C] (per_sample != 0, conditional BN), NULL = 1 / 0.
  * y bf16 same shape as x. */
 int cg_bn_apply(const void* x, int N, int HW, int C, const float* mean, const float* var,
                 float eps, const float* gamma, const float* beta, int per_sample, int relu,
                 void* y, cgStream stream);
+/* cg_bn_apply with mean / var [N / stat_group][C] (stat_group > 0; N % stat_group == 0). */
+int cg_bn_apply_groups(const void* x, int N, int HW, int C, const float* mean, const float* var,
+                       float eps, const float* gamma, const float* beta, int per_sample,
+                       int stat_group, int relu, void* y, cgStream stream);
 /* Backward of cg_bn_apply, in two stream-ordered stages so that data-parallel sync-BN can
  * all-reduce the per-channel means in between (tpu_ops.py:94-125 applied to the backward sums):
  *   reduce: dz = dy * (y > 0) if relu;  dbeta = sum dz;  dgamma = sum dz * xhat (per [C] or [N,C]);

@@ -19,8 +19,11 @@ class OracleGAN(object):
   def __init__(self, vs, architecture, g_cfg, d_cfg, image_shape, loss="non_saturating",
                penalty="no_penalty", lamba=1.0, disc_iters=1, conditional=False, num_classes=None,
                g_lr=0.0002, d_lr=None, beta1=0.9, beta2=0.999, g_use_ema=False,
-               ema_decay=0.9999, ema_start_step=40000):
+               ema_decay=0.9999, ema_start_step=40000, joint_gen_for_disc=False):
     self.vs = vs
+    # experimental_joint_gen_for_disc (modular_gan.py:444-463): ONE generator call on the z of all
+    # discriminator sub-steps (batch norm statistics over the joint batch), split afterwards
+    self.joint_gen_for_disc = joint_gen_for_disc
     self.arch = architecture
     self.g_cfg, self.d_cfg = g_cfg, d_cfg
     self.image_shape = image_shape
@@ -89,11 +92,23 @@ class OracleGAN(object):
     """subs: list of disc_iters+1 dicts {images, z, labels, sampled_labels, alpha}."""
     self._ensure_opts()
     d_losses = []
+    joint = None
+    if self.joint_gen_for_disc:
+      # modular_gan.py:451-458: generator(z[:batch_size * disc_iters]) then tf.split
+      with torch.no_grad():
+        z = torch.cat([s["z"] for s in subs[:self.disc_iters]], dim=0)
+        sy = None
+        if self.conditional:
+          sy = self.one_hot(torch.cat([s["sampled_labels"] for s in subs[:self.disc_iters]]))
+        joint = torch.chunk(self.G(z, sy), self.disc_iters, dim=0)
     for i in range(self.disc_iters):
       s = subs[i]
       with torch.no_grad():
-        sy = self.one_hot(s["sampled_labels"]) if self.conditional else None
-        generated = self.G(s["z"], sy)
+        if joint is not None:
+          generated = joint[i]
+        else:
+          sy = self.one_hot(s["sampled_labels"]) if self.conditional else None
+          generated = self.G(s["z"], sy)
       d_loss, _, _ = self.create_loss(s["images"], generated, s.get("labels"),
                                       s.get("sampled_labels"), s.get("alpha"))
       grads = torch.autograd.grad(d_loss, self.d_vars())

@@ -133,6 +133,76 @@ def test_gconv_forward_adjoint_wgrad(K, dev, case):
     assert_close_f32(db, dy64.sum(dim=(0, 1, 2)), name + " dbias", rtol=2e-4, abs_rms=2e-4)
 
 
+def _close_on_device(got, ref, what, rel, abs_rms):
+    """assert_close_* for tensors too large to ship to the host: same bound, evaluated on the GPU."""
+    g = got.detach().to(torch.float64).reshape(ref.shape)
+    rms = float(ref.pow(2).mean().sqrt()) + 1e-30
+    excess = (g - ref).abs() - (rel * ref.abs() + abs_rms * rms)
+    bad = int((excess > 0).sum())
+    assert bad == 0, "%s: %d/%d elements out of tolerance (worst excess %.3g, rms %.3g)" % (
+        what, bad, ref.numel(), float(excess.max()), rms)
+
+
+def _ref_conv3x3_dev64(x, w):
+    """3x3 SAME convolution as nine shifted fp64 GEMMs on the device (plain torch, no kernel of
+    libcgamd.so): x [N,H,W,Ci], w [3,3,Ci,Co] -> [N,H,W,Co]."""
+    n, h, w_, ci = x.shape
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+    out = torch.zeros((n * h * w_, w.shape[-1]), dtype=torch.float64, device=x.device)
+    for r in range(3):
+        for s_ in range(3):
+            out += xp[:, r:r + h, s_:s_ + w_, :].reshape(-1, ci) @ w[r, s_]
+    return out.reshape(n, h, w_, -1)
+
+
+FULL_SIZE_CASES = [
+    # the geometries bench.py and the microbenchmarks actually run (VERDICT r01, item 6)
+    ("cifar_D_32x32", 128, 32, 32, 128, 128),
+    ("cifar_G_32x32", 64, 32, 32, 256, 256),
+    ("cifar_D_8x8", 128, 8, 8, 128, 128),
+    ("resnet128_D_64x64", 128, 64, 64, 128, 128),
+    ("resnet128_D_128x128", 128, 128, 128, 64, 64),
+    ("resnet128_D_4x4", 128, 4, 4, 512, 512),
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_CASES, ids=[c[0] for c in FULL_SIZE_CASES])
+def test_gconv_full_size_shapes(K, dev, case):
+    """Forward, data gradient, weight and bias gradient of the 3x3 convolutions at the batch sizes
+    of the benchmark (the dispatcher picks other kernel variants -- tile sizes, ring depths, halo
+    splits -- there than at the toy sizes above).  The CPU oracle would need minutes per case at
+    these sizes; the reference here is nine shifted fp64 GEMMs in plain torch on the device."""
+    name, N, H, W, Ci, Co = case
+    g = torch.Generator(device=dev).manual_seed(sum(ord(c) for c in name))
+    xb = torch.randn((N, H, W, Ci), generator=g, device=dev, dtype=torch.float32).to(BF16)
+    wb = (torch.randn((3, 3, Ci, Co), generator=g, device=dev, dtype=torch.float32) /
+          math.sqrt(9 * Ci)).to(BF16)
+    dyb = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
+    bias = torch.randn(Co, generator=g, device=dev, dtype=torch.float32)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+    bt_f, bt_b = K.weight_prep(wb.to(torch.float32), want_fwd=True, want_bwd=True)
+    x64, w64, dy64 = xb.double(), wb.double(), dyb.double()
+
+    ref = _ref_conv3x3_dev64(x64, w64) + bias.double()
+    y = K.gconv(geom, xb, bt_f, bias=bias)
+    _close_on_device(y, ref, name + " fwd bf16", 2.0 * 2.0 ** -8, 2.0 ** -8)
+    del ref, y
+    # data gradient = convolution of dy with the flipped, transposed filter
+    ref_dx = _ref_conv3x3_dev64(dy64, w64.flip(0, 1).transpose(2, 3).contiguous())
+    dx = K.gconv(K.geom_adjoint(geom), dyb, bt_b, out_f32=True)
+    _close_on_device(dx, ref_dx, name + " dgrad f32", 2e-4, 2e-4)
+    del ref_dx, dx
+    # weight / bias gradient, ReLU self-gate on the input (the form every block uses)
+    xr = torch.relu(x64)
+    xp = F.pad(xr, (0, 0, 1, 1, 1, 1))
+    dy2 = dy64.reshape(-1, Co)
+    ref_dw = torch.stack([torch.stack([
+        xp[:, r:r + H, s_:s_ + W, :].reshape(-1, Ci).t() @ dy2 for s_ in range(3)]) for r in range(3)])
+    dw, db = K.gwgrad(geom, xb, dyb, gate_in=xb, slope_in=0.0, want_dbias=True)
+    _close_on_device(dw, ref_dw, name + " wgrad", 2e-4, 2e-4)
+    _close_on_device(db, dy2.sum(dim=0), name + " dbias", 2e-4, 2e-4)
+
+
 @pytest.mark.parametrize("size", [8, 32])
 @pytest.mark.parametrize("slope", [0.0, 0.2])
 def test_gconv_gates_residual(K, dev, slope, size):
@@ -232,6 +302,75 @@ def test_gconv_fused_batch_norm(K, dev, case):
     m3, _ = K.bn_finalize(part2, cnt)
     assert_close_f32(m3, out2.detach().float().cpu().double().mean(dim=(0, 1, 2)),
                      name + " stats-only mean", rtol=1e-4, abs_rms=1e-4)
+
+
+@pytest.mark.parametrize("C,HW", [(64, 64), (256, 16), (40, 9), (3, 1024)])
+def test_batch_norm_statistics_groups(K, dev, C, HW):
+    """cg_bn_stats_groups / cg_bn_apply_groups: one launch over a batch that stands for `groups`
+    separate calls is bit for bit the separate calls (arch_ops.py:289-313 per call; the moving
+    averages take one update per call, in order: arch_ops.py:105-114)."""
+    groups, per = 3, 4
+    g = _gen(C * 7 + HW)
+    _, xb = rand_bf16((groups * per, HW, C), g, 2.0)
+    xb = xb.to(dev)
+    mm = torch.randn(C, generator=g).float().to(dev)
+    mv = (1.0 + torch.rand(C, generator=g)).float().to(dev)
+    mm_g, mv_g = mm.clone(), mv.clone()
+    mean_g, var_g = K.bn_stats(xb, mm_g, mv_g, 0.9, groups=groups)
+    assert mean_g.shape == (groups, C)
+    gamma = (1.0 + 0.3 * torch.randn((groups * per, C), generator=g)).float().to(dev)
+    beta = (0.3 * torch.randn((groups * per, C), generator=g)).float().to(dev)
+    y_g = K.bn_apply(xb, mean_g, var_g, 1e-5, gamma, beta, True, True)
+    for i in range(groups):
+        xs = xb[i * per:(i + 1) * per].contiguous()
+        m, v = K.bn_stats(xs, mm, mv, 0.9)
+        assert torch.equal(m, mean_g[i]) and torch.equal(v, var_g[i]), "group %d statistics" % i
+        y = K.bn_apply(xs, m, v, 1e-5, gamma[i * per:(i + 1) * per].contiguous(),
+                       beta[i * per:(i + 1) * per].contiguous(), True, True)
+        assert torch.equal(y, y_g[i * per:(i + 1) * per]), "group %d apply" % i
+    assert torch.equal(mm, mm_g) and torch.equal(mv, mv_g), "moving averages"
+
+
+@pytest.mark.parametrize("case", [
+    # name, per-group N, H, W, Ci, Co, up, per_sample
+    ("grp_c64", 2, 32, 32, 64, 128, 1, False),
+    ("grp_cbn_up", 2, 16, 16, 128, 64, 2, True),
+    ("grp_c256_16", 4, 16, 16, 256, 256, 1, False),
+], ids=lambda c: c[0])
+def test_gconv_fused_statistics_groups(K, dev, case):
+    """cg_gconv_fused with bn_stat_group and cg_bn_finalize_groups: the batched call with one set
+    of batch-norm statistics per group of samples equals the per-group calls bit for bit (same
+    kernel, same tiles), for the normalised input AND for the statistics it emits."""
+    name, per, H, W, Ci, Co, up, per_sample = case
+    groups = 3
+    N = groups * per
+    g = _gen(sum(ord(c) for c in name))
+    _, xb = rand_bf16((N, H, W, Ci), g)
+    _, wb = rand_bf16((3, 3, Ci, Co), g, 1.0 / math.sqrt(9 * Ci))
+    xb = xb.to(dev)
+    bias = torch.randn(Co, generator=g, dtype=torch.float32).to(dev)
+    gshape = (N, Ci) if per_sample else (Ci,)
+    gamma = (1.0 + 0.3 * torch.randn(gshape, generator=g)).float().to(dev)
+    beta = (0.3 * torch.randn(gshape, generator=g)).float().to(dev)
+    bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev))
+    mean, var = K.bn_stats(xb.reshape(N, H * W, Ci), groups=groups)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, up)
+    geom1 = K.geom_conv_same(per, H, W, Ci, Co, 3, 3, 1, up)
+    assert K.gconv_fused_rows(geom) > 0
+    out, part = K.gconv_fused(geom, xb, bt_f, bias=bias,
+                              bn=(mean, var, gamma, beta, 1e-5, per_sample), want_stats=True)
+    cnt = N * geom.Ho * geom.Wo
+    m_g, v_g = K.bn_finalize(part, cnt, groups=groups, phases=up * up)
+    for i in range(groups):
+        sl = slice(i * per, (i + 1) * per)
+        gm = gamma[sl].contiguous() if per_sample else gamma
+        bt_ = beta[sl].contiguous() if per_sample else beta
+        o1, p1 = K.gconv_fused(geom1, xb[sl].contiguous(), bt_f, bias=bias,
+                               bn=(mean[i].contiguous(), var[i].contiguous(), gm, bt_, 1e-5,
+                                   per_sample), want_stats=True)
+        assert torch.equal(o1, out[sl]), "%s group %d output" % (name, i)
+        m1, v1 = K.bn_finalize(p1, cnt // groups)
+        assert torch.equal(m1, m_g[i]) and torch.equal(v1, v_g[i]), "%s group %d stats" % (name, i)
 
 
 @pytest.mark.parametrize("case", [

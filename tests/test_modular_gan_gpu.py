@@ -489,3 +489,68 @@ def test_captured_step_matches_eager(dev, config, bsz):
     assert int(sg["global_step"]) == 2
     bad = [k for k in se if not torch.equal(se[k], sg[k])]
     assert not bad, bad[:8]
+
+
+def test_batched_generator_forward_matches_separate_calls(dev):
+    """train_step() runs the generator forwards of the discriminator sub-steps as ONE batched
+    no-gradient call with one set of batch-norm statistics per sub-step
+    (ModularGAN._generate_for_disc, ops.statistics_groups) -- the arithmetic of the reference's
+    separate calls (modular_gan.py:464-467).  The batched call may dispatch other kernel variants
+    (larger grids), so the images agree to bf16 accumulation noise, and the moving averages take
+    the sub-steps' updates in order."""
+    from compare_gan_amd.architectures import arch_ops as ops
+    config, bsz = "resnet_cifar10.gin", 16
+    bind = ("standardize_batch.use_moving_averages = True",)
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED, bindings=bind)
+    n = options["disc_iters"]
+    images = torch.zeros((bsz,) + dataset.image_shape, dtype=torch.float32, device=dev)
+    labels = torch.zeros((bsz,), dtype=torch.int32, device=dev)
+    mov = [k for k in gan.store.vars if k.endswith("moving_mean") or k.endswith("moving_variance")]
+    assert mov
+    saved = {k: gan.store.vars[k].detach().clone() for k in mov}
+    with ops.use_store(gan.store):
+        fs = [gan._preprocess(images, labels, i)[0] for i in range(n + 1)]   # pylint: disable=protected-access
+        gan._generate_for_disc(fs)                                          # pylint: disable=protected-access
+        joint = [fs[i]["generated"].clone() for i in range(n)]
+        mov_joint = {k: gan.store.vars[k].detach().clone() for k in mov}
+        with torch.no_grad():
+            for k in mov:
+                gan.store.vars[k].copy_(saved[k])
+            separate = [gan.generator(fs[i]["z"], y=None, is_training=True) for i in range(n)]
+    torch.cuda.synchronize()
+    assert "generated" not in fs[n]     # the generator sub-step keeps its own (gradient) forward
+    for i in range(n):
+        d = (joint[i].double() - separate[i].double()).abs()
+        assert float(d.max()) <= 0.03 and float(d.mean()) <= 1e-3, (i, float(d.max()), float(d.mean()))
+    for k in mov:
+        a, b = mov_joint[k].double(), gan.store.vars[k].detach().double()
+        assert float((a - b).abs().max()) <= 1e-4 * (1.0 + float(b.abs().max())), k
+
+
+def test_joint_gen_for_disc_step_against_oracle(dev):
+    """ModularGAN.experimental_joint_gen_for_disc = True (modular_gan.py:444-463): ONE generator
+    call on the z of all discriminator sub-steps, batch-norm statistics over the joint batch, the
+    images split afterwards; one full unrolled step against the bf16-storage oracle."""
+    config, bsz = "resnet_cifar10.gin", 8
+    bind = ("ModularGAN.experimental_joint_gen_for_disc = True",)
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED, bindings=bind)
+    vs = U.mirror_to_oracle(gan, emulate_bf16=True)
+    ora = U.build_oracle(config, vs, joint_gen_for_disc=True)
+    ora_sep = U.build_oracle(config, U.mirror_to_oracle(gan, emulate_bf16=True))
+    nsub = options["disc_iters"] + 1
+    rng = np.random.RandomState(500)
+    images = rng.uniform(size=(nsub * bsz,) + dataset.image_shape).astype(np.float32)
+    labels = np.ones((nsub * bsz,), dtype=np.int32)
+    out = gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+    subs = [{"images": torch.from_numpy(images[i * bsz:(i + 1) * bsz]).double(),
+             "z": U.host_uniform((bsz, 128), "z/%d" % i, -1.0, 1.0, SEED, 0).double()}
+            for i in range(nsub)]
+    d_o, g_o = ora.train_step(subs)
+    d_s, _ = ora_sep.train_step(subs)
+    d_p = [float(x) for x in out["d_losses"]]
+    print("joint: product", d_p, "oracle", d_o, "oracle with separate calls", d_s)
+    for a, b in zip(d_p, d_o):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b))
+    assert abs(float(out["g_loss"]) - g_o) <= 2e-2 * max(1.0, abs(g_o))
+    # the option is not a no-op: joint statistics move the first loss away from the separate calls'
+    assert abs(d_o[0] - d_s[0]) > 1e-6
