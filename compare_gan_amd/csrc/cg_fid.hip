@@ -393,6 +393,73 @@ extern "C" int cg_inception_score_f64(const float* logits, int64_t n, int k, dou
   return CG_OK;
 }
 
+// ---- FID scalar assembly on the device (no host round trip between the two eigen-solves) ----
+namespace {
+// f[i] = sign(w) * (|w| < eps ? |w| : sqrt|w|): tfgan's _symmetric_matrix_square_root rule applied
+// to the spectrum; sum_out (optional) = sum_i f[i], one block, fixed order.
+__global__ __launch_bounds__(256) void spectral_sqrt_kernel(const double* __restrict__ w, int n,
+                                                            double eps, double* __restrict__ f,
+                                                            double* __restrict__ sum_out) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double x = w[i], a = fabs(x);
+    const double r = (x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0)) * (a < eps ? a : sqrt(a));
+    if (f) f[i] = r;
+    s += r;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && sum_out) *sum_out = sm[0] + sm[1] + sm[2] + sm[3];
+}
+// out = tr(sigma) + tr(sigma_v) - 2 * sqrt_trace + |m - m_v|^2   (fid_score.py:58-75 via tfgan)
+__global__ __launch_bounds__(256) void fid_combine_kernel(const double* __restrict__ sigma,
+                                                          const double* __restrict__ sigma_v,
+                                                          const double* __restrict__ m,
+                                                          const double* __restrict__ m_v, int d,
+                                                          const double* __restrict__ sqrt_trace,
+                                                          double* __restrict__ out) {
+  __shared__ double sm[2][4];
+  double t = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    t += sigma[(int64_t)i * d + i] + sigma_v[(int64_t)i * d + i];
+    const double dm = m[i] - m_v[i];
+    q += dm * dm;
+  }
+  t = wave_sum_d(t);
+  q = wave_sum_d(q);
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][threadIdx.x >> 6] = t;
+    sm[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *out = (sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]) - 2.0 * *sqrt_trace +
+           (sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
+}
+}  // namespace
+
+extern "C" int cg_spectral_sqrt_f64(const double* w, int n, double eps, double* f, double* sum_out,
+                                    cgStream stream) {
+  if (!w || n <= 0 || (!f && !sum_out))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_spectral_sqrt_f64: bad argument");
+  spectral_sqrt_kernel<<<1, 256, 0, (hipStream_t)stream>>>(w, n, eps, f, sum_out);
+  CG_CHECK_LAUNCH("cg_spectral_sqrt_f64");
+  return CG_OK;
+}
+
+extern "C" int cg_fid_combine_f64(const double* sigma, const double* sigma_v, const double* mean,
+                                  const double* mean_v, int d, const double* sqrt_trace,
+                                  double* out, cgStream stream) {
+  if (!sigma || !sigma_v || !mean || !mean_v || !sqrt_trace || !out || d <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_fid_combine_f64: bad argument");
+  fid_combine_kernel<<<1, 256, 0, (hipStream_t)stream>>>(sigma, sigma_v, mean, mean_v, d,
+                                                         sqrt_trace, out);
+  CG_CHECK_LAUNCH("cg_fid_combine_f64");
+  return CG_OK;
+}
+
 // ---- KID (metrics/kid_score.py:44-149): sum and trace of the cubic polynomial kernel
 // (gram / dim + 1)^3 of one block, fp64, two-stage deterministic reduction ----
 constexpr int KID_BLOCKS = 256;

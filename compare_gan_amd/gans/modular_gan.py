@@ -410,18 +410,21 @@ class ModularGAN(AbstractGAN):
     self.g_loss = self.g_loss.detach()
     return self.d_loss
 
-  def _train_generator(self, features, labels):
-    """One G update (+ EMA) (modular_gan.py:487-510); D's weights get no gradient."""
+  def _train_generator(self, features, labels, shared_forward=False):
+    """One G update (+ EMA) (modular_gan.py:487-510); D's weights get no gradient.
+    shared_forward: features["generated"] already holds this sub-step's generator forward WITH
+    its autograd graph (the not-unrolled step builds one forward for both updates)."""
     features = dict(features)
     features["_generator_step"] = True
     self._set_requires_grad(self.d_opt, False)
     self._set_requires_grad(self.g_opt, True)
     with ops.use_store(self.store):
-      sampled_y = None
-      if self.conditional:
-        sampled_y = self._get_one_hot_labels(features["sampled_labels"])
-      self.g_opt.join()
-      features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
+      if not shared_forward:
+        sampled_y = None
+        if self.conditional:
+          sampled_y = self._get_one_hot_labels(features["sampled_labels"])
+        self.g_opt.join()
+        features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
     grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
                                 allow_unused=True)
@@ -483,6 +486,42 @@ class ModularGAN(AbstractGAN):
       g_loss = self._train_generator(fs[-1], ls[-1])
     self._join_updates()
     return {"d_losses": d_losses, "g_loss": g_loss}
+
+  def unroll_graph(self, use_tpu=True):
+    """modular_gan.py:533: the step is unrolled on accelerators or when forced by gin."""
+    return bool(self._experimental_force_graph_unroll or use_tpu)
+
+  def train_step_not_unrolled(self, images, labels):
+    """One session.run of the reference's NOT unrolled graph (modular_gan.py:533-584 with
+    use_tpu=False and experimental_force_graph_unroll=False): ONE sub-batch
+    [B,H,W,C] -- one generator forward on it, one D update, and, when the discriminator step
+    counter AFTER its increment is a multiple of disc_iters, one G update on the SAME z / images:
+    the generator forward is the one built at the start of the step, the discriminator forward is
+    fresh and sees the just-updated D (tf.control_dependencies, :573-576).  Otherwise g_loss = 0.
+
+    Kept for parity with GPU runs of the reference; the accelerator path (and bench.py) is the
+    unrolled train_step().  Reads the step counter on the host (one synchronisation)."""
+    if not self._built:
+      raise RuntimeError("call build() first")
+    if self._experimental_joint_gen_for_disc:
+      raise ValueError("Joining G forward passes is only supported for unrolled graphs.")
+    # the random streams are keyed by (name, global_step): the calls between two G updates get
+    # distinct names, as the reference's stateful random ops give them distinct draws
+    f, l = self._preprocess(images, labels, int(self.global_step_disc.item()) % self._disc_iters)
+    with ops.use_store(self.store):
+      sampled_y = None
+      if self.conditional:
+        sampled_y = self._get_one_hot_labels(f["sampled_labels"])
+      self._set_requires_grad(self.g_opt, True)
+      self.g_opt.join()
+      f["generated"] = self.generator(f["z"], y=sampled_y, is_training=True)
+      d_loss = self._train_discriminator(f, l)
+      if int(self.global_step_disc.item()) % self._disc_iters == 0:
+        g_loss = self._train_generator(f, l, shared_forward=True)
+      else:
+        g_loss = torch.zeros((), dtype=torch.float32, device=self.device)
+    self._join_updates()
+    return {"d_losses": [d_loss], "g_loss": g_loss}
 
   def _join_updates(self):
     self.d_opt.join()

@@ -1015,6 +1015,27 @@ def rowscale_f64(a, scale):
     return out
 
 
+def spectral_sqrt_f64(w, eps, want_values=True):
+    """(f, sum f) with f = sign(w) * (|w| if |w| < eps else sqrt|w|), both on the device."""
+    _req(w, F64, "w")
+    f = torch.empty_like(w) if want_values else None
+    total = torch.empty((1,), dtype=F64, device=w.device)
+    check(lib().cg_spectral_sqrt_f64(_p(w), w.numel(), float(eps), _p(f), _p(total), _stream()),
+          "cg_spectral_sqrt_f64")
+    return f, total
+
+
+def fid_combine_f64(sigma, sigma_v, mean, mean_v, sqrt_trace):
+    """tr(sigma) + tr(sigma_v) - 2 sqrt_trace + |mean - mean_v|^2 as a device scalar [1]."""
+    for t, nm in ((sigma, "sigma"), (sigma_v, "sigma_v"), (mean, "mean"), (mean_v, "mean_v"),
+                  (sqrt_trace, "sqrt_trace")):
+        _req(t, F64, nm)
+    out = torch.empty((1,), dtype=F64, device=sigma.device)
+    check(lib().cg_fid_combine_f64(_p(sigma), _p(sigma_v), _p(mean), _p(mean_v), sigma.shape[0],
+                                   _p(sqrt_trace), _p(out), _stream()), "cg_fid_combine_f64")
+    return out
+
+
 def syevj_f64(a, max_sweeps=30, tol=1e-15):
     """Destroys `a`.  Returns (w [d], v [d,d] with eigenvectors as ROWS)."""
     _req(a, F64, "a")

@@ -17,6 +17,7 @@ Every arithmetic op is a HIP kernel: cg_gconv (conv + bias + ReLU fused, act_out
 cg_spatial_reduce (global average pool), cg_gconv as the logits GEMM.  torch.cat only moves bytes.
 """
 import math
+import os
 
 import torch
 
@@ -133,7 +134,36 @@ class InceptionV3(object):
     self.device = torch.device(device)
     self.load_weights(weights if weights is not None else make_weights(seed))
 
+  # (producer, consumer) pairs whose intermediate channel count is not a multiple of 32 (48 / 80):
+  # the MFMA-tiled kernels slice K in 64-channel blocks and need Ci % 32 == 0 (cg_gconv falls back
+  # to the generic gather kernel otherwise, ~10x slower).  The producer gets zero output channels
+  # (zero kernel columns, zero bias: relu(0) = 0, and max-pooling zeros gives zeros), the consumer
+  # zero kernel rows for them -- the arithmetic on the real channels is unchanged.
+  _PAD_PAIRS = [("conv_3", "conv_4")] + [("%s/b1_1x1" % m, "%s/b1_5x5" % m)
+                                         for m in ("mixed", "mixed_1", "mixed_2")]
+
+  @classmethod
+  def _pad_channels(cls, weights):
+    if os.environ.get("CGAMD_INCEPTION_PAD", "1") == "0":
+      return weights, {}
+    w = dict(weights)
+    padded = {}
+    for prod, cons in cls._PAD_PAIRS:
+      kp, kc = w[prod + "/kernel"], w[cons + "/kernel"]
+      co = kp.shape[3]
+      cp = (co + 31) // 32 * 32
+      if cp == co or kc.shape[2] != co:
+        continue
+      w[prod + "/kernel"] = torch.cat([kp, kp.new_zeros(kp.shape[:3] + (cp - co,))], dim=3)
+      w[prod + "/bias"] = torch.cat([w[prod + "/bias"], kp.new_zeros((cp - co,))])
+      w[cons + "/kernel"] = torch.cat(
+          [kc, kc.new_zeros(kc.shape[:2] + (cp - co, kc.shape[3]))], dim=2)
+      padded[prod] = cp
+    return w, padded
+
   def load_weights(self, weights):
+    weights, self._padded_cout = self._pad_channels(
+        {k: v.to(F32) for k, v in weights.items()})
     self.weights = {k: v.to(F32).to(self.device).contiguous() for k, v in weights.items()}
     # frozen weights: the MFMA operand images are built once
     self._bt = {}
@@ -146,6 +176,7 @@ class InceptionV3(object):
   # -- ops -----------------------------------------------------------------------------------------
   def _conv(self, x, op):
     _, name, cout, kh, kw, stride, padding = op
+    cout = self._padded_cout.get(name, cout)
     n, h, w_, ci = x.shape
     if padding == "SAME":
       geom = K.geom_conv_same(n, h, w_, ci, cout, kh, kw, stride, 1)

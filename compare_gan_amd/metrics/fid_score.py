@@ -8,7 +8,7 @@ with the symmetric square root U diag(where(s < 1e-10, s, sqrt(s))) V^T taken fr
 O(n d^2) and O(d^3) parts run as fp64 HIP kernels (cg_mean_cov_f64, cg_syevj_f64, cg_gemm_f64,
 cg_rowscale_f64); for a symmetric matrix the SVD is its eigen-decomposition with
 s = |lambda|, V = sign(lambda) U, so the same function of the spectrum is applied to the Jacobi
-eigenvalues.  The O(d) scalar assembly happens on the host.
+eigenvalues (cg_spectral_sqrt_f64); the O(d) scalar assembly is one more kernel (cg_fid_combine_f64).
 """
 import numpy as np
 import torch
@@ -20,12 +20,6 @@ from compare_gan_amd.metrics import eval_task
 FID_CODE_FAILED = 4242.0
 _EPS = 1e-10
 _SWEEPS = 18
-
-
-def _spectral_sqrt_values(w):
-  """sign(l) * (|l| if |l| < eps else sqrt(|l|)): tfgan's _symmetric_matrix_square_root rule."""
-  s = np.abs(w)
-  return np.sign(w) * np.where(s < _EPS, s, np.sqrt(s))
 
 
 def _activations_on_device(acts, device):
@@ -43,17 +37,15 @@ def frechet_distance(real_activations, generated_activations, device="cuda:0"):
         tuple(real.shape), tuple(gen.shape)))
   m, sigma = K.mean_cov_f64(real)
   m_v, sigma_v = K.mean_cov_f64(gen)
-  # sqrt(sigma) = V^T diag(f(w)) V  (rows of V are eigenvectors)
+  # sqrt(sigma) = V^T diag(f(w)) V  (rows of V are eigenvectors); f and every scalar stay on the
+  # device: one host read at the very end
   w, v = K.syevj_f64(sigma.clone(), max_sweeps=_SWEEPS)
-  f = torch.from_numpy(_spectral_sqrt_values(w.cpu().numpy())).to(real.device)
+  f, _ = K.spectral_sqrt_f64(w, _EPS)
   sqrt_sigma = K.gemm_f64(v, K.rowscale_f64(v, f), ta=True)
   inner = K.gemm_f64(K.gemm_f64(sqrt_sigma, sigma_v), sqrt_sigma)
-  # symmetrise against rounding before the second decomposition
   w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS)
-  sqrt_trace = float(np.sum(_spectral_sqrt_values(w2.cpu().numpy())))
-  tr = float(torch.diagonal(sigma).sum().cpu()) + float(torch.diagonal(sigma_v).sum().cpu())
-  dm = (m - m_v).cpu().numpy()
-  return tr - 2.0 * sqrt_trace + float(np.dot(dm, dm))
+  _, sqrt_trace = K.spectral_sqrt_f64(w2, _EPS, want_values=False)
+  return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
 
 
 class FIDScoreTask(eval_task.EvalTask):

@@ -490,6 +490,18 @@ int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
 size_t cg_syevj_workspace_bytes(int d);
 int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,
                  size_t ws_bytes, cgStream stream);
+/* The scalar part of the Frechet distance on the device (fid_score.py:58-75 through tfgan's
+ * frechet_classifier_distance_from_activations), so that no host round trip sits between the two
+ * eigen-decompositions:
+ *   cg_spectral_sqrt_f64: f[i] = sign(w[i]) * (|w[i]| < eps ? |w[i]| : sqrt|w[i]|)  (tfgan's
+ *     _symmetric_matrix_square_root rule on the spectrum; f may be NULL), *sum_out = sum_i f[i]
+ *     (may be NULL);
+ *   cg_fid_combine_f64: *out = tr(sigma) + tr(sigma_v) - 2 * *sqrt_trace + |mean - mean_v|^2. */
+int cg_spectral_sqrt_f64(const double* w, int n, double eps, double* f, double* sum_out,
+                         cgStream stream);
+int cg_fid_combine_f64(const double* sigma, const double* sigma_v, const double* mean,
+                       const double* mean_v, int d, const double* sqrt_trace, double* out,
+                       cgStream stream);
 /* KID (metrics/kid_score.py:129-136): out2[0] = sum, out2[1] = trace of the cubic polynomial kernel
  * (gram / dim + 1)^3 of an [m, n] fp64 Gram block (cg_gemm_f64 of two activation blocks).
  * ws >= cg_poly3_kernel_workspace_bytes(). */

@@ -127,3 +127,29 @@ class OracleGAN(object):
       ogan.ema_update(self.ema, self.g_vars(), decay)
     self.global_step += 1
     return d_losses, float(g_loss.detach())
+
+  def train_step_not_unrolled(self, sub):
+    """One session.run of the NOT unrolled graph (modular_gan.py:533-584, use_tpu=False): one
+    generator forward shared by both updates, a D update, then -- when disc_step % disc_iters == 0
+    after the increment (:566-569) -- a G update through a FRESH forward of the updated D."""
+    self._ensure_opts()
+    s = sub
+    sy = self.one_hot(s["sampled_labels"]) if self.conditional else None
+    generated = self.G(s["z"], sy)                                       # :465-467, once
+    d_loss, _, _ = self.create_loss(s["images"], generated.detach(), s.get("labels"),
+                                    s.get("sampled_labels"), s.get("alpha"))
+    grads = torch.autograd.grad(d_loss, self.d_vars())
+    self.d_opt.step(grads)
+    self.global_step_disc += 1
+    g_val = 0.0
+    if self.global_step_disc % self.disc_iters == 0:
+      _, g_loss, _ = self.create_loss(s["images"], generated, s.get("labels"),
+                                      s.get("sampled_labels"), with_penalty=False)
+      grads = torch.autograd.grad(g_loss, self.g_vars())
+      self.g_opt.step(grads)
+      if self.g_use_ema:
+        decay = self.ema_decay if self.global_step >= self.ema_start_step else 0.0
+        ogan.ema_update(self.ema, self.g_vars(), decay)
+      self.global_step += 1
+      g_val = float(g_loss.detach())
+    return float(d_loss.detach()), g_val

@@ -110,3 +110,25 @@ def build_oracle(config, vs, **overrides):
     kw["d_cfg"] = kw["d_cfg"]()
     arch = kw.pop("architecture")
     return omg.OracleGAN(vs, arch, **kw)
+
+
+def resync_oracle(gan, ora):
+    """Copies the product's complete training state into the oracle (variables, spectral-norm
+    vectors, moving averages, Adam slots, step counters), so that the NEXT step starts from
+    identical states on both sides: Adam's first updates move every weight by ~lr whatever the
+    size of its gradient, which decorrelates weights with ~0 gradients after one step and makes a
+    free-running comparison of later steps meaningless."""
+    with torch.no_grad():
+        for name, v in gan.store.vars.items():
+            ora.vs.vars[name].copy_(v.detach().to("cpu").to(ora.vs.vars[name].dtype))
+    ora._ensure_opts()   # pylint: disable=protected-access
+    pairs = ((gan.g_opt, ora.g_opt, [n for n in ora.vs.trainable if n.startswith("generator")]),
+             (gan.d_opt, ora.d_opt, ora.d_var_names()))
+    for popt, oopt, onames in pairs:
+        idx = {n: i for i, n in enumerate(popt.names)}
+        with torch.no_grad():
+            for j, n in enumerate(onames):
+                oopt.m[j].copy_(popt.m[idx[n]].detach().cpu().to(oopt.m[j].dtype))
+                oopt.v[j].copy_(popt.v[idx[n]].detach().cpu().to(oopt.v[j].dtype))
+    ora.g_opt.t = ora.global_step = int(gan.global_step.item())
+    ora.d_opt.t = ora.global_step_disc = int(gan.global_step_disc.item())

@@ -73,6 +73,17 @@ def _substep_inputs(gan, dataset, bsz, sub, step, conditional):
 @pytest.mark.parametrize("config,bsz", [("resnet_cifar10.gin", 8), ("dcgan_celeba64.gin", 4),
                                         ("sndcgan_celebahq128.gin", 2)])
 def test_forward_and_gradients(dev, config, bsz, emulate):
+    _forward_and_gradients(dev, config, bsz, emulate)
+
+
+def test_forward_and_gradients_at_the_benchmark_batch(dev):
+    """resnet_cifar10.gin at batch 64 per sub-step -- the shape bench.py measures, where the
+    dispatcher selects the 128-pixel-row tiles, the deep rings and the halo splits it never uses at
+    batch 8 -- against the bf16-storage oracle."""
+    _forward_and_gradients(dev, "resnet_cifar10.gin", 64, True)
+
+
+def _forward_and_gradients(dev, config, bsz, emulate):
     from compare_gan_amd.architectures import arch_ops as ops
     gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED)
     vs = U.mirror_to_oracle(gan, emulate_bf16=emulate)
@@ -133,18 +144,24 @@ def test_forward_and_gradients(dev, config, bsz, emulate):
             assert U.rel_l2(v, vs.vars[name]) <= 2e-2, name
 
 
-def test_train_steps_resnet_cifar(dev):
-    """Two full unrolled steps (5 D sub-steps + 1 G sub-step each) vs the bf16-storage oracle:
-    the first step's losses agree closely; from the second step on Adam's sign-like first updates
-    (every weight moves by ~lr whatever its gradient's size) decorrelate weights whose gradients
-    are ~0, so only a loose band is asserted there.  Step counters follow the reference pin
-    modular_gan_test.py:175-177."""
-    config, bsz = "resnet_cifar10.gin", 8
+@pytest.mark.parametrize("bsz", [8, 64])
+def test_train_steps_resnet_cifar(dev, bsz):
+    """Two full unrolled steps (5 D sub-steps + 1 G sub-step each) of resnet_cifar10.gin vs the
+    bf16-storage oracle, at a toy batch and at the batch bench.py measures (64: the dispatcher
+    picks the kernel variants of the benchmark there).  Both steps are held to the same tolerance:
+    after the first one the oracle takes over the product's complete state (U.resync_oracle), so
+    the second step -- non-zero Adam slots, advanced power-iteration vectors and moving averages --
+    is compared from identical states instead of through Adam's sign-like first update.  Step
+    counters follow the reference pin modular_gan_test.py:175-177."""
+    config = "resnet_cifar10.gin"
     gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED)
     vs = U.mirror_to_oracle(gan, emulate_bf16=True)
     ora = U.build_oracle(config, vs)
     nsub = options["disc_iters"] + 1
-    for step in range(2):
+    lr = 2e-4
+    nsteps = 2 if bsz <= 8 else 1     # (the fp64 oracle needs ~20 s per step at batch 64)
+    for step in range(nsteps):
+        before = {n: v.detach().clone() for n, v in gan.store.trainable_variables()}
         rng = np.random.RandomState(500 + step)
         images = rng.uniform(size=(nsub * bsz,) + dataset.image_shape).astype(np.float32)
         labels = np.ones((nsub * bsz,), dtype=np.int32)
@@ -156,17 +173,29 @@ def test_train_steps_resnet_cifar(dev):
         d_o, g_o = ora.train_step(subs)
         d_p = [float(x) for x in out["d_losses"]]
         print("step", step, "d", d_p, d_o, "g", float(out["g_loss"]), g_o)
-        tol = 2e-2 if step == 0 else 0.6
         for a, b in zip(d_p, d_o):
-            assert abs(a - b) <= tol * max(1.0, abs(b))
-        assert abs(float(out["g_loss"]) - g_o) <= tol * max(1.0, abs(g_o))
-    assert int(gan.global_step.item()) == 2
-    assert int(gan.global_step_disc.item()) == 2 * options["disc_iters"]
-    # Adam's first steps move every weight by ~lr regardless of the gradient scale, so compare the
-    # weights themselves: they must agree to a small multiple of lr * steps
-    for name, v in gan.store.trainable_variables():
-        err = float((v.detach().cpu().double() - vs.vars[name].detach()).abs().max())
-        assert err <= 12 * 2e-4 * 2, (name, err)
+            assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (step, a, b)
+        assert abs(float(out["g_loss"]) - g_o) <= 2e-2 * max(1.0, abs(g_o)), step
+        # the step's weight UPDATE against the oracle's.  Adam's first updates are sign-like, so a
+        # weight whose gradient is ~0 (a bias in front of batch norm) moves by +-lr at random on
+        # either side: per element the two updates may differ by 2 lr per sub-step, and the
+        # direction is judged over each network as a whole (the exact and the bf16-storage oracle
+        # agree to cosine 0.93 / 0.945 there at batch 8 -- measured on the CPU)
+        for net in ("generator", "discriminator"):
+            ups, uos = [], []
+            for name, v in gan.store.trainable_variables(net):
+                up = v.detach().double().cpu() - before[name].double().cpu()
+                uo = vs.vars[name].detach().double() - before[name].double().cpu()
+                assert float((up - uo).abs().max()) <= 12 * lr, (step, name)
+                assert float(up.abs().max()) > 0.0, "%s did not move" % name
+                ups.append(up.reshape(-1))
+                uos.append(uo.reshape(-1))
+            c = U.cosine(torch.cat(ups), torch.cat(uos))
+            print("step", step, net, "update cosine", c)
+            assert c >= 0.90, (step, net, c)
+        U.resync_oracle(gan, ora)
+    assert int(gan.global_step.item()) == nsteps
+    assert int(gan.global_step_disc.item()) == nsteps * options["disc_iters"]
 
 
 def _wgangp_setup(dev, emulate):
@@ -246,13 +275,14 @@ def test_wgangp_step_resnet5(dev, emulate):
 
 def _biggan_family_forward_and_gradients(dev, label, bind, g_over, d_over, arch=None,
                                          min_g_grads=40, fwd_tol=(0.05, 5e-3),
-                                         d_tol=(0.98, 0.2), g_tol=(0.97, 0.3), check_u=True):
+                                         d_tol=(0.98, 0.2), g_tol=(0.97, 0.3), check_u=True,
+                                         bsz=2, g_step=True):
     """Generator forward, D sub-step and G sub-step losses and gradients of a BigGAN-family
-    architecture under biggan_imagenet128.gin against the bf16-storage oracle (128x128, batch 2)."""
+    architecture under biggan_imagenet128.gin against the bf16-storage oracle (128x128)."""
     from compare_gan_amd.architectures import arch_ops as ops
     from oracle import architectures as OA
     from oracle import arch_ops as oops
-    config, bsz = "biggan_imagenet128.gin", 2
+    config = "biggan_imagenet128.gin"
     gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED, bindings=bind)
     vs = U.mirror_to_oracle(gan, emulate_bf16=True)
     overrides = dict(
@@ -266,8 +296,8 @@ def _biggan_family_forward_and_gradients(dev, label, bind, g_over, d_over, arch=
     ora = U.build_oracle(config, vs, **overrides)
     rng = np.random.RandomState(11)
     images = torch.from_numpy(rng.uniform(size=(bsz,) + dataset.image_shape).astype(np.float32))
-    labels = torch.tensor([3, 977], dtype=torch.int32)
-    sampled = torch.tensor([5, 400], dtype=torch.int32)
+    labels = ((torch.arange(bsz) * 487 + 3) % 1000).to(torch.int32)      # 3, 490, 977, ...
+    sampled = ((torch.arange(bsz) * 395 + 5) % 1000).to(torch.int32)     # 5, 400, 795, ...
     z = U.host_normal((bsz, options["z_dim"]), "z/0", 0.0, 1.0, SEED, 0)
     with ops.use_store(gan.store):
         zd = gan.z_generator([bsz, options["z_dim"]], name="z/0")
@@ -299,6 +329,8 @@ def _biggan_family_forward_and_gradients(dev, label, bind, g_over, d_over, arch=
                      d_tol[0], d_tol[1])
     print(label + " D-step worst grad cosine", w)
 
+    if not g_step:
+        return
     gan._set_requires_grad(gan.d_opt, False)
     gan._set_requires_grad(gan.g_opt, True)
     gan._zero_grads(gan.g_opt)
@@ -335,29 +367,35 @@ def test_biggan_forward_and_gradients(dev):
         dict(hierarchical_z=True, embed_y=True, ch=32), dict(project_y=True, ch=32))
 
 
+def test_biggan_full_width_d_step(dev):
+    """biggan_imagenet128.gin at its own width ch = 96 (the benchmark's channel counts: 96 ... 1536,
+    multiples of 32 that are not multiples of 64 -- the half-empty last channel block of the halo
+    kernels), batch 2: generator forward and the D sub-step against the bf16-storage oracle
+    (VERDICT r01, item 6)."""
+    _biggan_family_forward_and_gradients(
+        dev, "biggan-ch96", [], dict(hierarchical_z=True, embed_y=True, ch=96),
+        dict(project_y=True, ch=96), g_step=False)
+
+
 def test_biggan_deep_forward_and_gradients(dev):
     """The same settings on resnet_biggan_deep_arch: bottleneck blocks,
     channel-dropping zero-insertion shortcuts in G (cg_unpool2 with the main branch as residual),
     pooled + channel-appending shortcuts in D, z concatenated with the label embedding for every
-    conditional batch norm, attention at 64x64 in both networks; ch = 32."""
+    conditional batch norm, attention at 64x64 in both networks; ch = 32.
+
+    Batch 8: at batch 2 the 40 conditional batch norms of this generator amplify every flipped
+    ReLU mask so much that the bf16-storage oracle itself only reaches cosine 0.84-0.86 against the
+    exact one on the G-step gradients (profiles/r01_oracle_sensitivity.txt), which left nothing to
+    assert in round 1 (floor 0.75).  At batch 8 the network is well conditioned and the test
+    carries the BigGAN family's standard tolerances (measured in round 2: generator output mean
+    |diff| 1.6e-3, every D-step and G-step gradient at cosine >= 0.9998, power-iteration vectors
+    within 2e-7)."""
     _biggan_family_forward_and_gradients(
         dev, "biggan-deep",
         ['options.architecture = "resnet_biggan_deep_arch"',
          "resnet_biggan_deep.Generator.ch = 32", "resnet_biggan_deep.Discriminator.ch = 32"],
         dict(embed_y=True, ch=32), dict(project_y=True, ch=32), arch="resnet_biggan_deep_arch",
-        min_g_grads=60,
-        # Measured (round 1, deterministic kernels): generator output mean |diff| 4.3e-3 with one
-        # pixel at 0.098; D-step gradients cosine >= 0.9997 for every variable; G-step losses agree
-        # to 0.2 %; the G-step gradients of blocks B1-B5 sit at cosine 0.80-0.91 (rel-L2
-        # 0.42-0.63).  That is this network's conditioning at batch 2: the bf16-storage oracle is
-        # itself only at cosine 0.84-0.86 / rel-L2 0.52-0.56 from the exact oracle for the same
-        # variables (scripts/oracle_sensitivity.py, profiles/r01_oracle_sensitivity.txt; plain
-        # BigGAN: 0.972), so two bf16 pipelines with different accumulation orders cannot agree
-        # better.  The G-step floor below guards against wiring errors only.
-        fwd_tol=(0.15, 8e-3), d_tol=(0.99, 0.2), g_tol=(0.75, 0.70),
-        # the spectral-norm vectors' comparison has not run on the GPU yet for this architecture
-        # (every visit so far stopped at the G-step gradients): reported, not asserted
-        check_u=False)
+        min_g_grads=60, bsz=8)
 
 
 @pytest.mark.parametrize("config,bsz", [("resnet_lsun-bedroom128.gin", 4), ("resnet_cifar10.gin", 16),
@@ -554,3 +592,38 @@ def test_joint_gen_for_disc_step_against_oracle(dev):
     assert abs(float(out["g_loss"]) - g_o) <= 2e-2 * max(1.0, abs(g_o))
     # the option is not a no-op: joint statistics move the first loss away from the separate calls'
     assert abs(d_o[0] - d_s[0]) > 1e-6
+
+
+def test_not_unrolled_step_against_oracle(dev):
+    """ModularGAN.train_step_not_unrolled(): the reference's GPU graph (modular_gan.py:533-584,
+    SURVEY App. A.7) -- one sub-batch per call, the G update only on every disc_iters-th call, on
+    the same z and images, through the generator forward built BEFORE the D update and a fresh
+    forward of the updated D.  Three calls with disc_iters = 2 against the bf16-storage oracle."""
+    config, bsz = "resnet_cifar10.gin", 8
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED,
+                                            bindings=("options.disc_iters = 2",))
+    assert not gan.unroll_graph(use_tpu=False) and gan.unroll_graph(use_tpu=True)
+    vs = U.mirror_to_oracle(gan, emulate_bf16=True)
+    ora = U.build_oracle(config, vs, disc_iters=2)
+    g_before = {n: v.detach().clone() for n, v in gan.store.trainable_variables("generator")}
+    for call in range(3):
+        rng = np.random.RandomState(900 + call)
+        images = rng.uniform(size=(bsz,) + dataset.image_shape).astype(np.float32)
+        out = gan.train_step_not_unrolled(torch.from_numpy(images).to(dev),
+                                          torch.ones((bsz,), dtype=torch.int32, device=dev))
+        # z is keyed by (seed, "z/<call within the cycle>", global_step); global_step moves only
+        # with the G update
+        step = 0 if call < 2 else 1
+        sub = {"images": torch.from_numpy(images).double(),
+               "z": U.host_uniform((bsz, 128), "z/%d" % (call % 2), -1.0, 1.0, SEED, step).double()}
+        d_o, g_o = ora.train_step_not_unrolled(sub)
+        d_p, g_p = float(out["d_losses"][0]), float(out["g_loss"])
+        print("call", call, "d", d_p, d_o, "g", g_p, g_o)
+        assert abs(d_p - d_o) <= 2e-2 * max(1.0, abs(d_o))
+        assert abs(g_p - g_o) <= 2e-2 * max(1.0, abs(g_o))
+        moved = any(not torch.equal(v, g_before[n])
+                    for n, v in gan.store.trainable_variables("generator"))
+        assert moved == (call >= 1), "generator update on the wrong call (%d)" % call
+        assert (g_p != 0.0) == (call == 1)
+        U.resync_oracle(gan, ora)
+    assert int(gan.global_step.item()) == 1 and int(gan.global_step_disc.item()) == 3
