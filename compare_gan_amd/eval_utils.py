@@ -55,10 +55,18 @@ def _to_three_channels(images):
 
 def get_real_images(dataset, num_examples, split=None, failure_on_insufficient_examples=True,
                     device="cuda:0"):
-  """num_examples real images with values in [0, 255] (eval_utils.py:87-141).  Offline only the
-  synthetic eval split exists (datasets.eval_images)."""
-  del split, failure_on_insufficient_examples
-  images = torch.from_numpy(dataset.eval_images(num_examples)).to(device)
+  """num_examples real images with values in [0, 255] (eval_utils.py:87-141): the first examples
+  of the dataset's eval split -- the on-disk arrays (datasets.use_data_dir) or the synthetic
+  source.  Only the default eval split exists here."""
+  if split not in (None, "test"):
+    raise ValueError("Only the default eval split is available, got %r" % (split,))
+  try:
+    arrays = dataset.eval_images(num_examples)
+  except ValueError:
+    if failure_on_insufficient_examples:
+      raise
+    raise NotImplementedError("partial eval splits are not supported")
+  images = torch.from_numpy(arrays).to(device)
   from compare_gan_amd.hip import kernels as K
   return _to_three_channels(K.scale_f32(images.contiguous(), None, 255.0))
 

@@ -20,10 +20,13 @@ from compare_gan_amd import gin
 from compare_gan_amd import utils
 from compare_gan_amd.architectures import arch_ops as ops
 from compare_gan_amd.architectures import dcgan
+from compare_gan_amd.architectures import infogan
+from compare_gan_amd.architectures import resnet30
 from compare_gan_amd.architectures import resnet5
 from compare_gan_amd.architectures import resnet_biggan
 from compare_gan_amd.architectures import resnet_biggan_deep
 from compare_gan_amd.architectures import resnet_cifar
+from compare_gan_amd.architectures import resnet_stl
 from compare_gan_amd.architectures import sndcgan
 from compare_gan_amd.gans import consts as c
 from compare_gan_amd.gans import loss_lib
@@ -227,7 +230,10 @@ class ModularGAN(AbstractGAN):
     if self._generator is None:
       architecture_fns = {
           c.DCGAN_ARCH: dcgan.Generator,
+          c.INFOGAN_ARCH: infogan.Generator,
           c.RESNET5_ARCH: resnet5.Generator,
+          c.RESNET30_ARCH: resnet30.Generator,
+          c.RESNET_STL_ARCH: resnet_stl.Generator,
           c.RESNET_BIGGAN_ARCH: resnet_biggan.Generator,
           c.RESNET_BIGGAN_DEEP_ARCH: resnet_biggan_deep.Generator,
           c.RESNET_CIFAR_ARCH: resnet_cifar.Generator,
@@ -245,7 +251,10 @@ class ModularGAN(AbstractGAN):
     if self._discriminator is None:
       architecture_fns = {
           c.DCGAN_ARCH: dcgan.Discriminator,
+          c.INFOGAN_ARCH: infogan.Discriminator,
           c.RESNET5_ARCH: resnet5.Discriminator,
+          c.RESNET30_ARCH: resnet30.Discriminator,
+          c.RESNET_STL_ARCH: resnet_stl.Discriminator,
           c.RESNET_BIGGAN_ARCH: resnet_biggan.Discriminator,
           c.RESNET_BIGGAN_DEEP_ARCH: resnet_biggan_deep.Discriminator,
           c.RESNET_CIFAR_ARCH: resnet_cifar.Discriminator,

@@ -505,13 +505,124 @@ def sndcgan_discriminator(vs, cfg, x, y, is_training):
   return torch.sigmoid(logit), logit, net
 
 
+# ------------------------------------------------------------------------------------------------
+# infogan (infogan.py:35-100), resnet_stl (resnet_stl.py:33-108), resnet30 (resnet30.py:36-143)
+# ------------------------------------------------------------------------------------------------
+def infogan_generator(vs, cfg, z, y, is_training, image_shape=(32, 32, 3)):
+  s = "generator"
+  h, w, c = image_shape
+  bs = z.shape[0]
+  # the reference calls arch_ops.batch_norm directly (infogan.py:53-59): always plain batch norm
+  bn = lambda t, nm: ops.batch_norm(vs, t, is_training, s + nm, cfg.bn_cfg)
+  net = ops.linear(vs, z, 1024, s + "/g_fc1", cfg.sn_cfg)
+  net = ops.lrelu(bn(net, "/g_bn1"))
+  net = ops.linear(vs, net, 128 * (h // 4) * (w // 4), s + "/g_fc2", cfg.sn_cfg)
+  net = ops.lrelu(bn(net, "/g_bn2"))
+  net = net.reshape(bs, h // 4, w // 4, 128)
+  net = ops.deconv2d(vs, net, [bs, h // 2, w // 2, 64], 4, 4, 2, 2, s + "/g_dc3", cfg.sn_cfg)
+  net = ops.lrelu(bn(net, "/g_bn3"))
+  net = ops.deconv2d(vs, net, [bs, h, w, c], 4, 4, 2, 2, s + "/g_dc4", cfg.sn_cfg, out_f32=True)
+  return torch.sigmoid(net)
+
+
+def infogan_discriminator(vs, cfg, x, y, is_training):
+  s = "discriminator"
+  sn = cfg.spectral_norm
+  bs = x.shape[0]
+  net = ops.lrelu(ops.conv2d(vs, x, 64, 4, 4, 2, 2, s + "/d_conv1", cfg.sn_cfg, use_sn=sn))
+  net = ops.conv2d(vs, net, 128, 4, 4, 2, 2, s + "/d_conv2", cfg.sn_cfg, use_sn=sn)
+  net = ops.lrelu(_batch_norm(vs, cfg, net, s + "/d_bn2", y=y, is_training=is_training))
+  net = net.reshape(bs, -1)
+  net = ops.linear(vs, net, 1024, s + "/d_fc3", cfg.sn_cfg, use_sn=sn)
+  net = ops.lrelu(_batch_norm(vs, cfg, net, s + "/d_bn3", y=y, is_training=is_training))
+  logit = ops.linear(vs, net, 1, s + "/d_fc4", cfg.sn_cfg, use_sn=sn, out_f32=True)
+  return torch.sigmoid(logit), logit, net
+
+
+def resnet_stl_generator(vs, cfg, z, y, is_training, image_shape=(48, 48, 3)):
+  s = "generator"
+  ch = 64
+  magic = [(8, 4), (4, 2), (2, 1)]
+  out = ops.linear(vs, z, 6 * 6 * 512, s + "/fc_noise", cfg.sn_cfg)
+  out = out.reshape(-1, 6, 6, 512)
+  for b in range(3):
+    out = resnet_block(vs, cfg, out, "%s/B%d" % (s, b + 1), ch * magic[b][0], ch * magic[b][1],
+                       "up", True, z, y, is_training)
+  # scope="final_norm" is dropped by call_with_accepted_args (resnet_stl.py:60-61): the variables
+  # live under the batch norm function's default name
+  out = _batch_norm(vs, cfg, out, s + "/batch_norm", z=z, y=y, is_training=is_training, relu=True)
+  out = ops.conv2d(vs, out, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg,
+                   out_f32=True)
+  return torch.sigmoid(out)
+
+
+def resnet_stl_discriminator(vs, cfg, x, y, is_training):
+  s = "discriminator"
+  colors = x.shape[3]
+  if colors not in (1, 3):
+    raise ValueError("Number of color channels unknown: %s" % colors)
+  ch = 64
+  out = resnet_block(vs, cfg, x, s + "/B0", colors, ch, "down", False, None, y, is_training)
+  magic = [(1, 2), (2, 4), (4, 8), (8, 16)]
+  for b in range(4):
+    out = resnet_block(vs, cfg, out, "%s/B%d" % (s, b + 1), ch * magic[b][0], ch * magic[b][1],
+                       "down" if b < 3 else "none", False, None, y, is_training)
+  out = torch.relu(out)
+  pre = vs.q(out.mean(dim=(1, 2)))
+  logit = ops.linear(vs, pre, 1, s + "/disc_final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm,
+                     out_f32=True)
+  return torch.sigmoid(logit), logit, pre
+
+
+def resnet30_generator(vs, cfg, z, y, is_training, image_shape=(128, 128, 3)):
+  s = "generator"
+  ch = 64
+  out = ops.linear(vs, z, 4 * 4 * 8 * ch, s + "/fc_noise", cfg.sn_cfg)
+  out = out.reshape(-1, 4, 4, 8 * ch)
+  cin, cout = 8 * ch, 4 * ch
+  for sb in range(6):
+    for i in range(5):
+      out = resnet_block(vs, cfg, out, "%s/B_%d_%d" % (s, sb, i), cin, cin, "none", True, z, y,
+                         is_training)
+    if sb < 5:
+      out = resnet_block(vs, cfg, out, "%s/B_%d_up" % (s, sb), cin, cout, "up", True, z, y,
+                         is_training)
+    cin, cout = cin // 2, cout // 2
+  out = ops.conv2d(vs, out, image_shape[2], 3, 3, 1, 1, s + "/final_conv", cfg.sn_cfg,
+                   out_f32=True)
+  return torch.sigmoid(out)
+
+
+def resnet30_discriminator(vs, cfg, x, y, is_training):
+  s = "discriminator"
+  ch = 64
+  out = ops.conv2d(vs, x, ch // 4, 3, 3, 1, 1, s + "/color_conv", cfg.sn_cfg)
+  cin, cout = ch // 4, ch // 2
+  for sb in range(6):
+    for i in range(5):
+      out = resnet_block(vs, cfg, out, "%s/B_%d_%d" % (s, sb, i), cin, cin, "none", False, None,
+                         y, is_training)
+    if sb < 5:
+      out = resnet_block(vs, cfg, out, "%s/B_%d_up" % (s, sb), cin, cout, "down", False, None, y,
+                         is_training)
+    cin, cout = cin * 2, cout * 2
+  out = out.reshape(-1, 4 * 4 * 8 * ch)
+  logit = ops.linear(vs, out, 1, s + "/disc_final_fc", cfg.sn_cfg, use_sn=cfg.spectral_norm,
+                     out_f32=True)
+  return torch.sigmoid(logit), logit, out
+
+
 GENERATORS = {
+    "infogan_arch": infogan_generator, "resnet_stl_arch": resnet_stl_generator,
+    "resnet30_arch": resnet30_generator,
     "resnet_cifar_arch": resnet_cifar_generator, "resnet5_arch": resnet5_generator,
     "resnet_biggan_arch": biggan_generator, "dcgan_arch": dcgan_generator,
     "resnet_biggan_deep_arch": biggan_deep_generator,
     "sndcgan_arch": sndcgan_generator,
 }
 DISCRIMINATORS = {
+    "infogan_arch": infogan_discriminator, "resnet_stl_arch": resnet_stl_discriminator,
+    "resnet30_arch": resnet30_discriminator,
     "resnet_cifar_arch": resnet_cifar_discriminator, "resnet5_arch": resnet5_discriminator,
     "resnet_biggan_arch": biggan_discriminator, "dcgan_arch": dcgan_discriminator,
     "resnet_biggan_deep_arch": biggan_deep_discriminator,
