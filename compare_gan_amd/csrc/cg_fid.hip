@@ -3,6 +3,7 @@
 // centred covariance GEMM, general fp64 GEMM, parallel one-sided Jacobi eigensolver for the
 // symmetric square roots, and the classifier score.  v1 kernels are LDS-tiled vector-ALU fp64.
 #include "cg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -184,6 +185,165 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ 
     vq[k] = sn * vx + cs * vy;
   }
 }
+// ---- block form of the same method --------------------------------------------------------------
+// The scalar round above moves all of G and V (2 x d^2 doubles, read + write) for ONE rotation per
+// row pair: bandwidth bound, ~27 us per round, 2047 rounds per sweep at d = 2048.  Here the rows
+// form nb = d / 16 blocks; a round pairs the BLOCKS by the circle method (nb - 1 rounds per sweep)
+// and one workgroup handles a pair of blocks = 32 rows:
+//   1. Gram matrix M = X X^T of its 32 rows (32 x 32, the inner products every rotation needs);
+//   2. one cyclic Jacobi sweep over all 496 row pairs ON M (two-sided rotations M <- R M R^T, the
+//      exact image of rotating the rows), accumulating the product J of the rotations;
+//   3. X <- J X for the rows of G and of V (one pass).
+// One pass over the data now carries 496 rotations instead of 16, the traffic per sweep drops 16x.
+// Same rotation rule and threshold as the scalar kernel; deterministic.
+constexpr int JB = 16;            // rows per block
+constexpr int JR = 2 * JB;        // rows per workgroup
+constexpr int JCW = 64;           // columns per staged chunk
+__global__ __launch_bounds__(256) void bjacobi_round_kernel(double* __restrict__ g,
+                                                            double* __restrict__ v, int d, int nb,
+                                                            int round, double tol,
+                                                            int* __restrict__ flags) {
+  if (flags[0]) return;
+  __shared__ double Tt[JCW][JR + 2];       // chunk, column-major: Tt[k][row]
+  __shared__ double Mp[4][JR][JR + 1];     // per-wave Gram partials
+  __shared__ double M[JR][JR + 1];
+  __shared__ double J[JR][JR + 1];
+  __shared__ double s_c[JB], s_s[JB];
+  __shared__ int s_p[JB], s_q[JB], s_rot;
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  // circle method over the nb blocks (nb even)
+  const int i = blockIdx.x, m = nb - 1;
+  int P, Q;
+  if (i == 0) { P = nb - 1; Q = round % m; }
+  else { P = (round + i) % m; Q = (round - i + m) % m; }
+  if (P > Q) { const int x = P; P = Q; Q = x; }
+  auto grow = [&](int r) -> int64_t { return (int64_t)(r < JB ? P * JB + r : Q * JB + r - JB); };
+
+  // ---- 1. Gram matrix: thread (ti, tj) of every wave owns a 4 x 4 block, waves split the columns
+  {
+    const int ti = l >> 3, tj = l & 7;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int c0 = 0; c0 < d; c0 += JCW) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = t + 256 * e, r = idx >> 6, k = idx & 63;
+        Tt[k][r] = g[grow(r) * d + c0 + k];
+      }
+      __syncthreads();
+      for (int k = w; k < JCW; k += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = Tt[k][4 * ti + e]; b[e] = Tt[k][4 * tj + e]; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) Mp[w][4 * ti + x][4 * tj + y] = acc[x][y];
+  }
+  if (t == 0) s_rot = 0;
+  __syncthreads();
+  for (int e = t; e < JR * JR; e += 256) {
+    const int r = e / JR, c = e - r * JR;
+    M[r][c] = Mp[0][r][c] + Mp[1][r][c] + Mp[2][r][c] + Mp[3][r][c];
+    J[r][c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+
+  // ---- 2. one cyclic sweep on M (circle method over the 32 rows: 31 rounds of 16 disjoint pairs)
+  for (int ir = 0; ir < JR - 1; ++ir) {
+    if (t < JB) {
+      const int mm = JR - 1;
+      int p, q;
+      if (t == 0) { p = JR - 1; q = ir % mm; }
+      else { p = (ir + t) % mm; q = (ir - t + mm) % mm; }
+      if (p > q) { const int x = p; p = q; q = x; }
+      const double al = M[p][p], be = M[q][q], ga = M[p][q];
+      double cs = 1.0, sn = 0.0;
+      if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300) {
+        const double zeta = (be - al) / (2.0 * ga);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        cs = 1.0 / sqrt(1.0 + tt * tt);
+        sn = cs * tt;
+        atomicAdd(&s_rot, 1);
+      }
+      s_c[t] = cs; s_s[t] = sn; s_p[t] = p; s_q[t] = q;
+    }
+    __syncthreads();
+    {   // rows p, q of M and J <- R (rows)
+      const int pi = t >> 4, p = s_p[pi], q = s_q[pi];
+      const double cs = s_c[pi], sn = s_s[pi];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = (t & 15) + 16 * h;
+        const double mp = M[p][c], mq = M[q][c];
+        M[p][c] = cs * mp - sn * mq;
+        M[q][c] = sn * mp + cs * mq;
+        const double jp = J[p][c], jq = J[q][c];
+        J[p][c] = cs * jp - sn * jq;
+        J[q][c] = sn * jp + cs * jq;
+      }
+    }
+    __syncthreads();
+    {   // columns p, q of M <- (M) R^T
+      const int pi = t >> 4, p = s_p[pi], q = s_q[pi];
+      const double cs = s_c[pi], sn = s_s[pi];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = (t & 15) + 16 * h;
+        const double mp = M[r][p], mq = M[r][q];
+        M[r][p] = cs * mp - sn * mq;
+        M[r][q] = sn * mp + cs * mq;
+      }
+    }
+    __syncthreads();
+  }
+  if (s_rot == 0) return;          // nothing rotated: rows already orthogonal to the threshold
+  if (t == 0) atomicAdd(&flags[1], s_rot);
+
+  // ---- 3. rows <- J rows, for G and V; thread tile 4 rows x 2 columns of a 32 x 64 chunk
+  const int ti = t >> 5, tj = t & 31;
+  for (int which = 0; which < 2; ++which) {
+    double* __restrict__ x = which == 0 ? g : v;
+    for (int c0 = 0; c0 < d; c0 += JCW) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = t + 256 * e, r = idx >> 6, k = idx & 63;
+        Tt[k][r] = x[grow(r) * d + c0 + k];
+      }
+      __syncthreads();
+      double acc[4][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a][0] = acc[a][1] = 0.0;
+#pragma unroll 8
+      for (int sI = 0; sI < JR; ++sI) {
+        const double b0 = Tt[2 * tj][sI], b1 = Tt[2 * tj + 1][sI];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const double ja = J[4 * ti + a][sI];
+          acc[a][0] += ja * b0;
+          acc[a][1] += ja * b1;
+        }
+      }
+      __syncthreads();             // every read of this chunk is done before it is overwritten
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        double* o = x + grow(4 * ti + a) * d + c0 + 2 * tj;
+        o[0] = acc[a][0];
+        o[1] = acc[a][1];
+      }
+    }
+  }
+}
 __global__ void jacobi_sweep_end_kernel(int* flags) {
   if (flags[0]) return;
   if (flags[1] == 0) flags[0] = 1;
@@ -348,7 +508,19 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
   jacobi_init_kernel<<<cdiv((int64_t)d * d, 256), 256, 0, st>>>(v, d, flags);
   CG_CHECK_LAUNCH("cg_syevj_f64(init)");
   const int np = (d + 1) & ~1;
-  if (d > 1) {
+  static const int block_min = []() {
+    const char* e = getenv("CGAMD_JACOBI_BLOCK_MIN");   // smallest d for the block form (0 = off)
+    return e ? atoi(e) : 256;
+  }();
+  if (block_min > 0 && d >= block_min && d % JR == 0) {
+    const int nb = d / JB;   // even
+    for (int s = 0; s < max_sweeps; ++s) {
+      for (int r = 0; r < nb - 1; ++r)
+        bjacobi_round_kernel<<<nb / 2, 256, 0, st>>>(a, v, d, nb, r, tol, flags);
+      jacobi_sweep_end_kernel<<<1, 1, 0, st>>>(flags);
+    }
+    CG_CHECK_LAUNCH("cg_syevj_f64(block sweeps)");
+  } else if (d > 1) {
     for (int s = 0; s < max_sweeps; ++s) {
       for (int r = 0; r < np - 1; ++r) {
         jacobi_round_kernel<<<np / 2, 256, 0, st>>>(a, v, d, np, r, tol, flags);

@@ -80,6 +80,36 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(int kind, const float* __
   }
 }
 
+// SSGAN rotation head (gans/ssgan.py:186-203): loss = -mean_i log(softmax(logits_i)[label_i] +
+// 1e-10) over n rows of k classes, and dlogits = d loss / d logits; one block, fixed order.
+__global__ __launch_bounds__(256) void softmax_xent_eps_kernel(const float* __restrict__ logits,
+                                                               const int* __restrict__ labels,
+                                                               int n, int k, float eps,
+                                                               float* __restrict__ loss,
+                                                               float* __restrict__ dlogits) {
+  __shared__ float sm4[4];
+  const float inv_n = 1.f / (float)n;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float* row = logits + (int64_t)i * k;
+    float mx = row[0];
+    for (int c = 1; c < k; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < k; ++c) se += expf(row[c] - mx);
+    const int y = labels[i];
+    const float py = expf(row[y] - mx) / se;
+    acc += -logf(py + eps);
+    // d(-log(p_y + eps)) / d logit_c = -(p_y / (p_y + eps)) * (delta_yc - p_c)
+    const float w = py / (py + eps) * inv_n;
+    for (int c = 0; c < k; ++c) {
+      const float pc = expf(row[c] - mx) / se;
+      dlogits[(int64_t)i * k + c] = -w * ((c == y ? 1.f : 0.f) - pc);
+    }
+  }
+  acc = block_sum_256(acc, sm4);
+  if (threadIdx.x == 0) *loss = acc * inv_n;
+}
+
 __global__ void interpolate_kernel(const float* __restrict__ x, const float* __restrict__ xf,
                                    const float* __restrict__ alpha, int64_t per, int64_t total,
                                    bf16_t* __restrict__ out) {
@@ -344,6 +374,16 @@ extern "C" int cg_gan_loss(int kind, const float* logits, int B, float* losses, 
   gan_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(kind, logits, B, losses, dlogits_d,
                                                       dlogits_g);
   CG_CHECK_LAUNCH("cg_gan_loss");
+  return CG_OK;
+}
+
+extern "C" int cg_softmax_xent_eps(const float* logits, const int32_t* labels, int n, int k,
+                                   float eps, float* loss, float* dlogits, cgStream stream) {
+  if (!logits || !labels || !loss || !dlogits || n <= 0 || k <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_softmax_xent_eps: bad argument");
+  softmax_xent_eps_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, labels, n, k, eps, loss,
+                                                              dlogits);
+  CG_CHECK_LAUNCH("cg_softmax_xent_eps");
   return CG_OK;
 }
 

@@ -286,7 +286,8 @@ class ModularGAN(AbstractGAN):
                       device=meta)
       y2 = None if y is None else torch.empty((2 * batch_size, y.shape[1]), dtype=y.dtype,
                                               device=meta)
-      self.discriminator(x, y=y2, is_training=True)
+      d_out = self.discriminator(x, y=y2, is_training=True)
+      self._build_heads(x, d_out)     # subclasses create the variables of their extra heads
       self._check_variables()
     if self.device.type == "meta":
       self._built = True
@@ -300,6 +301,11 @@ class ModularGAN(AbstractGAN):
     tpu_random.set_random_offset(seed, self.global_step)
     self._built = True
     return self
+
+  def _build_heads(self, x, d_out):
+    """Shape-only hook of build(): x is the (meta) discriminator input [2B,H,W,C], d_out the
+    discriminator's (prob, logits, features)."""
+    del x, d_out
 
   def _check_variables(self):
     """Every trainable variable belongs to exactly one of G / D (modular_gan.py:345-357)."""

@@ -770,6 +770,22 @@ class GanLossFn(torch.autograd.Function):
     return (out.reshape(ctx.shape) if out is not None else None), None
 
 
+class SoftmaxXentEpsFn(torch.autograd.Function):
+  """-mean_i log(softmax(logits_i)[label_i] + eps) (ssgan.py:191-199), first-order."""
+
+  @staticmethod
+  def forward(ctx, logits, labels, eps):
+    loss, dlogits = K.softmax_xent_eps(logits.contiguous(), labels, eps)
+    ctx.save_for_backward(dlogits)
+    return loss.reshape(())
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, up):
+    (dlogits,) = ctx.saved_tensors
+    return K.scale_f32(dlogits, up.reshape(1).to(F32).contiguous()), None, None
+
+
 class GradientPenaltyFn(torch.autograd.Function):
   """mean((sqrt(1e-4 + sum g^2) - 1)^2) over fp32 input gradients g [B, ...]."""
 

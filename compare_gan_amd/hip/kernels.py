@@ -794,6 +794,19 @@ def gan_loss(kind, logits):
     return losses, dd, dg
 
 
+def softmax_xent_eps(logits, labels, eps=1e-10):
+    """(-mean log(softmax(logits)[label] + eps) as a [1] tensor, dlogits [n,k])."""
+    _req(logits, F32, "logits")
+    if labels.dtype != torch.int32:
+        raise TypeError("labels must be int32")
+    n, k = logits.shape
+    loss = torch.empty((1,), dtype=F32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(lib().cg_softmax_xent_eps(_p(logits), _p(labels), n, k, float(eps), _p(loss),
+                                    _p(dlogits), _stream()), "cg_softmax_xent_eps")
+    return loss, dlogits
+
+
 def interpolate(x, x_fake, alpha):
     _req(x, F32, "x")
     _req(x_fake, F32, "x_fake")

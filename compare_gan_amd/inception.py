@@ -87,6 +87,7 @@ SPEC = [
     ]),
     _mixed_8("mixed_9", "avg3"), _mixed_8("mixed_10", "max3s1"),
 ]
+_CHUNK = int(os.environ.get("CGAMD_INCEPTION_BATCH", "512"))   # images per call of transform()
 POOL3_DIM = 2048
 NUM_LOGITS = 1008
 INPUT_SIZE = 299
@@ -230,9 +231,13 @@ class InceptionV3(object):
     return K.cast_bf16_to_f32(pool3), logits
 
   def transform(self, images_0_255, batch_size=64):
-    """eval_utils.inception_transform_np: batched over a [N, H, W, 3] array (host or device)."""
+    """eval_utils.inception_transform_np: batched over a [N, H, W, 3] array (host or device).
+    The frozen graph has no cross-sample operation, so the features of an image do not depend on
+    how the set is cut into batches: at least _CHUNK images go through per call (the reference's
+    batches of 64 leave the 17x17 and 8x8 stages at a few hundred workgroups per launch)."""
     feats, logits = [], []
     n = images_0_255.shape[0]
+    batch_size = max(int(batch_size), _CHUNK)
     for i in range(0, n, batch_size):
       batch = images_0_255[i:i + batch_size]
       if not torch.is_tensor(batch):

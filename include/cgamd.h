@@ -401,6 +401,11 @@ int cg_attention_bwd(const void* theta, const void* phi, const void* g, const vo
  * ------------------------------------------------------------------------------------------ */
 int cg_gan_loss(int kind, const float* logits, int B, float* losses, float* dlogits_d,
                 float* dlogits_g, cgStream stream);
+/* Rotation loss of the self-supervised GAN (gans/ssgan.py:186-203):
+ *   *loss = -mean_i log(softmax(logits[i, :])[labels[i]] + eps)  (the reference adds eps = 1e-10
+ *   INSIDE the log), dlogits [n,k] = d loss / d logits.  logits fp32 [n,k], labels int32 [n]. */
+int cg_softmax_xent_eps(const float* logits, const int32_t* labels, int n, int k, float eps,
+                        float* loss, float* dlogits, cgStream stream);
 /* interpolates = x + alpha[b] * (x_fake - x)   (penalty_lib.py:72-73), fp32 in, bf16 out. */
 int cg_interpolate(const float* x, const float* x_fake, const float* alpha, int B, int64_t per,
                    void* out_bf16, cgStream stream);

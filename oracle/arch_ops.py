@@ -183,8 +183,10 @@ def unpool(x):
 
 
 def avg_pool2(x):
-  """tf.nn.pool(x, [2,2], 'AVG', 'SAME', strides=[2,2]) (resnet_ops.py:132-133), even sizes."""
-  return F.avg_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+  """tf.nn.pool(x, [2,2], 'AVG', 'SAME', strides=[2,2]) (resnet_ops.py:132-133): output size
+  ceil(size / 2), a window that overhangs the border averages its valid elements only."""
+  return F.avg_pool2d(x.permute(0, 3, 1, 2), 2, 2, ceil_mode=True,
+                      count_include_pad=False).permute(0, 2, 3, 1)
 
 
 def max_pool2(x):

