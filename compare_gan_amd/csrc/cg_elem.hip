@@ -300,6 +300,50 @@ __global__ void pool2d_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
   }
 }
 
+// 8 channels per thread (16-byte loads / stores), C % 8 == 0: the Inception stages pool 64 ... 2048
+// channels and are pure HBM streams; the scalar form above ran at a tenth of the bandwidth
+// (1 ms per call on 512 x 35 x 35 x 288: as much time as all convolutions of the network).
+__global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restrict__ x, int N,
+                                                          int H, int W, int C8, int k, int s,
+                                                          int p, int kind, int Ho, int Wo,
+                                                          bf16_t* __restrict__ y) {
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c8 = (int)(i % C8);
+    int64_t q = i / C8;
+    const int ow = (int)(q % Wo);
+    q /= Wo;
+    const int oh = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = kind == 0 ? -3.4e38f : 0.f;
+    int cnt = 0;
+    for (int r = 0; r < k; ++r) {
+      const int ih = oh * s - p + r;
+      if (ih < 0 || ih >= H) continue;
+      for (int t = 0; t < k; ++t) {
+        const int iw = ow * s - p + t;
+        if (iw < 0 || iw >= W) continue;
+        const uint4 raw = *reinterpret_cast<const uint4*>(
+            x + ((((int64_t)n * H + ih) * W + iw) * C8 + c8) * 8);
+        float v[8];
+        unpack8_bf16(raw, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = kind == 0 ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
+        ++cnt;
+      }
+    }
+    if (kind != 0) {
+      const float d = (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = acc[e] / d;
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8_bf16(acc);
+  }
+}
+
 // TF1 legacy bilinear resize (align_corners=False, half_pixel_centers=False):
 //   src = dst * (in / out);  lo = floor(src), hi = min(lo+1, in-1), frac = src - lo.
 __global__ void inception_preprocess_kernel(const float* __restrict__ x, int N, int H, int W,
@@ -672,6 +716,15 @@ extern "C" int cg_pool2d(const void* x, int N, int H, int W, int C, int k, int s
       Wo <= 0 || (kind != 0 && kind != 1))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_pool2d: bad argument");
   const int64_t total = (int64_t)N * Ho * Wo * C;
+  if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const int64_t units = total / 8;
+    int64_t blocks = (units + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    pool2d_vec8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, N, H, W, C / 8, k, s, p, kind, Ho, Wo, (bf16_t*)y);
+    CG_CHECK_LAUNCH("cg_pool2d");
+    return CG_OK;
+  }
   pool2d_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
       (const bf16_t*)x, N, H, W, C, k, s, p, kind, Ho, Wo, (bf16_t*)y);
   CG_CHECK_LAUNCH("cg_pool2d");

@@ -113,8 +113,29 @@ __global__ void jacobi_init_kernel(double* __restrict__ v, int d, int* __restric
   if (i == 0) {
     flags[0] = 0;  // converged
     flags[1] = 0;  // rotations in current sweep
+    *reinterpret_cast<unsigned long long*>(flags + 2) = 0ull;   // largest squared row norm
   }
 }
+// largest squared row norm of A (ordered as an integer: the values are non-negative doubles)
+__global__ __launch_bounds__(256) void jacobi_scale_kernel(const double* __restrict__ a, int d,
+                                                           int* __restrict__ flags) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const double x = a[(int64_t)blockIdx.x * d + k];
+    s += x * x;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(flags + 2),
+              (unsigned long long)__double_as_longlong(sm[0] + sm[1] + sm[2] + sm[3]));
+}
+// rows whose squared norm fell below this fraction of the largest one are numerically zero (the
+// null space of a rank-deficient matrix): rotating them is noise and would keep the sweeps from
+// ever reporting convergence
+constexpr double JACOBI_NULL_ROW = 1e-26;
 __global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ g,
                                                            double* __restrict__ v, int d, int np,
                                                            int round, double tol,
@@ -159,7 +180,9 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ 
     const double ga = sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3];
     int rot = 0;
     double cs = 1.0, sn = 0.0;
-    if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300) {
+    const double thr = JACOBI_NULL_ROW * __longlong_as_double(
+        (long long)*reinterpret_cast<const unsigned long long*>(flags + 2));
+    if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300 && al > thr && be > thr) {
       const double zeta = (be - al) / (2.0 * ga);
       const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
       cs = 1.0 / sqrt(1.0 + t * t);
@@ -269,7 +292,9 @@ __global__ __launch_bounds__(256) void bjacobi_round_kernel(double* __restrict__
       if (p > q) { const int x = p; p = q; q = x; }
       const double al = M[p][p], be = M[q][q], ga = M[p][q];
       double cs = 1.0, sn = 0.0;
-      if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300) {
+      const double thr = JACOBI_NULL_ROW * __longlong_as_double(
+          (long long)*reinterpret_cast<const unsigned long long*>(flags + 2));
+      if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300 && al > thr && be > thr) {
         const double zeta = (be - al) / (2.0 * ga);
         const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         cs = 1.0 / sqrt(1.0 + tt * tt);
@@ -506,6 +531,7 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
   hipStream_t st = (hipStream_t)stream;
   int* flags = (int*)ws;
   jacobi_init_kernel<<<cdiv((int64_t)d * d, 256), 256, 0, st>>>(v, d, flags);
+  jacobi_scale_kernel<<<d, 256, 0, st>>>(a, d, flags);
   CG_CHECK_LAUNCH("cg_syevj_f64(init)");
   const int np = (d + 1) & ~1;
   static const int block_min = []() {

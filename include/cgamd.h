@@ -490,8 +490,12 @@ int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
                     cgStream stream);
 /* Symmetric eigen-decomposition by parallel cyclic one-sided Jacobi: a [d,d] fp64 symmetric
  * (destroyed), eigenvalues -> w [d] (unsorted), eigenvectors -> ROWS of v [d,d]
- * (a = v^T diag(w) v).  max_sweeps bounds the work; rotation threshold tol (e.g. 1e-14).
- * ws >= cg_syevj_workspace_bytes(d). */
+ * (a = v^T diag(w) v).  A pair of rows is rotated while |<g_p, g_q>| > tol * |g_p| |g_q|
+ * (tol e.g. 1e-12) and neither row is numerically zero (squared norm below 1e-26 of the largest
+ * row of `a`: the null space of a rank-deficient matrix); a sweep without rotations ends the work
+ * on the device (the remaining launches return at once), max_sweeps bounds it.  From d = 256
+ * (d % 32 == 0) the sweeps run in block form: 32 rows per workgroup, their Gram matrix, one cyclic
+ * sweep on it, one pass applying the accumulated rotations.  ws >= cg_syevj_workspace_bytes(d). */
 size_t cg_syevj_workspace_bytes(int d);
 int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,
                  size_t ws_bytes, cgStream stream);

@@ -801,7 +801,7 @@ def test_syevj_block_form(K, dev, d, rank):
     x = rng.randn(rank, d) * (0.2 + rng.rand(d) * 3.0)
     a = x.T @ x / rank
     for name, mat in (("psd", a), ("indefinite", a - 0.5 * np.diag(rng.rand(d)) * np.trace(a) / d)):
-        w, v = K.syevj_f64(torch.from_numpy(mat.copy()).to(dev), max_sweeps=18)
+        w, v = K.syevj_f64(torch.from_numpy(mat.copy()).to(dev), max_sweeps=60, tol=1e-12)
         w, v = w.cpu().numpy(), v.cpu().numpy()
         scale = np.abs(np.linalg.eigvalsh(mat)).max()
         np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(mat), rtol=1e-9,
