@@ -1,4 +1,4 @@
-"""Builds libcgamd.so (the C-ABI HIP library) and the oracle's C pieces in-tree.
+"""Builds libcgamd.so (the C-ABI HIP library) in-tree; the oracle is pure Python, nothing to compile.
 
 hipcc cross-compiles for gfx950 without a GPU.  Usage: python -m compare_gan_amd.csrc.build
 """

@@ -110,6 +110,85 @@ __global__ __launch_bounds__(256) void softmax_xent_eps_kernel(const float* __re
   if (threadIdx.x == 0) *loss = acc * inv_n;
 }
 
+// S3GAN (gans/s3gan.py:118-160): one block per example.
+//   avail[i] = sum_k y[i,k] > 0.5 (a label was passed);  y_out[i,:] = y[i,:] where a label is
+//   available, else the predictor's label: softmax(aux[i,:]) (soft) or one_hot(argmax aux[i,:]).
+//   aux may be NULL (no predictor): y_out = y.
+__global__ __launch_bounds__(256) void s3gan_labels_kernel(const float* __restrict__ aux,
+                                                           const bf16_t* __restrict__ y, int k,
+                                                           int soft, bf16_t* __restrict__ y_out,
+                                                           float* __restrict__ avail) {
+  __shared__ float sm4[4];
+  __shared__ float s_max;
+  __shared__ int s_arg;
+  const int i = blockIdx.x, t = threadIdx.x;
+  const bf16_t* yr = y + (int64_t)i * k;
+  bf16_t* yo = y_out + (int64_t)i * k;
+  float s = 0.f;
+  for (int c = t; c < k; c += 256) s += bf2f(yr[c]);
+  s = block_sum_256(s, sm4);
+  const bool has = s > 0.5f;
+  if (t == 0) avail[i] = has ? 1.f : 0.f;
+  if (has || aux == nullptr) {
+    for (int c = t; c < k; c += 256) yo[c] = yr[c];
+    return;
+  }
+  const float* ar = aux + (int64_t)i * k;
+  if (t == 0) {   // k <= a few thousand: a serial scan keeps tf.arg_max's first-maximum rule
+    float mx = ar[0];
+    int arg = 0;
+    for (int c = 1; c < k; ++c)
+      if (ar[c] > mx) { mx = ar[c]; arg = c; }
+    s_max = mx;
+    s_arg = arg;
+  }
+  __syncthreads();
+  if (!soft) {
+    for (int c = t; c < k; c += 256) yo[c] = c == s_arg ? (bf16_t)0x3f80 : (bf16_t)0;
+    return;
+  }
+  float se = 0.f;
+  for (int c = t; c < k; c += 256) se += expf(ar[c] - s_max);
+  se = block_sum_256(se, sm4);
+  for (int c = t; c < k; c += 256) yo[c] = f2bf(expf(ar[c] - s_max) / se);
+}
+
+// tf.losses.softmax_cross_entropy(labels, logits, weights) with the default reduction
+// SUM_BY_NONZERO_WEIGHTS (s3gan.py:311-313): loss = sum_i w_i * CE_i / #{w_i != 0},
+// CE_i = -sum_k y_ik * log_softmax(logits_i)_k; dlogits = d loss / d logits (labels are constants).
+__global__ __launch_bounds__(256) void softmax_xent_weighted_kernel(
+    const float* __restrict__ logits, const bf16_t* __restrict__ labels,
+    const float* __restrict__ weights, int n, int k, float* __restrict__ loss,
+    float* __restrict__ dlogits) {
+  __shared__ float sm4[4];
+  const int t = threadIdx.x;
+  float cnt = 0.f;
+  for (int i = t; i < n; i += 256) cnt += weights[i] != 0.f ? 1.f : 0.f;
+  cnt = block_sum_256(cnt, sm4);
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+  float acc = 0.f;
+  for (int i = t; i < n; i += 256) {
+    const float* row = logits + (int64_t)i * k;
+    const bf16_t* yr = labels + (int64_t)i * k;
+    float mx = row[0];
+    for (int c = 1; c < k; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f, ys = 0.f, dot = 0.f;
+    for (int c = 0; c < k; ++c) {
+      se += expf(row[c] - mx);
+      const float yv = bf2f(yr[c]);
+      ys += yv;
+      dot += yv * (row[c] - mx);
+    }
+    const float lse = logf(se);
+    const float w = weights[i];
+    acc += w * (ys * lse - dot);
+    for (int c = 0; c < k; ++c)
+      dlogits[(int64_t)i * k + c] = w * inv * (expf(row[c] - mx - lse) * ys - bf2f(yr[c]));
+  }
+  acc = block_sum_256(acc, sm4);
+  if (t == 0) *loss = acc * inv;
+}
+
 __global__ void interpolate_kernel(const float* __restrict__ x, const float* __restrict__ xf,
                                    const float* __restrict__ alpha, int64_t per, int64_t total,
                                    bf16_t* __restrict__ out) {
@@ -384,6 +463,27 @@ extern "C" int cg_softmax_xent_eps(const float* logits, const int32_t* labels, i
   softmax_xent_eps_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, labels, n, k, eps, loss,
                                                               dlogits);
   CG_CHECK_LAUNCH("cg_softmax_xent_eps");
+  return CG_OK;
+}
+
+extern "C" int cg_s3gan_labels(const float* aux_logits, const void* y, int n, int k, int soft,
+                               void* y_out, float* is_label_available, cgStream stream) {
+  if (!y || !y_out || !is_label_available || n <= 0 || k <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_s3gan_labels: bad argument");
+  s3gan_labels_kernel<<<n, 256, 0, (hipStream_t)stream>>>(aux_logits, (const bf16_t*)y, k, soft,
+                                                          (bf16_t*)y_out, is_label_available);
+  CG_CHECK_LAUNCH("cg_s3gan_labels");
+  return CG_OK;
+}
+
+extern "C" int cg_softmax_xent_weighted(const float* logits, const void* labels,
+                                        const float* weights, int n, int k, float* loss,
+                                        float* dlogits, cgStream stream) {
+  if (!logits || !labels || !weights || !loss || !dlogits || n <= 0 || k <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_softmax_xent_weighted: bad argument");
+  softmax_xent_weighted_kernel<<<1, 256, 0, (hipStream_t)stream>>>(
+      logits, (const bf16_t*)labels, weights, n, k, loss, dlogits);
+  CG_CHECK_LAUNCH("cg_softmax_xent_weighted");
   return CG_OK;
 }
 

@@ -135,6 +135,8 @@ SIGNATURES = {
                                  vp, vp, vp, c_sz, vp]),
     "cg_gan_loss": (c_int, [c_int, vp, c_int, vp, vp, vp, vp]),
     "cg_softmax_xent_eps": (c_int, [vp, vp, c_int, c_int, c_f32, vp, vp, vp]),
+    "cg_s3gan_labels": (c_int, [vp, vp, c_int, c_int, c_int, vp, vp, vp]),
+    "cg_softmax_xent_weighted": (c_int, [vp, vp, vp, c_int, c_int, vp, vp, vp]),
     "cg_interpolate": (c_int, [vp, vp, vp, c_int, c_i64, vp, vp]),
     "cg_gradient_penalty": (c_int, [vp, c_int, c_i64, vp, vp, vp]),
     "cg_gradient_penalty_bwd": (c_int, [vp, vp, vp, c_int, c_i64, vp, vp]),

@@ -786,6 +786,24 @@ class SoftmaxXentEpsFn(torch.autograd.Function):
     return K.scale_f32(dlogits, up.reshape(1).to(F32).contiguous()), None, None
 
 
+class SoftmaxXentWeightedFn(torch.autograd.Function):
+  """tf.losses.softmax_cross_entropy(labels, logits, weights) (s3gan.py:311-313), first-order;
+  labels and weights are constants (the reference stops their gradients)."""
+
+  @staticmethod
+  def forward(ctx, logits, labels, weights):
+    loss, dlogits = K.softmax_xent_weighted(logits.contiguous(), labels.contiguous(),
+                                            weights.contiguous())
+    ctx.save_for_backward(dlogits)
+    return loss.reshape(())
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, up):
+    (dlogits,) = ctx.saved_tensors
+    return K.scale_f32(dlogits, up.reshape(1).to(F32).contiguous()), None, None
+
+
 class GradientPenaltyFn(torch.autograd.Function):
   """mean((sqrt(1e-4 + sum g^2) - 1)^2) over fp32 input gradients g [B, ...]."""
 

@@ -807,6 +807,31 @@ def softmax_xent_eps(logits, labels, eps=1e-10):
     return loss, dlogits
 
 
+def s3gan_labels(aux_logits, y, soft):
+    """(y_out bf16 [n,k], is_label_available fp32 [n]): see cg_s3gan_labels."""
+    _req(y, BF16, "y")
+    _req(aux_logits, F32, "aux_logits", True)
+    n, k = y.shape
+    y_out = torch.empty_like(y)
+    avail = torch.empty((n,), dtype=F32, device=y.device)
+    check(lib().cg_s3gan_labels(_p(aux_logits), _p(y), n, k, int(bool(soft)), _p(y_out),
+                                _p(avail), _stream()), "cg_s3gan_labels")
+    return y_out, avail
+
+
+def softmax_xent_weighted(logits, labels, weights):
+    """(loss [1], dlogits [n,k]) of tf.losses.softmax_cross_entropy(labels, logits, weights)."""
+    _req(logits, F32, "logits")
+    _req(labels, BF16, "labels")
+    _req(weights, F32, "weights")
+    n, k = logits.shape
+    loss = torch.empty((1,), dtype=F32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(lib().cg_softmax_xent_weighted(_p(logits), _p(labels), _p(weights), n, k, _p(loss),
+                                         _p(dlogits), _stream()), "cg_softmax_xent_weighted")
+    return loss, dlogits
+
+
 def interpolate(x, x_fake, alpha):
     _req(x, F32, "x")
     _req(x_fake, F32, "x_fake")

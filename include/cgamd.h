@@ -406,6 +406,17 @@ int cg_gan_loss(int kind, const float* logits, int B, float* losses, float* dlog
  *   INSIDE the log), dlogits [n,k] = d loss / d logits.  logits fp32 [n,k], labels int32 [n]. */
 int cg_softmax_xent_eps(const float* logits, const int32_t* labels, int n, int k, float eps,
                         float* loss, float* dlogits, cgStream stream);
+/* S3GAN label handling (gans/s3gan.py:118-160): is_label_available[i] = sum_k y[i,k] > 0.5;
+ * y_out[i,:] = y[i,:] where a label is available, otherwise the predictor's label --
+ * softmax(aux_logits[i,:]) (soft != 0) or one_hot(argmax) -- y / y_out bf16 [n,k], aux_logits fp32
+ * [n,k] or NULL (no predictor: y_out = y). */
+int cg_s3gan_labels(const float* aux_logits, const void* y, int n, int k, int soft, void* y_out,
+                    float* is_label_available, cgStream stream);
+/* tf.losses.softmax_cross_entropy(labels, logits, weights) with SUM_BY_NONZERO_WEIGHTS
+ * (gans/s3gan.py:311-313): *loss = sum_i w_i CE_i / #{w_i != 0}; dlogits [n,k].  labels bf16 [n,k]
+ * (one-hot or soft), logits fp32 [n,k], weights fp32 [n]. */
+int cg_softmax_xent_weighted(const float* logits, const void* labels, const float* weights, int n,
+                             int k, float* loss, float* dlogits, cgStream stream);
 /* interpolates = x + alpha[b] * (x_fake - x)   (penalty_lib.py:72-73), fp32 in, bf16 out. */
 int cg_interpolate(const float* x, const float* x_fake, const float* alpha, int B, int64_t per,
                    void* out_bf16, cgStream stream);

@@ -218,3 +218,95 @@ class OracleSSGAN(OracleGAN):
   def d_var_names(self):
     # "discriminator_rotation/..." matches the scope prefix "discriminator" (abstract_arch.py:43-45)
     return [n for n in self.vs.trainable if n.startswith("discriminator")]
+
+
+class OracleS3GAN(OracleGAN):
+  """gans/s3gan.py:39-321: projection on the (inferred) label, predictor head, rotation head."""
+
+  def __init__(self, *args, self_supervision="rotation", rotated_batch_fraction=2,
+               weight_rotation_loss_d=1.0, weight_rotation_loss_g=0.2, project_y=False,
+               use_predictor=False, use_soft_pred=False, weight_class_loss=1.0, **kwargs):
+    super(OracleS3GAN, self).__init__(*args, **kwargs)
+    if use_predictor and not project_y:
+      raise ValueError("Using predictor requires projection.")
+    self.self_supervision = self_supervision
+    self.rotated_batch_fraction = rotated_batch_fraction
+    self.w_rot_d, self.w_rot_g = weight_rotation_loss_d, weight_rotation_loss_g
+    self.project_y, self.use_predictor = project_y, use_predictor
+    self.use_soft_pred, self.w_class = use_soft_pred, weight_class_loss
+
+  def one_hot(self, labels):
+    """Label -1 = no label: an all-zero row (s3gan.py:112)."""
+    lab = labels.long()
+    oh = F.one_hot(lab.clamp(min=0), self.num_classes).to(self.vs.dtype)
+    return oh * (lab >= 0).to(self.vs.dtype).unsqueeze(1)
+
+  def heads(self, x, y):
+    """s3gan.py:98-162."""
+    from oracle import arch_ops as ops
+    d_probs, d_logits, x_rep = self.D(x, y)
+    sn, sn_cfg = self.d_cfg.spectral_norm, self.d_cfg.sn_cfg
+    avail = (y.sum(dim=1, keepdim=True) > 0.5).to(y.dtype)                      # :118-119
+    rot = None
+    if "rotation" in self.self_supervision:
+      rot = ops.linear(self.vs, x_rep, 4, "discriminator_rotation/score_classify", sn_cfg,
+                       use_sn=sn, out_f32=True)                                  # :123-130
+    if not self.project_y:
+      return d_probs, d_logits, rot, None, avail
+    aux = None
+    if self.use_predictor:
+      aux = ops.linear(self.vs, x_rep, y.shape[1], "discriminator_predictor/predictor_linear",
+                       sn_cfg, use_sn=sn, out_f32=True)                          # :138-141
+      if self.use_soft_pred:
+        y_pred = torch.softmax(aux, dim=1)
+      else:
+        y_pred = F.one_hot(aux.argmax(dim=1), aux.shape[1]).to(y.dtype)
+      y = ((1.0 - avail) * y_pred + avail * y).detach()                          # :147-148
+    emb = ops.linear(self.vs, self.vs.q(y), x_rep.shape[-1], "discriminator_projection", sn_cfg,
+                     use_sn=sn, use_bias=False, kernel_init=self.vs.glorot_normal_init())
+    d_logits = d_logits + (emb * x_rep).sum(dim=1, keepdim=True)                 # :157
+    return torch.sigmoid(d_logits), d_logits, rot, aux, avail
+
+  def create_loss(self, images, generated, labels, sampled_labels, alpha=None, with_penalty=True):
+    assert self.conditional
+    bs = images.shape[0]
+    real_y, fake_y = self.one_hot(labels), self.one_hot(sampled_labels)
+    rotation = self.self_supervision == "rotation"
+    rotated_bs = bs // self.rotated_batch_fraction
+    nrot = rotated_bs // 4
+    if rotation:                                                                 # :178-196
+      real_rot = rotate_images(images[bs - nrot:], (1, 2, 3))
+      fake_rot = rotate_images(generated[bs - nrot:], (1, 2, 3))
+      all_x = torch.cat([images, real_rot, generated, fake_rot], 0)
+      all_y = torch.cat([real_y, real_y[bs - nrot:].repeat(3, 1), fake_y,
+                         fake_y[bs - nrot:].repeat(3, 1)], 0)
+    else:
+      all_x, all_y = torch.cat([images, generated], 0), torch.cat([real_y, fake_y], 0)
+    d_pred, d_logits, rot, aux, avail = self.heads(all_x, all_y)
+    half = d_logits.shape[0] // 2
+    d_loss, _, _, g_loss = ogan.get_losses(self.loss, d_pred[:half][:bs], d_pred[half:][:bs],
+                                           d_logits[:half][:bs], d_logits[half:][:bs])
+    self.rot_real_loss = self.rot_fake_loss = self.class_loss_real = None
+    if rotation:                                                                 # :283-296
+      lab = torch.arange(4).repeat_interleave(nrot)
+      onehot = F.one_hot(lab, 4).to(rot.dtype)
+      rr, rf = rot[:half][half - rotated_bs:], rot[half:][half - rotated_bs:]
+      real_loss = -(onehot * torch.log(torch.softmax(rr, -1) + 1e-10)).sum(1).mean()
+      fake_loss = -(onehot * torch.log(torch.softmax(rf, -1) + 1e-10)).sum(1).mean()
+      d_loss = d_loss + real_loss * self.w_rot_d
+      g_loss = g_loss + fake_loss * self.w_rot_g
+      self.rot_real_loss, self.rot_fake_loss = float(real_loss.detach()), float(fake_loss.detach())
+    if self.use_predictor:                                                       # :306-314
+      w = avail[:half][:bs].reshape(-1)
+      ce = -(real_y * torch.log_softmax(aux[:half][:bs], dim=1)).sum(1)
+      cnt = (w != 0).sum().clamp(min=1).to(ce.dtype)
+      class_loss = (w * ce).sum() / cnt          # Reduction.SUM_BY_NONZERO_WEIGHTS
+      d_loss = d_loss + self.w_class * class_loss
+      self.class_loss_real = float(class_loss.detach())
+    return d_loss, g_loss, d_logits
+
+  def d_vars(self):
+    return [self.vs.vars[n] for n in self.d_var_names()]
+
+  def d_var_names(self):
+    return [n for n in self.vs.trainable if n.startswith("discriminator")]
