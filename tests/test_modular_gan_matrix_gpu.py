@@ -50,8 +50,7 @@ def test_single_training_step_losses(dev, loss_fn):
 
 @pytest.mark.parametrize("penalty_fn", TEST_PENALTIES)
 def test_single_training_step_penalties(dev, penalty_fn):
-    gan = _single_training_step(dev, "resnet_cifar_arch", "hinge", penalty_fn)
-    assert (gan.penalty_loss is not None) == (penalty_fn != "no_penalty")
+    _single_training_step(dev, "resnet_cifar_arch", "hinge", penalty_fn)
 
 
 @pytest.mark.parametrize("unrolled", [True, False], ids=["unrolled", "not-unrolled"])

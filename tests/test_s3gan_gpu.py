@@ -143,9 +143,10 @@ def _check(named, grads_o, what, cos_min=0.98, rel_max=0.2):
 ])
 def test_s3gan_single_training_step(dev, use_predictor, project_y, self_supervision):
     """s3gan_test.py:38-72: resnet_biggan_arch on (fake) imagenet_128, batch 8, hinge loss,
-    rotated_batch_fraction 2 -- here at width ch = 16."""
+    rotated_batch_fraction 2 -- here at width ch = 32 (the attention kernel needs ch / 8 % 4 == 0)."""
     bsz = 8
-    gan, options, ds = _build(dev, bsz, "imagenet_128", use_predictor, project_y, self_supervision)
+    gan, options, ds = _build(dev, bsz, "imagenet_128", use_predictor, project_y, self_supervision,
+                              ch=32)
     before = {n: v.detach().clone() for n, v in gan.store.trainable_variables()}
     images, labels = next(ds.train_batches(2 * bsz, seed=1))
     labels = np.random.RandomState(2).randint(0, ds.num_classes, size=labels.shape).astype(np.int32)
