@@ -32,6 +32,7 @@ def set_random_offset(seed, step_tensor):
   (device int64 tensor) and the run seed used by subsequent calls."""
   _st()["seed"] = int(seed)
   _st()["step"] = step_tensor
+  _st()["sub_step"] = 0     # a (re)bound stream starts at the first sub-step
 
 
 def set_sub_step(index):

@@ -83,7 +83,7 @@ def main():
             if float(du.norm()) == 0.0:
                 continue
             cos = float(torch.dot(du, dv) / (du.norm() * dv.norm()))
-            if cos < 0.99:
+            if cos < 0.98:
                 low.append((k, round(cos, 4)))
         worst = num / (den_u * den_v) ** 0.5
         stage("low-cosine variables: %s" % (low,))
