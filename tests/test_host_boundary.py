@@ -320,3 +320,41 @@ def test_remaining_architectures_build_like_the_oracle(arch, image_shape):
   assert 0.0 <= float(prob.min()) and float(prob.max()) <= 1.0
   oracle = {n: tuple(v.shape) for n, v in vs.vars.items()}
   assert oracle == product
+
+
+def test_ssgan_s3gan_heads_and_rotations():
+  """gans/ssgan.py:79-102 and gans/s3gan.py:98-176 on the shape-only device: the auxiliary heads
+  live under scopes that D's scope prefix matches (so they train with D), in the reference's
+  creation order; and rotate_images (gans/utils.py:38-50) against the oracle's index form."""
+  import numpy as np
+  from compare_gan_amd.gans import s3gan, ssgan   # noqa: F401  (register SSGAN / S3GAN)
+  from oracle import modular_gan as omg
+  x = torch.arange(2 * 4 * 4 * 3, dtype=torch.float32).reshape(2, 4, 4, 3)
+  assert torch.equal(ssgan.rotate_images(x, (1, 2, 3)), omg.rotate_images(x, (1, 2, 3)))
+  assert torch.equal(ssgan.rotate_images(x), omg.rotate_images(x))
+  assert np.array_equal(ssgan.rotate_images(x, (1,)).numpy(), np.rot90(x.numpy(), 1, axes=(1, 2)))
+  gan, _, _ = U.build_product("resnet_cifar10.gin", 4, "meta", bindings=(
+      "options.gan_class = @SSGAN", "SSGAN.rotated_batch_size = 4"))
+  heads = [n for n, _ in gan.store.trainable_variables("discriminator")
+           if not n.startswith("discriminator/")]
+  assert heads == ["discriminator_rotation/score_classify/kernel",
+                   "discriminator_rotation/score_classify/bias"]
+  assert tuple(gan.store.vars[heads[0]].shape) == (128, 4)
+  with pytest.raises(Exception):      # rotated_batch_size is gin.REQUIRED (ssgan.py:48)
+    U.build_product("resnet_cifar10.gin", 4, "meta", bindings=("options.gan_class = @SSGAN",))
+  gan, _, _ = U.build_product("biggan_imagenet128.gin", 8, "meta", bindings=(
+      "options.gan_class = @S3GAN", "S3GAN.rotated_batch_fraction = 2", "S3GAN.use_predictor = True",
+      "S3GAN.project_y = True", "resnet_biggan.Generator.ch = 16",
+      "resnet_biggan.Discriminator.ch = 16"))
+  heads = [n for n, _ in gan.store.trainable_variables("discriminator")
+           if not n.startswith("discriminator/")]
+  assert heads == ["discriminator_rotation/score_classify/kernel",
+                   "discriminator_rotation/score_classify/bias",
+                   "discriminator_predictor/predictor_linear/kernel",
+                   "discriminator_predictor/predictor_linear/bias",
+                   "discriminator_projection/kernel"]
+  assert tuple(gan.store.vars["discriminator_projection/kernel"].shape) == (1000, 16 * 16)
+  with pytest.raises(ValueError):     # s3gan.py:80-81
+    U.build_product("biggan_imagenet128.gin", 8, "meta", bindings=(
+        "options.gan_class = @S3GAN", "S3GAN.rotated_batch_fraction = 2",
+        "S3GAN.use_predictor = True", "S3GAN.project_y = False"))
