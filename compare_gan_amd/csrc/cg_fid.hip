@@ -250,13 +250,28 @@ __global__ __launch_bounds__(256) void bjacobi_round_kernel(double* __restrict__
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    // the next chunk's loads are in flight while this one is multiplied (only 64 workgroups are
+    // resident: a round is bound by the latency of its serial chunk loads, not by bandwidth)
+    double cur[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = t + 256 * e;
+      cur[e] = g[grow(idx >> 6) * d + (idx & 63)];
+    }
     for (int c0 = 0; c0 < d; c0 += JCW) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int idx = t + 256 * e, r = idx >> 6, k = idx & 63;
-        Tt[k][r] = g[grow(r) * d + c0 + k];
+        const int idx = t + 256 * e;
+        Tt[idx & 63][idx >> 6] = cur[e];
       }
       __syncthreads();
+      if (c0 + JCW < d) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = t + 256 * e;
+          cur[e] = g[grow(idx >> 6) * d + c0 + JCW + (idx & 63)];
+        }
+      }
       for (int k = w; k < JCW; k += 4) {
         double a[4], b[4];
 #pragma unroll
@@ -337,15 +352,35 @@ __global__ __launch_bounds__(256) void bjacobi_round_kernel(double* __restrict__
 
   // ---- 3. rows <- J rows, for G and V; thread tile 4 rows x 2 columns of a 32 x 64 chunk
   const int ti = t >> 5, tj = t & 31;
-  for (int which = 0; which < 2; ++which) {
-    double* __restrict__ x = which == 0 ? g : v;
-    for (int c0 = 0; c0 < d; c0 += JCW) {
+  // chunks of G then of V as one stream of 2 * d / JCW chunks, the next one prefetched
+  const int nchunks = 2 * (d / JCW);
+  auto chunk_ptr = [&](int ci) -> double* { return (ci < d / JCW ? g : v); };
+  auto chunk_col = [&](int ci) -> int { return (ci < d / JCW ? ci : ci - d / JCW) * JCW; };
+  double cur[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = t + 256 * e;
+    cur[e] = g[grow(idx >> 6) * d + (idx & 63)];
+  }
+  for (int ci = 0; ci < nchunks; ++ci) {
+    double* __restrict__ x = chunk_ptr(ci);
+    const int c0 = chunk_col(ci);
+    {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int idx = t + 256 * e, r = idx >> 6, k = idx & 63;
-        Tt[k][r] = x[grow(r) * d + c0 + k];
+        const int idx = t + 256 * e;
+        Tt[idx & 63][idx >> 6] = cur[e];
       }
       __syncthreads();
+      if (ci + 1 < nchunks) {
+        const double* __restrict__ xn = chunk_ptr(ci + 1);
+        const int cn = chunk_col(ci + 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = t + 256 * e;
+          cur[e] = xn[grow(idx >> 6) * d + cn + (idx & 63)];
+        }
+      }
       double acc[4][2];
 #pragma unroll
       for (int a = 0; a < 4; ++a) acc[a][0] = acc[a][1] = 0.0;
@@ -538,7 +573,7 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
     const char* e = getenv("CGAMD_JACOBI_BLOCK_MIN");   // smallest d for the block form (0 = off)
     return e ? atoi(e) : 256;
   }();
-  if (block_min > 0 && d >= block_min && d % JR == 0) {
+  if (block_min > 0 && d >= block_min && d % JCW == 0) {   // whole 64-column chunks, nb even
     const int nb = d / JB;   // even
     for (int s = 0; s < max_sweeps; ++s) {
       for (int r = 0; r < nb - 1; ++r)

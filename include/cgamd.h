@@ -505,7 +505,7 @@ int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
  * (tol e.g. 1e-12) and neither row is numerically zero (squared norm below 1e-26 of the largest
  * row of `a`: the null space of a rank-deficient matrix); a sweep without rotations ends the work
  * on the device (the remaining launches return at once), max_sweeps bounds it.  From d = 256
- * (d % 32 == 0) the sweeps run in block form: 32 rows per workgroup, their Gram matrix, one cyclic
+ * (d % 64 == 0) the sweeps run in block form: 32 rows per workgroup, their Gram matrix, one cyclic
  * sweep on it, one pass applying the accumulated rotations.  ws >= cg_syevj_workspace_bytes(d). */
 size_t cg_syevj_workspace_bytes(int d);
 int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,

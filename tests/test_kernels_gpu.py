@@ -791,10 +791,10 @@ def test_fid_statistics(K, dev):
     assert abs(float(sc) - ofid.classifier_score_from_logits(logits)) < 1e-9 * float(sc)
 
 
-@pytest.mark.parametrize("d,rank", [(256, 256), (512, 200), (96, 96)])
+@pytest.mark.parametrize("d,rank", [(256, 256), (512, 200), (96, 96), (288, 288)])
 def test_syevj_block_form(K, dev, d, rank):
     """cg_syevj_f64 on matrices large enough for the block form of the Jacobi sweeps (d >= 256,
-    d % 32 == 0; 96 takes the scalar rounds): eigenvalues against numpy's eigvalsh, the
+    d % 64 == 0; 96 and 288 take the scalar rounds): eigenvalues against numpy's eigvalsh, the
     reconstruction V^T diag(w) V and the orthonormality of V -- full-rank and rank-deficient PSD
     matrices (a covariance of n < d samples has d - n zero eigenvalues), and an indefinite one."""
     rng = np.random.RandomState(d + rank)
