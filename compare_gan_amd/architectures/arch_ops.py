@@ -274,6 +274,12 @@ def _split_act(inputs):
   return inputs, None
 
 
+def fork(x):
+  """Two aliases of a block input that feeds both the shortcut and the main branch: their gradient
+  contributions are summed by a HIP launch (Fn.ForkFn).  Pending activations are materialised."""
+  return Fn.fork(as_tensor(x))
+
+
 def relu(x):
   """tf.nn.relu as a pending activation (resnet_ops.py:165,175)."""
   return Act(x, 0.0)

@@ -26,7 +26,10 @@ class BigGanResNetBlock(resnet_ops.ResNetBlock):
       raise ValueError("Unexpected number of input channels (expected {}, got {}).".format(
           self._in_channels, inputs.shape[-1]))
     with ops.variable_scope(self._name):
-      outputs = self.batch_norm_relu(inputs, z=z, y=y, is_training=is_training, name="bn1")
+      inputs_main = inputs
+      if self._add_shortcut and resnet_ops._FORK:   # pylint: disable=protected-access
+        inputs, inputs_main = ops.fork(inputs)
+      outputs = self.batch_norm_relu(inputs_main, z=z, y=y, is_training=is_training, name="bn1")
       outputs = self._get_conv(outputs, self._in_channels, self._out_channels, self._scale1,
                                suffix="conv1")
       outputs = self.batch_norm_relu(outputs, z=z, y=y, is_training=is_training, name="bn2")

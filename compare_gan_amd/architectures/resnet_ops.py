@@ -13,6 +13,10 @@ from compare_gan_amd.architectures import abstract_arch
 from compare_gan_amd.architectures import arch_ops as ops
 
 
+import os as _os
+_FORK = _os.environ.get("CGAMD_FORK", "1") != "0"   # A/B switch (read once)
+
+
 def unpool(value, name="unpool"):
   """Zero-insertion 2x upsampling (resnet_ops.py:35-56) as a stand-alone op: a 1x1 identity gather
   is never needed on the hot path (conv2d(upsample=True) fuses it); kept for API parity."""
@@ -102,9 +106,13 @@ class ResNetBlock(object):
               ops.conv_pool_supported(inputs, self._out_channels, 3, 3) and
               ops.conv_pool_supported(_Shape(inputs, self._out_channels), self._out_channels,
                                       3, 3))
+      if _FORK:
+        inputs, inputs_main = ops.fork(inputs)
+      else:
+        inputs_main = inputs
       shortcut = self._get_conv(inputs, self._in_channels, self._out_channels, self._scale,
                                 suffix="conv_shortcut", pool=fuse)
-      output = self.batch_norm_relu(inputs, z=z, y=y, is_training=is_training, name="bn1")
+      output = self.batch_norm_relu(inputs_main, z=z, y=y, is_training=is_training, name="bn1")
       output = self._get_conv(output, self._in_channels, self._out_channels, self._scale1,
                               suffix="conv1")
       output = self.batch_norm_relu(output, z=z, y=y, is_training=is_training, name="bn2")

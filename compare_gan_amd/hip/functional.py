@@ -770,6 +770,50 @@ class GanLossFn(torch.autograd.Function):
     return (out.reshape(ctx.shape) if out is not None else None), None
 
 
+class SumFn(torch.autograd.Function):
+  """a + b (bf16 or fp32, same shape) as a HIP launch; linear, so differentiable to any order."""
+
+  @staticmethod
+  def forward(ctx, a, b):
+    a, b = a.contiguous(), b.contiguous()
+    if a.dtype != b.dtype:
+      a = a if a.dtype == F32 else K.cast_bf16_to_f32(a)
+      b = b if b.dtype == F32 else K.cast_bf16_to_f32(b)
+    return K.axpby_f32(a, 1.0, b, 1.0) if a.dtype == F32 else K.axpby(a, 1.0, b, 1.0)
+
+  @staticmethod
+  def backward(ctx, d):
+    return d, d
+
+
+class ForkFn(torch.autograd.Function):
+  """A tensor with TWO consumers (a residual block's input feeds the shortcut and the main branch,
+  resnet_ops.py:156-181): returns two aliases of it, and sums the two gradient contributions with
+  a HIP launch -- otherwise autograd accumulates them with a torch add, the one piece of hot-path
+  arithmetic that would run outside libcgamd.so."""
+
+  @staticmethod
+  def forward(ctx, x):
+    ctx.set_materialize_grads(False)
+    return x.view_as(x), x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, g1, g2):
+    if g1 is None or g2 is None:
+      return g1 if g2 is None else g2
+    if torch.is_grad_enabled():
+      return SumFn.apply(g1, g2)
+    with torch.no_grad():
+      return SumFn.forward(None, g1, g2)
+
+
+def fork(x):
+  """(x, x) for two consumers when a gradient will flow back; plain aliases otherwise."""
+  if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and not x.is_meta:
+    return ForkFn.apply(x)
+  return x, x
+
+
 class SoftmaxXentEpsFn(torch.autograd.Function):
   """-mean_i log(softmax(logits_i)[label_i] + eps) (ssgan.py:191-199), first-order."""
 
