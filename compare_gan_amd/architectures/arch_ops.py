@@ -264,6 +264,7 @@ class statistics_groups(object):
 import os as _os
 _FUSED_BN = _os.environ.get("CGAMD_FUSED_BN", "1") != "0"   # A/B switch (read once)
 _FUSED_POOL = _os.environ.get("CGAMD_FUSED_POOL", "1") != "0"
+_PAD_ATTENTION = _os.environ.get("CGAMD_PAD_ATTENTION", "1") != "0"
 
 
 def _split_act(inputs):
@@ -366,7 +367,7 @@ def prepare_module(module):
 # linear / conv2d / deconv2d (arch_ops.py:538-592)
 # ------------------------------------------------------------------------------------------------
 def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f32, pending_bn=None,
-               pool=False):
+               pool=False, padded=False):
   """Runs inside the weight's variable scope: the kernel variable is <scope>/kernel.
   pending_bn: the PendingBN whose tensor `x` is (conv2d only).  pool: 2x2 average pooling fused
   behind the convolution (residual at the pooled size; callers check conv_pool_supported)."""
@@ -380,6 +381,8 @@ def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f3
       shape = (shape[0], shape[1] // 2, shape[2] // 2, shape[3])
     return torch.empty(shape, dtype=F32 if out_f32 else BF16, device="meta")
   bt_pair = store.bt_ready.pop(wname, None)
+  if padded:
+    bt_pair = None     # the operand images prepared per module have the variable's own shape
   if pool:
     if pending_bn is not None:
       x = pending_bn.materialize()
@@ -440,7 +443,8 @@ def conv_pool_supported(inputs, output_dim, k_h, k_w):
 
 
 def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", use_sn=False,
-           use_bias=True, upsample=False, residual=None, out_f32=False, dx_f32=False, pool=False):
+           use_bias=True, upsample=False, residual=None, out_f32=False, dx_f32=False, pool=False,
+           pad_out_to=None, logical_in=None):
   """2-D convolution, TF 'SAME' padding (arch_ops.py:559-573).
 
   Extensions that keep the reference semantics but fuse its neighbours into the kernel:
@@ -454,18 +458,32 @@ def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", u
   if d_h != d_w:
     raise ValueError("conv2d: only equal strides are supported (got %d, %d)" % (d_h, d_w))
   n, h, w_, ci = x.shape
+  # Channel padding (the self-attention block's 12 / 24 / 48-channel projections): the VARIABLE
+  # keeps the reference's shape [k_h, k_w, logical_in or ci, output_dim]; the kernel that runs sees
+  # it zero-padded to `pad_out_to` output channels / to the `ci` (already padded) input channels,
+  # so that the MFMA-tiled kernels apply (they slice K in 32-channel granules).  Zero rows /
+  # columns change nothing in the arithmetic of the real channels.
+  ci_var = ci if logical_in is None else int(logical_in)
+  co_run = output_dim if pad_out_to is None else int(pad_out_to)
+  resized = ci_var != ci or co_run != output_dim
+  padded = resized and not x.is_meta
   with variable_scope(name):
-    w = get_variable("kernel", [k_h, k_w, ci, output_dim], weight_initializer(stddev=stddev))
+    w = get_variable("kernel", [k_h, k_w, ci_var, output_dim], weight_initializer(stddev=stddev))
     if use_sn:
       w = spectral_norm(w, build_only=x.is_meta)
     bias = get_variable("bias", [output_dim], constant(0.0)) if use_bias else None
+    if padded:
+      if bias is not None and co_run != output_dim:
+        bias = torch.nn.functional.pad(bias, (0, co_run - output_dim))
+      w = torch.nn.functional.pad(w, (0, co_run - output_dim, 0, ci - ci_var))   # data movement
+    output_dim = co_run
     geom = K.geom_conv_same(n, h, w_, ci, output_dim, k_h, k_w, d_h, 2 if upsample else 1)
     # gradients w.r.t. image-like inputs (the network input) are kept in fp32: they feed the
     # gradient penalty's norm (penalty_lib.py:77-78) and the generator's output head
     if pool and (upsample or d_h != 1):
       raise ValueError("conv2d: pool=True needs a unit-stride convolution without upsampling")
     return _conv_call(x, slope, w, bias, geom, False, residual, out_f32, dx_f32 or ci <= 4,
-                      pending_bn, pool)
+                      pending_bn, pool, padded=resized)
 
 
 def conv1x1(inputs, output_dim, **kwargs):
@@ -746,16 +764,24 @@ def non_local_block(x, name, use_sn):
   with variable_scope(name):
     n, h, w, c = x.shape
     ca, cg = c // 8, c // 2
-    theta = conv1x1(x, ca, name="conv2d_theta", use_sn=use_sn, use_bias=False)
-    phi = max_pool2(conv1x1(x, ca, name="conv2d_phi", use_sn=use_sn, use_bias=False))
-    g = max_pool2(conv1x1(x, cg, name="conv2d_g", use_sn=use_sn, use_bias=False))
+    # the projections run padded to multiples of 32 channels (zero kernel columns): at ch = 96 the
+    # discriminator's block has 12 / 48 of them, which would leave its six 1x1 convolutions and their
+    # gradients to the generic gather kernel at 3-25 TFLOP/s (7 % of the BigGAN-128 step)
+    cap, cgp = (ca + 31) // 32 * 32, (cg + 31) // 32 * 32
+    if not _PAD_ATTENTION or c % 32:
+      cap, cgp = ca, cg
+    theta = conv1x1(x, ca, name="conv2d_theta", use_sn=use_sn, use_bias=False, pad_out_to=cap)
+    phi = max_pool2(conv1x1(x, ca, name="conv2d_phi", use_sn=use_sn, use_bias=False,
+                            pad_out_to=cap))
+    g = max_pool2(conv1x1(x, cg, name="conv2d_g", use_sn=use_sn, use_bias=False, pad_out_to=cgp))
     if x.is_meta:
-      attn_g = torch.empty((n, h, w, cg), dtype=BF16, device="meta")
+      attn_g = torch.empty((n, h, w, cgp), dtype=BF16, device="meta")
     else:
-      attn_g = Fn.AttentionFn.apply(theta.reshape(n, h * w, ca), phi.reshape(n, h * w // 4, ca),
-                                    g.reshape(n, h * w // 4, cg)).reshape(n, h, w, cg)
+      attn_g = Fn.AttentionFn.apply(theta.reshape(n, h * w, cap), phi.reshape(n, h * w // 4, cap),
+                                    g.reshape(n, h * w // 4, cgp)).reshape(n, h, w, cgp)
     sigma = get_variable("sigma", [], constant(0.0))
-    attn_g = conv1x1(attn_g, c, name="conv2d_attn_g", use_sn=use_sn, use_bias=False)
+    attn_g = conv1x1(attn_g, c, name="conv2d_attn_g", use_sn=use_sn, use_bias=False,
+                     logical_in=cg)
     if x.is_meta:
       return x
     return Fn.ScaledResidualFn.apply(x, attn_g, sigma.reshape(1))
