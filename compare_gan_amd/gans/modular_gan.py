@@ -553,12 +553,10 @@ class ModularGAN(AbstractGAN):
     batch-norm moving averages -- a spectrally normalised generator runs one power iteration per
     call (arch_ops.py:479-535), so it keeps its separate calls."""
     n = self._disc_iters
-    joint = self._experimental_joint_gen_for_disc
-    if n < 2:
+    groups = self.joint_generation_groups()
+    if groups is None:
       return
-    if not joint:
-      if not _JOINT_G or self.store.sn_registry.get(self.generator.name):
-        return
+    joint = groups == 1
     with torch.no_grad():
       z = torch.cat([f["z"] for f in fs[:n]], dim=0)
       sampled_y = None
@@ -571,6 +569,19 @@ class ModularGAN(AbstractGAN):
     bsz = z.shape[0] // n
     for i in range(n):
       fs[i]["generated"] = generated[i * bsz:(i + 1) * bsz]
+
+  def joint_generation_groups(self):
+    """How train_step() runs the generator forwards of the discriminator sub-steps: None =
+    one call per sub-step; 1 = one joint call with joint batch-norm statistics (the reference's
+    experimental_joint_gen_for_disc); disc_iters = one batched call with one set of statistics
+    per sub-step (same arithmetic as separate calls, only for generators without per-call state)."""
+    if self._disc_iters < 2:
+      return None
+    if self._experimental_joint_gen_for_disc:
+      return 1
+    if not _JOINT_G or self.store.sn_registry.get(self.generator.name):
+      return None
+    return self._disc_iters
 
   def _disc_sub_step(self, features, labels):
     """G forward (no gradient) on the sub-step's z + one D update (modular_gan.py:465-485)."""

@@ -358,3 +358,26 @@ def test_ssgan_s3gan_heads_and_rotations():
     U.build_product("biggan_imagenet128.gin", 8, "meta", bindings=(
         "options.gan_class = @S3GAN", "S3GAN.rotated_batch_fraction = 2",
         "S3GAN.use_predictor = True", "S3GAN.project_y = False"))
+
+
+def test_joint_generation_policy():
+  """ModularGAN.joint_generation_groups(): the generator forwards of the discriminator sub-steps
+  are batched with per-sub-step statistics only when that is the arithmetic of the separate calls
+  (modular_gan.py:464-467) -- not for a spectrally normalised generator (one power iteration per
+  call, arch_ops.py:479-535) -- and jointly (one statistics group) under the reference's
+  experimental_joint_gen_for_disc (modular_gan.py:444-458)."""
+  gan, _, _ = U.build_product("resnet_cifar10.gin", 2, "meta")
+  assert gan.joint_generation_groups() == 5                       # disc_iters = 5, G without SN
+  gan, _, _ = U.build_product("resnet_cifar10.gin", 2, "meta", bindings=("options.disc_iters = 1",))
+  assert gan.joint_generation_groups() is None
+  gan, _, _ = U.build_product("resnet_cifar10.gin", 2, "meta",
+                              bindings=("ModularGAN.experimental_joint_gen_for_disc = True",))
+  assert gan.joint_generation_groups() == 1
+  bind = ("resnet_biggan.Generator.ch = 16", "resnet_biggan.Discriminator.ch = 16")
+  gan, _, _ = U.build_product("biggan_imagenet128.gin", 2, "meta", bindings=bind)
+  assert gan.joint_generation_groups() is None                    # G.spectral_norm = True
+  gan, _, _ = U.build_product("biggan_imagenet128.gin", 2, "meta", bindings=bind + (
+      "ModularGAN.experimental_joint_gen_for_disc = True",))
+  assert gan.joint_generation_groups() == 1
+  with pytest.raises(ValueError):     # modular_gan.py:538-540
+    gan.train_step_not_unrolled(torch.empty((2, 128, 128, 3)), torch.empty((2,), dtype=torch.int32))
