@@ -118,6 +118,8 @@ enum {
   CG_PROF_FAST_WGRAD_64,          // fast_wgrad_kernel<64, *> (+ split reduce)
   CG_PROF_STEM_WGRAD,             // stem_wgrad_kernel<*> incl. the narrow-output (adjoint) form
   CG_PROF_GWGRAD_GENERIC,         // gwgrad_kernel<...>
+  CG_PROF_SCONV,                  // sconv_kernel<*> (cg_conv_small.hip)
+  CG_PROF_SWGRAD,                 // swgrad_kernel<*> (cg_conv_small.hip)
   CG_PROF_COUNT
 };
 void cg_prof_begin(int family, double flops, double bytes, hipStream_t st);
@@ -138,6 +140,60 @@ struct CgProfScope {
   }
   ~CgProfScope() { cg_prof_end(fam, st); }
 };
+
+// ---- LDS-DMA (buffer_load ... lds) issued from inline asm ----------------------------------------
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 builtin that
+// follows a __builtin_amdgcn_raw_ptr_buffer_load_lds in program order (it cannot tell the LDS region
+// the DMA writes from the one the read touches), which drains the prefetch of the NEXT tile before
+// the current one is multiplied -- the weight-gradient kernels lost their double buffering to it.
+// Issued from inline asm the DMA is invisible to that pass: the kernel orders its LDS reads behind
+// the DMA with its own counted `s_waitcnt vmcnt(N)` (+ a barrier where other waves staged the data),
+// and every other wait (LDS reads -> MFMA) stays compiler-managed.
+//   rs   : the buffer descriptor as four wave-uniform dwords (cg_make_rsrc)
+//   voff : per-lane byte offset (>= 0x80000000: the bounds check returns zeros)
+//   soff : wave-uniform byte offset;  lds : wave-uniform LDS byte address, lane l lands at lds + 16 l
+// M0 (the DMA's LDS base) is saved and restored inside the statement; s_nop 4 covers a descriptor /
+// offset SGPR written by v_readfirstlane just before (cdna_hip_programming.md section 5.7).
+typedef __attribute__((ext_vector_type(4))) int cg_i32x4_t;
+__device__ __forceinline__ cg_i32x4_t cg_make_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t p = (uint64_t)base;
+  cg_i32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((p >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void cg_dma16_asm(cg_i32x4_t rs, uint32_t voff, uint32_t soff,
+                                             uint32_t lds) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rs), "s"(lds), "s"(soff)
+      : "memory");
+}
+// The same without the M0 save / restore and with the single wait state an M0 write needs before
+// an LDS-DMA: for kernels in which NOTHING else uses M0 (no LDS-DMA builtin, no s_movrel, no
+// s_sendmsg -- check the .s) and whose descriptor / offset SGPRs are written by scalar instructions
+// long before (cg_make_rsrc at kernel entry).
+__device__ __forceinline__ void cg_dma16_asm_m0(cg_i32x4_t rs, uint32_t voff, uint32_t soff,
+                                                uint32_t lds) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, %3 offen lds"
+      :
+      : "v"(voff), "s"(rs), "s"(lds), "s"(soff)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t cg_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -23,6 +23,23 @@ void cg_hconv_rw_launch(const cgConvGeom* g, const void* in, const void* bt, voi
                         int out_is_f32, const float* bias, const void* gate_in,
                         const void* gate_out, float slope_out, const void* residual,
                         hipStream_t st);
+// small-map 3x3 form: 64-pixel x 64-channel workgroups, K split over the waves (cg_conv_small.hip)
+bool cg_sconv_geom_ok(const cgConvGeom* g);
+bool cg_sconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in);
+void cg_sconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out, int out_is_f32,
+                     const float* bias, const void* gate_in, const void* gate_out, float slope_out,
+                     const void* residual, hipStream_t st);
+// small-map weight gradient: one tap x 64 x 64 per workgroup, all pixels, no partials; several
+// layers per launch (cg_conv_small.hip)
+bool cg_swgrad_geom_ok(const cgConvGeom* g);
+bool cg_swgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in,
+                         const void* gate_dy, bool grouped);
+void cg_swgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in, const void* dy,
+                      float* dw, int accumulate, float* dbias, hipStream_t st);
+#define CG_SWGRAD_MAX_JOBS 24
+void cg_swgrad_launch_multi(const cgConvGeom* const* geoms, const void* const* ins,
+                            const int* relus, const void* const* dys, float* const* dws,
+                            const int* accumulates, float* const* dbs, int n, hipStream_t st);
 // the same launch with the fused batch-norm prologue / statistics epilogue (cgConvFusion, cgamd.h)
 void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, void* out,
                            int out_is_f32, const float* bias, const void* gate_in,

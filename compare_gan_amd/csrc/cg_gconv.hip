@@ -622,6 +622,12 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
     CG_CHECK_LAUNCH("cg_gconv(stem)");
     return CG_OK;
   }
+  if (cg_sconv_supported(g, in, gate_in, slope_in)) {
+    hipStream_t fst = (hipStream_t)stream;
+    cg_sconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fst);
+    CG_CHECK_LAUNCH("cg_gconv(small)");
+    return CG_OK;
+  }
   if (cg_hconv_rw_supported(g, in, gate_in, slope_in)) {
     hipStream_t fst = (hipStream_t)stream;
     cg_hconv_rw_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
@@ -825,6 +831,12 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
     }
     return rc2;
   }
+  if (cg_swgrad_supported(g, in, gate_in, slope_in, gate_dy, false)) {
+    hipStream_t fst = (hipStream_t)stream;
+    cg_swgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, fst);
+    CG_CHECK_LAUNCH("cg_gwgrad(small)");
+    return CG_OK;
+  }
   if (cg_hwgrad_supported(g, in, gate_in, slope_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
     cg_hwgrad_launch(g, in, gate_in, dy, dw, accumulate, dbias, ws, fst);
@@ -889,4 +901,61 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
     }
   }
   return CG_OK;
+}
+
+// Several weight gradients in one call (the deferred weight gradients of a backward pass,
+// compare_gan_amd/hip/functional.py): the small-map ones -- which cannot fill the chip one at a
+// time -- share launches of up to CG_SWGRAD_MAX_JOBS layers; the others run one by one.
+extern "C" int cg_gwgrad_groupable(const cgConvGeom* g) {
+  if (!g || check_geom(g, "cg_gwgrad_groupable")) return 0;
+  return cg_swgrad_supported(g, nullptr, nullptr, 0.f, nullptr, true) ? 1 : 0;
+}
+
+extern "C" int cg_gwgrad_multi(const cgWgradItem* items_host, int n, void* ws, size_t ws_bytes,
+                               cgStream stream) {
+  if (n < 0 || (n > 0 && !items_host)) CG_FAIL(CG_ERR_BAD_ARG, "cg_gwgrad_multi: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const cgConvGeom* geoms[CG_SWGRAD_MAX_JOBS];
+  const void* ins[CG_SWGRAD_MAX_JOBS];
+  const void* dys[CG_SWGRAD_MAX_JOBS];
+  float* dws[CG_SWGRAD_MAX_JOBS];
+  float* dbs[CG_SWGRAD_MAX_JOBS];
+  int relus[CG_SWGRAD_MAX_JOBS], accs[CG_SWGRAD_MAX_JOBS];
+  int m = 0;
+  auto flush = [&]() -> int {
+    if (m == 0) return CG_OK;
+    double fl = 0, by = 0;
+    if (cg_prof_enabled())
+      for (int i = 0; i < m; ++i) {
+        double f, b;
+        cg_conv_algorithmic_cost(geoms[i], &f, &b);
+        fl += f;
+        by += b;
+      }
+    if (cg_prof_enabled()) cg_prof_begin(CG_PROF_SWGRAD, fl, by, st);
+    cg_swgrad_launch_multi(geoms, ins, relus, dys, dws, accs, dbs, m, st);
+    cg_prof_end(CG_PROF_SWGRAD, st);
+    m = 0;
+    CG_CHECK_LAUNCH("cg_gwgrad_multi(small)");
+    return CG_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const cgWgradItem& it = items_host[i];
+    int rc = check_geom(&it.geom, "cg_gwgrad_multi");
+    if (rc) return rc;
+    if (!it.in || !it.dy || !it.dw) CG_FAIL(CG_ERR_BAD_ARG, "cg_gwgrad_multi: null tensor");
+    if (cg_swgrad_supported(&it.geom, it.in, it.gate_in, it.slope_in, nullptr, true)) {
+      geoms[m] = &it.geom; ins[m] = it.in; dys[m] = it.dy; dws[m] = it.dw; dbs[m] = it.dbias;
+      relus[m] = it.gate_in != nullptr; accs[m] = it.accumulate;
+      if (++m == CG_SWGRAD_MAX_JOBS) {
+        rc = flush();
+        if (rc) return rc;
+      }
+    } else {
+      rc = cg_gwgrad(&it.geom, it.in, it.gate_in, it.slope_in, it.dy, nullptr, 0.f, it.dw,
+                     it.accumulate, it.dbias, ws, ws_bytes, stream);
+      if (rc) return rc;
+    }
+  }
+  return flush();
 }

@@ -72,6 +72,7 @@ random_uniform = gin.external_configurable(_random_uniform, name="uniform", modu
 # takes.  CGAMD_DP_OVERLAP=1 / 0 forces it on / off.
 _DP_OVERLAP = os.environ.get("CGAMD_DP_OVERLAP", "auto")
 _JOINT_G = os.environ.get("CGAMD_JOINT_G", "1") != "0"   # batched generator forwards (A/B switch)
+_DEFER_WGRAD = os.environ.get("CGAMD_DEFER_WGRAD", "1") != "0"   # grouped small-map weight gradients
 _DP_OVERLAP_MIN_BYTES = 32 << 20
 
 
@@ -416,8 +417,9 @@ class ModularGAN(AbstractGAN):
       self.create_loss(features, labels)
     # torch.autograd.grad hands the gradients over directly: no AccumulateGrad nodes, whose
     # stream affinity would break hipGraph capture (they run on the stream they were created on)
-    grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
-                                allow_unused=True)
+    with Fn.deferred_wgrads(self._wgrads_deferrable() and self.penalty_loss is None):
+      grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
+                                  allow_unused=True)
     self.d_opt.apply_gradients(self.global_step_disc, grads=self._fill_unused(self.d_opt, grads))
     self.d_loss = self.d_loss.detach()
     if self.penalty_loss is not None:
@@ -441,8 +443,9 @@ class ModularGAN(AbstractGAN):
         self.g_opt.join()
         features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
-    grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
-                                allow_unused=True)
+    with Fn.deferred_wgrads(self._wgrads_deferrable()):
+      grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
+                                  allow_unused=True)
     self.g_opt.apply_gradients(self.global_step, ema_decay=self._ema_decay,
                                ema_start=self._ema_start_step,
                                grads=self._fill_unused(self.g_opt, grads))
@@ -450,6 +453,14 @@ class ModularGAN(AbstractGAN):
     self.g_loss = self.g_loss.detach()
     self.d_loss = self.d_loss.detach()
     return self.g_loss
+
+  def _wgrads_deferrable(self):
+    """Weight gradients may be deferred and grouped (Fn.deferred_wgrads) when every weight gets
+    exactly ONE gradient contribution in the backward pass: one discriminator / generator call per
+    graph (the base class's create_loss without deprecated_split_disc_calls) and no penalty term
+    (checked by the caller: a penalty differentiates the discriminator a second time)."""
+    return (_DEFER_WGRAD and not self._deprecated_split_disc_calls and
+            type(self).create_loss is ModularGAN.create_loss)
 
   def _unit_grad(self):
     """d(loss)/d(loss) = 1, allocated once (autograd would launch a fill per backward pass)."""

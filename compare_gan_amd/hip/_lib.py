@@ -46,6 +46,12 @@ class PrepItem(ctypes.Structure):
                 ("Ci", ctypes.c_int32), ("Co", ctypes.c_int32)]
 
 
+class WgradItem(ctypes.Structure):
+    """Mirror of cgWgradItem."""
+    _fields_ = [("geom", ConvGeom), ("in_", vp), ("gate_in", vp), ("slope_in", c_f32),
+                ("accumulate", ctypes.c_int32), ("dy", vp), ("dw", vp), ("dbias", vp)]
+
+
 class ConvFusion(ctypes.Structure):
     """Mirror of cgConvFusion."""
     _fields_ = [("bn_mean", vp), ("bn_var", vp), ("bn_gamma", vp), ("bn_beta", vp),
@@ -75,6 +81,8 @@ SIGNATURES = {
     "cg_bn_finalize": (c_int, [vp, c_int, c_int, c_i64, vp, vp, vp, vp, c_f32, vp]),
     "cg_gwgrad_workspace_bytes": (c_sz, [GP]),
     "cg_gwgrad": (c_int, [GP, vp, vp, c_f32, vp, vp, c_f32, vp, c_int, vp, vp, c_sz, vp]),
+    "cg_gwgrad_multi": (c_int, [ctypes.POINTER(WgradItem), c_int, vp, c_sz, vp]),
+    "cg_gwgrad_groupable": (c_int, [GP]),
     "cg_spectral_norm_workspace_bytes": (c_sz, [c_int, c_int]),
     "cg_spectral_norm": (c_int, [vp, c_int, c_int, c_int, c_f32, vp, vp, vp, vp, vp, vp, c_sz, vp]),
     "cg_sn_backward_workspace_bytes": (c_sz, [c_int, c_int]),

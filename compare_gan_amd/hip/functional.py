@@ -94,8 +94,50 @@ def _wgrad_side_stream():
   return _WGRAD["stream"]
 
 
+# ------------------------------------------------------------------------------------------------
+# deferred weight gradients
+# ------------------------------------------------------------------------------------------------
+# tf.gradients(loss, var_list) hands the optimiser all kernel gradients of a network at once
+# (modular_gan.py:480-483,494-497): nothing in the data-gradient chain reads them.  The weight
+# gradients of the small feature maps (4x4 / 8x8 blocks) cannot fill 256 CUs one at a time, so
+# inside a deferred_wgrads() context GConvFn.backward only RECORDS them -- it returns tensors whose
+# contents are not written yet -- and flush_wgrads() runs all of them in one cg_gwgrad_multi call
+# (several layers per launch, no split partials).  Readers flush first: the spectral-norm
+# backward, the optimiser (through join_wgrad_stream()) and the end of the context.  The caller
+# guarantees that no weight receives a second gradient contribution inside the context (autograd
+# would add to the unwritten tensor): modular_gan enables it for single-call discriminator /
+# generator graphs without penalties only.
+_DEFER = {"on": False, "jobs": []}
+
+
+class deferred_wgrads(object):
+  def __init__(self, enabled=True):
+    self._enabled = bool(enabled)
+
+  def __enter__(self):
+    self._old = _DEFER["on"]
+    _DEFER["on"] = self._enabled
+    return self
+
+  def __exit__(self, etype, *exc):
+    _DEFER["on"] = self._old
+    if etype is None:
+      flush_wgrads()
+    else:
+      del _DEFER["jobs"][:]
+
+
+def flush_wgrads():
+  """Runs every recorded weight gradient (their output tensors are valid afterwards)."""
+  if _DEFER["jobs"]:
+    jobs, _DEFER["jobs"] = _DEFER["jobs"], []
+    K.gwgrad_multi(jobs)
+
+
 def join_wgrad_stream():
-  """Makes the current stream wait for every weight gradient launched on the side stream."""
+  """Makes the current stream wait for every weight gradient launched on the side stream, and
+  runs the deferred ones."""
+  flush_wgrads()
   if _WGRAD["dirty"]:
     torch.cuda.current_stream().wait_stream(_WGRAD["stream"])
     _WGRAD["dirty"] = False
@@ -163,6 +205,16 @@ class GConvFn(torch.autograd.Function):
           if t is not None:
             t.record_stream(main)    # allocated on the side stream, consumed on the main one
         _WGRAD["dirty"] = True
+      elif (_DEFER["on"] and need_w and not spec.transpose and x.is_cuda and
+            (gate_out is None or spec.slope_out is None) and
+            (gate_in is None or spec.slope_in is None or
+             (spec.slope_in == 0.0 and gate_in.data_ptr() == x.data_ptr())) and
+            K.gwgrad_groupable(spec.geom)):
+        g = spec.geom
+        dw = torch.empty((g.kh, g.kw, g.Ci, g.Co), dtype=F32, device=x.device)
+        db = torch.empty((g.Co,), dtype=F32, device=x.device) if want_b else None
+        relu_in = gate_in is not None and spec.slope_in is not None
+        _DEFER["jobs"].append((g, x, dy16, relu_in, dw, db))
       else:
         dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
     return dx, dw, db, dr, None, None, None, None, None

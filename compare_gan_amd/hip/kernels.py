@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from compare_gan_amd.hip import _lib
-from compare_gan_amd.hip._lib import ConvGeom, check
+from compare_gan_amd.hip._lib import ConvGeom, WgradItem, check
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -261,6 +261,48 @@ def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, 
                           _p(gate_dy), float(slope_dy), _p(dw), int(accumulate), _p(dbias),
                           _p(ws), ws.numel(), _stream()), "cg_gwgrad")
     return dw, dbias
+
+
+_GROUPABLE = {}
+
+
+def gwgrad_groupable(geom):
+    """True when gwgrad_multi runs this weight gradient in a launch shared with other layers."""
+    key = geom.key()
+    if key not in _GROUPABLE:
+        _GROUPABLE[key] = bool(lib().cg_gwgrad_groupable(ctypes.byref(geom)))
+    return _GROUPABLE[key]
+
+
+def gwgrad_multi(jobs):
+    """Several weight gradients in one call (cg_gwgrad_multi): jobs = [(geom, x, dy, relu_in,
+    dw, dbias)], x / dy bf16, relu_in = the input carries its own ReLU gate, dw fp32
+    [kh,kw,Ci,Co] and dbias fp32 [Co] (or None) are written.  The 3x3 layers on small maps share
+    launches; the rest run one by one."""
+    if not jobs:
+        return
+    items = (WgradItem * len(jobs))()
+    need = 256
+    for it, (geom, x, dy, relu_in, dw, dbias) in zip(items, jobs):
+        _req(x, BF16, "x")
+        _req(dy, BF16, "dy")
+        _req(dw, F32, "dw")
+        _req(dbias, F32, "dbias", True)
+        if x.numel() != geom.N * geom.Hin * geom.Win * geom.Ci:
+            raise ValueError("x has the wrong number of elements for %s" % (geom.key(),))
+        if dy.numel() != geom.N * geom.Ho * geom.Wo * geom.Co:
+            raise ValueError("dy has the wrong number of elements for %s" % (geom.key(),))
+        it.geom = geom
+        it.in_ = _p(x)
+        it.gate_in = _p(x) if relu_in else None
+        it.slope_in = 0.0
+        it.accumulate = 0
+        it.dy = _p(dy)
+        it.dw = _p(dw)
+        it.dbias = _p(dbias)
+        need = max(need, int(lib().cg_gwgrad_workspace_bytes(ctypes.byref(it.geom))))
+    ws = _ws(need, jobs[0][1])
+    check(lib().cg_gwgrad_multi(items, len(jobs), _p(ws), ws.numel(), _stream()), "cg_gwgrad_multi")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -172,6 +172,29 @@ size_t cg_gwgrad_workspace_bytes(const cgConvGeom* geom);
 int cg_gwgrad(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
               const void* dy, const void* gate_dy, float slope_dy, float* dw, int accumulate,
               float* dbias, void* ws, size_t ws_bytes, cgStream stream);
+/* Several weight gradients in one call: tf.gradients(loss, var_list) hands all kernel gradients
+ * of a network to the optimiser at once (modular_gan.py:480-483,494-497), so they need not be
+ * computed inside the data-gradient chain.  `items` is a HOST array (device pointers by value in
+ * the kernel arguments: hipGraph-capturable).  The 3x3 layers on small maps (N*H*W <= 8192 pixels,
+ * channel counts multiples of 64; resnet_cifar.py:119-167 blocks B3/B4, resnet5.py:99-145 blocks
+ * B4/B5) share launches: none of them fills the chip alone without splitting its pixel sum into
+ * fp32 partials.  Every other item runs as cg_gwgrad with the shared workspace
+ * (ws_bytes >= max over the items of cg_gwgrad_workspace_bytes).  gate_in: NULL or == in (ReLU
+ * self-gate, slope_in 0) for the grouped form, anything cg_gwgrad accepts otherwise. */
+typedef struct {
+  cgConvGeom geom;
+  const void* in;
+  const void* gate_in;
+  float slope_in;
+  int32_t accumulate;
+  const void* dy;
+  float* dw;
+  float* dbias;
+} cgWgradItem;
+int cg_gwgrad_multi(const cgWgradItem* items_host, int n, void* ws, size_t ws_bytes,
+                    cgStream stream);
+/* 1 when cg_gwgrad_multi would run `geom` in a shared launch (worth deferring), else 0. */
+int cg_gwgrad_groupable(const cgConvGeom* geom);
 
 /* ------------------------------------------------------------------------------------------
  * Spectral normalisation (arch_ops.py:453-535): one power-iteration round, sigma, u update.

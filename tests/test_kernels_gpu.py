@@ -101,6 +101,14 @@ CONV_CASES = [
     ("wstem_32", 3, 32, 32, 3, 64, 3, 1, 1),
     ("wstem_64x32_c96", 1, 64, 32, 3, 96, 3, 1, 1),
     ("wstem_16_c128", 5, 16, 16, 3, 128, 3, 1, 1),
+    # small-map kernels (cg_conv_small.hip: sconv / swgrad): four 4x4 images per tile with a ragged
+    # last tile, 8x8 tiles, several 8x8 tiles per image (non-square), 3 channel blocks, 16-pixel
+    # k-steps on 16-wide rows
+    ("small_4x4", 6, 4, 4, 64, 64, 3, 1, 1),
+    ("small_4x4_c192", 5, 4, 4, 192, 128, 3, 1, 1),
+    ("small_8x8", 3, 8, 8, 128, 192, 3, 1, 1),
+    ("small_16x8", 2, 16, 8, 128, 64, 3, 1, 1),
+    ("small_16x16", 2, 16, 16, 64, 128, 3, 1, 1),
 ]
 
 
@@ -205,6 +213,61 @@ def test_gconv_full_size_shapes(K, dev, case):
     dw, db = K.gwgrad(geom, xb, dyb, gate_in=xb, slope_in=0.0, want_dbias=True)
     _close_on_device(dw, ref_dw, name + " wgrad", 2e-4, 2e-4)
     _close_on_device(db, dy2.sum(dim=0), name + " dbias", 2e-4, 2e-4)
+
+
+def test_gwgrad_multi_grouped(K, dev):
+    """cg_gwgrad_multi: the weight (+ bias) gradients of several layers in one call -- the small-map
+    ones share a launch (swgrad_kernel), the others run through cg_gwgrad -- against the fp64 oracle
+    convolution; ReLU input gates on some jobs, the sizes of the ResNet-CIFAR discriminator's 8x8
+    blocks (resnet_cifar.py:119-167) at batch 8 among them."""
+    g = _gen(91)
+    shapes = [(8, 8, 8, 128, 128, True), (8, 8, 8, 128, 128, False), (5, 4, 4, 64, 192, True),
+              (2, 16, 16, 64, 64, False), (2, 32, 32, 64, 64, True), (3, 8, 8, 96, 64, False)]
+    jobs, refs = [], []
+    for (N, H, W, Ci, Co, relu) in shapes:
+        x64, xb = rand_bf16((N, H, W, Ci), g)
+        dy64, dyb = rand_bf16((N, H, W, Co), g)
+        geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+        w0 = torch.zeros((3, 3, Ci, Co), dtype=torch.float64, requires_grad=True)
+        xin = torch.relu(x64) if relu else x64
+        (_ref_conv(xin, w0, 1, 1) * dy64).sum().backward()
+        dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev)
+        db = torch.full((Co,), float("nan"), device=dev)
+        jobs.append((geom, xb.to(dev), dyb.to(dev), relu, dw, db))
+        refs.append((w0.grad, dy64.sum(dim=(0, 1, 2))))
+    K.gwgrad_multi(jobs)
+    for (N, H, W, Ci, Co, relu), (_, _, _, _, dw, db), (rw, rb) in zip(shapes, jobs, refs):
+        name = "multi %dx%dx%dx%d->%d" % (N, H, W, Ci, Co)
+        assert_close_f32(dw, rw, name + " wgrad", rtol=2e-4, abs_rms=2e-4)
+        assert_close_f32(db, rb, name + " dbias", rtol=2e-4, abs_rms=2e-4)
+
+
+def test_deferred_wgrads_match_immediate(K, dev):
+    """Fn.deferred_wgrads(): the recorded weight gradients, run as one cg_gwgrad_multi call at the
+    end of the context (or when the spectral-norm backward asks for them), equal the ones computed
+    inside the backward pass -- bit for bit where the same kernel runs, to rounding otherwise."""
+    from compare_gan_amd.hip import functional as Fn
+    g = _gen(17)
+    N, H, W, C = 8, 8, 8, 128
+    _, xb = rand_bf16((N, H, W, C), g)
+    ws = [rand_bf16((3, 3, C, C), g, 0.03)[1].float().to(dev).requires_grad_(True) for _ in range(3)]
+    bs = [torch.zeros(C, device=dev, requires_grad=True) for _ in range(3)]
+    geom = K.geom_conv_same(N, H, W, C, C, 3, 3, 1, 1)
+
+    def run(defer):
+        h = xb.to(dev)
+        for w, b in zip(ws, bs):
+            h = Fn.gconv(h, w, b, gate_in=h, spec=Fn.ConvSpec(geom, slope_in=0.0))
+        loss = Fn.relu_mean(h).sum()
+        with Fn.deferred_wgrads(defer):
+            grads = torch.autograd.grad(loss, ws + bs)
+        return [t.clone() for t in grads]
+
+    immediate = run(False)
+    deferred = run(True)
+    for a, b in zip(immediate, deferred):
+        assert torch.isfinite(b).all()
+        assert_close_f32(b, a.double().cpu(), "deferred vs immediate", rtol=1e-4, abs_rms=1e-4)
 
 
 @pytest.mark.parametrize("size", [8, 32])
@@ -853,6 +916,9 @@ CONV_VARIANT_ENVS = [
     # halo-staged forward / weight-gradient kernels wherever they apply
     ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1", "CGAMD_HCONV_RW_MIN": "1"}),
     ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0", "CGAMD_WSTEM": "0", "CGAMD_HCONV_RW": "0"}),
+    # small-map kernels (cg_conv_small.hip) wherever their geometry fits / nowhere
+    ("small_all", {"CGAMD_SCONV": "2", "CGAMD_SWGRAD": "2"}),
+    ("no_small", {"CGAMD_SCONV": "0", "CGAMD_SWGRAD": "0"}),
 ]
 
 
