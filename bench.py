@@ -14,6 +14,12 @@ timed region.  On N = 1 two extra legs run AFTER the timed region:
   cpu_baseline : the CPU oracle (restatement of the reference, PyTorch-CPU fp32, all host cores)
                  on the same workload for a bounded sample.  The reference's own TF1 path cannot be
                  installed here, hence kind = "port".
+Self-calibration (boxes of one pool differ by +-15 % in sustained clocks): before the warm-up the
+captured step is replayed for `--preheat-s` seconds (reported as `preheat_s`; `--warmup` keeps its
+meaning: W untimed steps right before the timed region), the shader / memory clocks are read before
+and after the timed region, and two microbenchmarks of the SAME process -- a pure bf16 MFMA loop and
+a float4 copy -- give `roofline.peak_measured` / `hbm_measured`, so that `frac_of_measured` is
+comparable between boxes while `frac` stays against the datasheet peak.
 """
 import argparse
 import json
@@ -49,12 +55,20 @@ def parse_args():
                    help="skip the resnet128 D-step / BigGAN-128 legs")
     p.add_argument("--legs", default="", help="comma list of legs to run (default: all)")
     p.add_argument("--biggan-batch", type=int, default=64)
+    p.add_argument("--biggan-big-batch", type=int, default=256,
+                   help="per-GPU batch of the biggan128_bs256 leg (C5: global 2048 on 8 GPUs)")
+    p.add_argument("--preheat-s", type=float, default=1.0,
+                   help="seconds of untimed step replays before the warm-up (clock ramp)")
+    p.add_argument("--cpu-mode", default="step", help=argparse.SUPPRESS)
+    p.add_argument("--cpu-bindings", default="", help=argparse.SUPPRESS)
     return p.parse_args()
 
 
-def cpu_baseline(config, batch, budget_s=20.0):
-    """The oracle's train step on the host cores, bounded: whole unrolled steps are timed until
-    `budget_s` seconds of CPU work have been spent (at least one step)."""
+def cpu_baseline(config, batch, budget_s=20.0, mode="step", no_penalty=False):
+    """The oracle on the host cores, bounded: whole unrolled steps (mode "step") or single
+    discriminator sub-steps (mode "dstep": G forward without gradient, D forward + backward, TF-Adam
+    on D -- the unit of the resnet128_dstep leg) are timed until `budget_s` seconds of CPU work have
+    been spent (at least one)."""
     from oracle import arch_ops as oops
     from tests import gan_util as U
     try:
@@ -64,49 +78,90 @@ def cpu_baseline(config, batch, budget_s=20.0):
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     vs = oops.VarStore(dtype=torch.float32, seed=1)
-    ora = U.build_oracle(config, vs)
-    nsub = ora.disc_iters + 1
+    over = {"penalty": "no_penalty"} if no_penalty else {}
+    ora = U.build_oracle(config, vs, **over)
+    nsub = ora.disc_iters + 1 if mode == "step" else 1
     h, w, c = ora.image_shape
     gen = torch.Generator().manual_seed(547)
     subs = [{"images": torch.rand(batch, h, w, c, generator=gen),
-             "z": torch.rand(batch, 128, generator=gen) * 2 - 1} for _ in range(nsub)]
+             "z": torch.rand(batch, 128, generator=gen) * 2 - 1,
+             "alpha": torch.rand(batch, 1, 1, 1, generator=gen)} for _ in range(nsub)]
+
+    def dstep(sub):
+        ora._ensure_opts()   # pylint: disable=protected-access
+        with torch.no_grad():
+            generated = ora.G(sub["z"], None)
+        d_loss, _, _ = ora.create_loss(sub["images"], generated, None, None, sub["alpha"])
+        ora.d_opt.step(torch.autograd.grad(d_loss, ora.d_vars()))
+
     steps, t0 = 0, time.time()
     while True:
-        ora.train_step(subs)
+        if mode == "step":
+            ora.train_step(subs)
+        else:
+            dstep(subs[0])
         steps += 1
         dt = time.time() - t0
         if dt >= budget_s or steps >= 8:
             break
+    what = ("%d full unrolled step(s) (%d D + 1 G sub-steps each)" % (steps, ora.disc_iters)
+            if mode == "step" else "%d discriminator sub-step(s)%s" % (
+                steps, " without the penalty" if no_penalty else ""))
     return {"value": round(batch * nsub * steps / dt, 2), "unit": "img/s",
-            "cores": cores, "kind": "port",
-            "sample": "%d full unrolled step(s) (%d D + 1 G sub-steps each) of %s at batch %d in "
-                      "%.1f s, fp32 PyTorch-CPU restatement of the reference (oracle/); the first "
-                      "step includes variable creation" % (steps, ora.disc_iters, config, batch, dt)}
+            "cores": cores, "kind": "port", "batch": batch,
+            "sample": "%s of %s at batch %d in %.1f s, fp32 PyTorch-CPU restatement of the "
+                      "reference (oracle/); the first one includes variable creation" % (
+                          what, config, batch, dt)}
 
 
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r02_pmc_traffic.json")
+                                "r03_pmc_traffic.json")
 PMC_TRAFFIC_NOTE = ("HBM bytes per launch of this kernel family = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                     "from two rocprofv3 --pmc passes of this workload (scripts/pmc_traffic.py -> "
-                    "profiles/r02_pmc_traffic.json); null when that summary is absent")
+                    "profiles/r03_pmc_traffic.json, one table per workload); null when that summary "
+                    "is absent")
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, workload="cifar"):
     """PMC counters cannot be read from inside the timed process: the committed summary of the
     separate `rocprofv3 --pmc` passes over this same command is reported (bytes per launch)."""
     try:
         with open(PMC_TRAFFIC_FILE) as f:
-            return json.load(f)["families"][family]["hbm_bytes_per_launch"]
+            d = json.load(f)
+        d = d.get("workloads", {}).get(workload, d if workload == "cifar" else {})
+        return d["families"][family]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
 
-def cpu_baseline_guarded(config, batch, budget_s):
+def read_clocks():
+    """Current shader / memory clock in MHz from the amdgpu sysfs tables (the active level carries a
+    `*`), or None where the box does not expose them."""
+    import glob
+    out = {}
+    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        val = None
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/" + name)):
+            try:
+                with open(path) as f:
+                    for line in f:
+                        if "*" in line:
+                            val = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                if val is not None:
+                    break
+            except (OSError, ValueError, IndexError):
+                continue
+        out[key] = val
+    return out
+
+
+def cpu_baseline_guarded(config, batch, budget_s, mode="step", no_penalty=False):
     """Runs cpu_baseline in a child process under a hard timeout so that a slow or oversubscribed
     host can never stall the benchmark line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", config,
-           "--batch-per-gpu", str(batch), "--cpu-budget-s", str(budget_s)]
+           "--batch-per-gpu", str(batch), "--cpu-budget-s", str(budget_s), "--cpu-mode", mode,
+           "--cpu-bindings", "no_penalty" if no_penalty else ""]
     env = dict(os.environ)
     env["HIP_VISIBLE_DEVICES"] = ""
     try:
@@ -131,7 +186,8 @@ def family_table(fam, n_prof):
             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
 
 
-def extra_leg(config, bindings, batch, mode, steps, warmup, dev, survey_tflop=None):
+def extra_leg(config, bindings, batch, mode, steps, warmup, dev, survey_tflop=None, calib=None,
+              traffic_key=None):
     """A second workload measured in the same process AFTER the headline line's timed region:
     mode "dstep" = ONE discriminator sub-step (fresh z, G forward, D forward/backward, D Adam), the
     unit BASELINE.json's north star names for the 128x128 ResNet; mode "step" = one full unrolled
@@ -195,6 +251,13 @@ def extra_leg(config, bindings, batch, mode, steps, warmup, dev, survey_tflop=No
         "conv_kernel_ms_eager": round(conv_ms, 4),
         "kernels": family_table(fam, n_prof),
     }
+    if calib:
+        leg["peak_measured"] = round(calib["mfma_bf16_tflops"], 1)
+        leg["frac_of_measured"] = round(counted / dt / calib["mfma_bf16_tflops"], 4)
+    if traffic_key:
+        leg["traffic"] = {k: pmc_traffic(k, traffic_key) for k in leg["kernels"]
+                          if pmc_traffic(k, traffic_key) is not None}
+        leg["traffic_source"] = PMC_TRAFFIC_NOTE
     del run, eager, out
     gan._graph = None   # pylint: disable=protected-access
     del gan
@@ -206,7 +269,8 @@ def extra_leg(config, bindings, batch, mode, steps, warmup, dev, survey_tflop=No
 def main():
     args = parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.config, args.batch_per_gpu, args.cpu_budget_s)))
+        print(json.dumps(cpu_baseline(args.config, args.batch_per_gpu, args.cpu_budget_s,
+                                      args.cpu_mode, args.cpu_bindings == "no_penalty")))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -248,18 +312,10 @@ def main():
     step_fn = gan.train_step
     if use_graph:
         # the whole step -- including the RCCL gradient all-reduces under data parallelism -- is
-        # replayed from one hipGraph; if the capture of the collective path is refused by the
-        # runtime, fall back to eager launches rather than lose the measurement
-        try:
-            step_fn = gan.capture_train_step()
-        except Exception as e:  # pylint: disable=broad-except
-            if world == 1 and not force_dp:
-                raise
-            sys.stderr.write("hipGraph capture failed under data parallelism (%r); running "
-                             "eagerly\n" % (e,))
-            torch.cuda.synchronize()
-            use_graph = False
-            step_fn = gan.train_step
+        # replayed from one hipGraph.  A capture the runtime refuses is an ERROR (a silently eager
+        # run would be reported as if it were the captured one): CGAMD_DP_GRAPH=0 asks for eager
+        # launches explicitly
+        step_fn = gan.capture_train_step()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -268,14 +324,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # disclosed pre-heat: the clocks of an idle box ramp for several hundred ms under load, which a
+    # 0.2 s timed region right after 5 warm-up steps would sit inside of
+    preheat_steps, t_pre = 0, time.perf_counter()
+    while time.perf_counter() - t_pre < args.preheat_s:
+        for i in range(4):
+            step_fn(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+        preheat_steps += 4
+    preheat_s = time.perf_counter() - t_pre
     for i in range(args.warmup):
         step_fn(*pool[i % len(pool)])
     sync_all()
+    clocks_before = read_clocks()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step_fn(*pool[i % len(pool)])
     sync_all()
     dt = time.perf_counter() - t0
+    clocks_after = read_clocks()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -303,7 +370,20 @@ def main():
                                    args.config, options["disc_iters"], bsz, *dataset.image_shape),
                    "global_batch": bsz * world, "images_per_step": bsz * world * nsub,
                    "parallelism": "dp%d" % world, "hip_graph": bool(use_graph)},
+        "preheat_s": round(preheat_s, 3), "preheat_steps": preheat_steps,
+        "clocks": {"before": clocks_before, "after": clocks_after},
     }
+    calib = None
+    if rank == 0 and world == 1:
+        # measured roofline denominators of THIS box, right after the timed region
+        calib = K.calibrate(dev)
+        result["calibration"] = {
+            "mfma_bf16_tflops": round(calib["mfma_bf16_tflops"], 1),
+            "hbm_copy_gbs": round(calib["hbm_copy_gbs"], 1),
+            "how": "pure v_mfma_f32_32x32x16_bf16 loop on random operands for %.0f ms (2048 "
+                   "workgroups of 4 waves, 8 independent accumulators) and a float4 copy of %d MiB "
+                   "(read + write bytes), HIP events, same process" % (calib["mfma_ms"], calib["copy_mb"]),
+            "clocks_after": read_clocks()}
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # HIP-event brackets on the launch stream around every convolution launch, eager replays of
@@ -321,6 +401,9 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "peak_measured": round(calib["mfma_bf16_tflops"], 1),
+            "frac_of_measured": round(achieved / calib["mfma_bf16_tflops"], 4),
+            "hbm_peak": PEAK_HBM_GBS, "hbm_measured": round(calib["hbm_copy_gbs"], 1),
             "traffic": pmc_traffic(name),
             "traffic_source": PMC_TRAFFIC_NOTE,
             "launches_per_step": st["launches"] / n_prof,
@@ -348,9 +431,13 @@ def main():
         res = eval_gan_lib.evaluate_gan(gan, [is_lib.InceptionScoreTask(), fid_lib.FIDScoreTask()],
                                         num_averaging_runs=1)
         torch.cuda.synchronize()
+        t_eval = time.perf_counter() - t0
         result["fid10k"] = {
-            "wall_s": round(time.perf_counter() - t0, 3), "num_examples": n_eval,
+            "wall_s": round(t_eval + t_setup, 3), "eval_s": round(t_eval, 3),
+            "num_examples": n_eval,
             "extractor_setup_s": round(t_setup, 3),
+            "wall_definition": "building the Inception extractor (weights, MFMA operand images) + "
+                               "sampling + features of 2 x 10,000 images + fp64 statistics",
             "split_s": {k: round(v, 3) for k, v in eval_gan_lib.LAST_TIMING.items()},
             "fid": round(float(res["fid_score_mean"]), 4),
             "inception_score": round(float(res["inception_score_mean"]), 4),
@@ -374,26 +461,42 @@ def main():
             ("resnet128_dstep_gp", "resnet_lsun-bedroom128.gin", (), 64, "dstep", 10, 2, None),
             # one BigGAN-128 iteration (2 D + 1 G) ~ 0.6 TFLOP per image of batch
             ("biggan128", "biggan_imagenet128.gin", (), args.biggan_batch, "step", 4, 2, None),
+            # C5 of BASELINE.json: global batch 2048 on 8 GPUs = 256 per GPU
+            ("biggan128_bs256", "biggan_imagenet128.gin", (), args.biggan_big_batch, "step", 2, 1,
+             None),
         ]
         for key, cfg, binds, b, mode, k, w, survey in legs:
             if args.legs and key not in args.legs.split(","):
                 continue
             try:
-                result[key] = extra_leg(cfg, binds, b, mode, k, w, dev, survey)
+                result[key] = extra_leg(cfg, binds, b, mode, k, w, dev, survey, calib,
+                                        "resnet128_dstep" if key == "resnet128_dstep" else None)
             except Exception as e:  # pylint: disable=broad-except
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
                 result[key] = {"error": repr(e)[:400]}
+        if "resnet128_dstep" in result and "error" not in result["resnet128_dstep"] and \
+                not args.no_cpu_baseline:
+            # the oracle's discriminator sub-step on the host cores, at a REDUCED batch (8 instead of
+            # 64: the CPU path is linear in the batch) -- img/s is per image
+            result["resnet128_dstep"]["cpu_baseline"] = cpu_baseline_guarded(
+                "resnet_lsun-bedroom128.gin", 8, args.cpu_budget_s, "dstep", True)
 
     if world > 1 or force_dp:
+        import gc
         import torch.distributed as dist
         dist.barrier()
-        # the captured graph holds RCCL kernel nodes: release it before the communicator goes away
+        # orderly teardown: the captured graph holds RCCL kernel nodes and the model holds the
+        # communication streams -- release graph, model and cached blocks, THEN the communicator
         torch.cuda.synchronize()
         step_fn = None
         if getattr(gan, "_graph", None) is not None:
             gan._graph = None   # pylint: disable=protected-access
+        gan = None
+        out = None
+        gc.collect()
         torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio; flush it so that the JSON line is the LAST
     # line on stdout
@@ -406,9 +509,8 @@ def main():
         sys.stdout.write(json.dumps(result) + "\n")
     sys.stdout.flush()
     sys.stderr.flush()
-    if world > 1 or force_dp:
-        # skip interpreter teardown of HIP / RCCL objects: one run in ~5 died there with a core dump
-        # AFTER the measurement (exit order of communicator, graph and stream destructors)
+    if (world > 1 or force_dp) and os.environ.get("CGAMD_BENCH_HARD_EXIT", "0") == "1":
+        # operator override only: skips the interpreter's teardown of HIP / RCCL objects
         os._exit(0)
 
 

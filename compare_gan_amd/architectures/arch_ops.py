@@ -95,6 +95,21 @@ class VariableStore(object):
           self.vars[n].copy_(v.to(self.vars[n].dtype))
         elif strict:
           raise KeyError("unexpected variable %s" % n)
+    # the accumulator switch of accumulator-mode batch norm (arch_ops.py:136-147 `update_accus`) is
+    # persisted as a variable but read from its host mirror on the hot path: a checkpoint saved
+    # with the switch on must turn the mirror on too (one device read per load, none per call)
+    switches = [v for n, v in self.vars.items() if "accu/update_accus" in n and n in sd]
+    if switches and not switches[0].is_meta:
+      self.accu_fill = bool(max(float(v.max()) for v in switches) > 0)
+
+  def set_accu_fill(self, on):
+    """Turns the filling of the batch-norm accumulators on / off: the persisted `update_accus`
+    variables (checkpoint contract) and their host mirror move together."""
+    with torch.no_grad():
+      for n, v in self.vars.items():
+        if "accu/update_accus" in n:
+          v.fill_(1 if on else 0)
+    self.accu_fill = bool(on)
 
 
 _STORE = [None]
@@ -345,6 +360,12 @@ def prepare_module(module):
   store.sn_ready, store.bt_ready = {}, {}
   if store.device.type == "meta":
     return
+  # whoever updates this network's variables on another stream (the data-parallel optimiser on its
+  # communication stream, modular_gan._OptimizerState) registers a join here: EVERY reader of the
+  # variables goes through this function, so no call site can forget the dependency edge
+  hook = getattr(store, "before_call", {}).get(module)
+  if hook is not None:
+    hook()
   sn = store.sn_registry.get(module, {})
   names = [n for n in sn if n in store.vars]
   if names:

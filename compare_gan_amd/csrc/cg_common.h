@@ -191,6 +191,20 @@ __device__ __forceinline__ void cg_dma16_asm_m0(cg_i32x4_t rs, uint32_t voff, ui
       : "v"(voff), "s"(rs), "s"(lds), "s"(soff)
       : "memory");
 }
+// global_load_lds_dwordx4 form (flat global address per lane instead of a buffer descriptor)
+__device__ __forceinline__ void cg_glds16_asm(const void* gptr, uint32_t lds) {
+  uint32_t keep;
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gptr), "s"(l)
+      : "memory");
+}
 __device__ __forceinline__ uint32_t cg_lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }

@@ -40,6 +40,15 @@ __device__ __forceinline__ void glds16(const void* gptr, bf16_t* lds_wave_base) 
   __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gptr, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
+// ASMDMA: the LDS-DMA goes through inline asm (cg_common.h: cg_glds16_asm) so that hipcc does not put
+// `s_waitcnt vmcnt(0)` in front of the transposed LDS reads that follow it in program order -- the
+// weight-gradient kernels below stage slice i + 1 before they multiply slice i
+template <bool ASMDMA>
+__device__ __forceinline__ void glds16x(const void* gptr, bf16_t* lds_wave_base) {
+  if constexpr (ASMDMA) cg_glds16_asm(gptr, cg_lds_addr(lds_wave_base));
+  else glds16(gptr, lds_wave_base);
+}
+
 __device__ __forceinline__ bf16x8_t relu_bf16x8(bf16x8_t v) {
   // bf16 sign bit == int16 sign bit: max_i16(x, 0) is relu(x) (and maps -0.0 to +0.0)
   s16x8_t s = __builtin_bit_cast(s16x8_t, v);
@@ -1104,7 +1113,7 @@ struct FastWgradArgs {
 // slices of 64 rows.  LDS rows are TKC*2 bytes (x) / 256 B (dy); chunk c (16 B) of row r is stored at
 // slot c ^ ((r & 3) << 1), which spreads the 4 rows of every transpose-read block over 4 distinct
 // 32-byte bank windows.
-template <int TKC, bool RELU>
+template <int TKC, bool RELU, bool ASMDMA>
 __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
   constexpr int MR = 64;
   constexpr int X_ELEMS = MR * TKC, Y_ELEMS = MR * 128;
@@ -1169,7 +1178,7 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
                        (unsigned)iw < (unsigned)a.Win;
       const int64_t xoff =
           ((int64_t)((int)n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * TKC + xchunk * 8;
-      glds16(xok ? a.in + xoff : zero, Xb + j * 512);
+      glds16x<ASMDMA>(xok ? a.in + xoff : zero, Xb + j * 512);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1183,7 +1192,7 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(FastWgradArgs a) {
       const int64_t yoff =
           ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + c0 +
           ychunk * 8;
-      glds16((mok && y_ok) ? a.dy + yoff : zero, Yb + j * 512);
+      glds16x<ASMDMA>((mok && y_ok) ? a.dy + yoff : zero, Yb + j * 512);
     }
   };
 
@@ -1603,7 +1612,7 @@ struct HaloWgradArgs {
 constexpr int HW_GROUPS = 20;   // halo staging groups (8 rows each) per buffer: up to 160 pixels
 constexpr int HW_SLOTS = HW_GROUPS / 4;
 
-template <bool RELU, bool W4>
+template <bool RELU, bool W4, bool ASMDMA>
 __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
   __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * (HW_GROUPS * 512 + 64 * 64)];
   auto Xh = [&](int buf) { return smem + buf * (HW_GROUPS * 512 + 64 * 64); };
@@ -1664,7 +1673,7 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
                         (unsigned)iw < (unsigned)a.Win;
         const int64_t off =
             ((int64_t)(n * a.Hin + ih) * a.Win + iw) * a.Ci + cb * 64 + ((d >> 16) & 7) * 8;
-        glds16(ok ? a.in + off : zero, Xb + (j * 4 + wave) * 512);
+        glds16x<ASMDMA>(ok ? a.in + off : zero, Xb + (j * 4 + wave) * 512);
       }
     }
 #pragma unroll
@@ -1675,7 +1684,7 @@ __global__ __launch_bounds__(256, 2) void halo_wgrad_kernel(HaloWgradArgs a) {
       const int c8 = ((d >> 16) & 7) * 8;
       const bool ok = n < a.N && (c0 + c8) < a.Co;
       const int64_t off = ((int64_t)(n * a.Ho + oh) * a.Wo + ow) * a.Co + c0 + c8;
-      glds16(ok ? a.dy + off : zero, Yb + j * 512);
+      glds16x<ASMDMA>(ok ? a.dy + off : zero, Yb + j * 512);
     }
   };
 
@@ -2301,6 +2310,15 @@ void cg_fast_wgrad_plan(const cgConvGeom* g, int* splits, int* rows_per_split) {
   *rows_per_split = rps;
 }
 
+// CGAMD_ASM_DMA=0 selects the builtin LDS-DMA forms of the weight-gradient kernels (A/B switch)
+static bool asm_dma_enabled() {
+  static const int on = [] {
+    const char* e = getenv("CGAMD_ASM_DMA");
+    return e ? atoi(e) : 1;
+  }();
+  return on != 0;
+}
+
 static bool halo_wgrad_ok(const cgConvGeom* g) {
   static const int off = [] {
     const char* e = getenv("CGAMD_NO_HALO_WGRAD");
@@ -2383,13 +2401,19 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
     dim3 grid(h.cblocks * h.ntiles, p.splits);
     CgProfScope prof(CG_PROF_HALO_WGRAD, g, st);
     const bool w4 = p.TW == 4;
-    if (h.relu_in) {
-      if (w4) halo_wgrad_kernel<true, true><<<grid, 256, 0, st>>>(h);
-      else halo_wgrad_kernel<true, false><<<grid, 256, 0, st>>>(h);
-    } else {
-      if (w4) halo_wgrad_kernel<false, true><<<grid, 256, 0, st>>>(h);
-      else halo_wgrad_kernel<false, false><<<grid, 256, 0, st>>>(h);
-    }
+#define HALO_WG(ASM_)                                                                  \
+  do {                                                                                 \
+    if (h.relu_in) {                                                                   \
+      if (w4) halo_wgrad_kernel<true, true, ASM_><<<grid, 256, 0, st>>>(h);            \
+      else halo_wgrad_kernel<true, false, ASM_><<<grid, 256, 0, st>>>(h);              \
+    } else {                                                                           \
+      if (w4) halo_wgrad_kernel<false, true, ASM_><<<grid, 256, 0, st>>>(h);           \
+      else halo_wgrad_kernel<false, false, ASM_><<<grid, 256, 0, st>>>(h);             \
+    }                                                                                  \
+  } while (0)
+    if (asm_dma_enabled()) HALO_WG(true);
+    else HALO_WG(false);
+#undef HALO_WG
     if (p.splits > 1) {
       const int64_t n4 = (int64_t)(KC / 4);
       launch_split_reduce4_pair(wsf, n4, dw, wsf + (size_t)p.splits * KC, g->Co / 4, dbias,
@@ -2431,17 +2455,19 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
   }
   dim3 grid(a.ktiles * a.ntiles, splits);
   CgProfScope prof(tkc == 128 ? CG_PROF_FAST_WGRAD_128 : CG_PROF_FAST_WGRAD_64, g, st);
+#define FAST_WG(TKC_, ASM_)                                                            \
+  do {                                                                                 \
+    if (a.relu_in) fast_wgrad_kernel<TKC_, true, ASM_><<<grid, 256, 0, st>>>(a);       \
+    else fast_wgrad_kernel<TKC_, false, ASM_><<<grid, 256, 0, st>>>(a);                \
+  } while (0)
   if (tkc == 128) {
-    if (a.relu_in)
-      fast_wgrad_kernel<128, true><<<grid, 256, 0, st>>>(a);
-    else
-      fast_wgrad_kernel<128, false><<<grid, 256, 0, st>>>(a);
+    if (asm_dma_enabled()) FAST_WG(128, true);
+    else FAST_WG(128, false);
   } else {
-    if (a.relu_in)
-      fast_wgrad_kernel<64, true><<<grid, 256, 0, st>>>(a);
-    else
-      fast_wgrad_kernel<64, false><<<grid, 256, 0, st>>>(a);
+    if (asm_dma_enabled()) FAST_WG(64, true);
+    else FAST_WG(64, false);
   }
+#undef FAST_WG
   const int64_t c4 = g->Co / 4;
   if (splits > 1) {
     const int64_t n4 = (int64_t)(KC / 4);  // Ci % 64 == 0 and Co % 8 == 0 -> divisible

@@ -758,6 +758,8 @@ struct HWgradArgs {
   int accumulate;
   int dy_up;         // dy is [N, H/2, W/2, Co]: the gradient of a 2x2 average pooling behind the
   float out_scale;   // convolution (its nearest-neighbour up-sampling times out_scale = 1/4)
+  int asm_dma;       // LDS-DMA from inline asm (cg_dma16_asm): keeps hipcc from draining the next
+                     // slice's prefetch in front of the transposed LDS reads (CGAMD_ASM_DMA, A/B)
   FastDiv dNt, dTx, dTy;
 };
 
@@ -772,7 +774,7 @@ __device__ __forceinline__ bf16x8_t hc_tr_read2(hc_lds_ptr p) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <bool RELU, int TWL>
+template <bool RELU, int TWL, bool ASMDMA>
 __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
   constexpr int TW = 1 << TWL, TH = 256 >> TWL, PITCH = TW + 2;
   constexpr int HROWS = (TH + 2) * PITCH;
@@ -811,34 +813,74 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
                   ? (uint32_t)((((y >> us) * (a.Win >> us) + (x >> us)) * a.Co + c0 + c * 8) * 2)
                   : HC_OOB;
   }
-  auto stage = [&](int buf, int sl) {
+  // staging of one slice, in two steps so that the inline-asm form can spread the pieces over the
+  // k-steps of the slice being multiplied: prepare() = the slice's scalars, piece(i) = one 1-KiB DMA
+  // (i < HC_HSLOTS: window piece wave + 8 i, then the 4 dy pieces of this wave)
+  struct StageCtx {
+    int iy0, ix0;
+    const bf16_t* xo;
+    const bf16_t* yo;
+    cg_i32x4_t rxa, rya;
+    uint32_t xb_addr, yb_addr;
+  };
+  constexpr int NPIECE = HC_HSLOTS + 4;
+  auto stage_prepare = [&](StageCtx& c, int buf, int sl) {
     // slice -> (image, tile row, tile column): wave-uniform
     const int t1 = (int)fdiv((uint32_t)sl, a.dTx);
     const int tx = sl - t1 * a.tiles_x;
     const int n = (int)fdiv((uint32_t)t1, a.dTy);
     const int ty = t1 - n * a.tiles_y;
-    const int iy0 = ty * TH - a.pt, ix0 = tx * TW - a.pl;
-    const bf16_t* xo = a.in + (((int64_t)n * a.Hin + iy0) * a.Win + ix0) * a.Ci + cb * 64;
+    c.iy0 = ty * TH - a.pt;
+    c.ix0 = tx * TW - a.pl;
+    c.xo = a.in + (((int64_t)n * a.Hin + c.iy0) * a.Win + c.ix0) * a.Ci + cb * 64;
     const int us = a.dy_up;   // tile origins are even
-    const bf16_t* yo = a.dy + (((int64_t)n * (a.Hin >> us) + ((ty * TH) >> us)) * (a.Win >> us) +
-                               ((tx * TW) >> us)) * a.Co;
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc((void*)xo, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry =
-        __builtin_amdgcn_make_buffer_rsrc((void*)yo, 0, 0x7fffffff, 0x00020000);
-    unsigned char* Xb = smem + buf * BUF;
-    unsigned char* Yb = Xb + X_BYTES;
-#pragma unroll
-    for (int j = 0; j < HC_HSLOTS; ++j) {
-      if (wave + 8 * j < HC_HALO_PIECES) {
-        const int hy = hyx[j] & 0xffff, hx = hyx[j] >> 16;
-        const bool ok = (unsigned)(iy0 + hy) < (unsigned)a.Hin &&
-                        (unsigned)(ix0 + hx) < (unsigned)a.Win;
-        hc_dma16(rx, ok ? hrel[j] : HC_OOB, 0, Xb + (wave + 8 * j) * 1024);
-      }
+    c.yo = a.dy + (((int64_t)n * (a.Hin >> us) + ((ty * TH) >> us)) * (a.Win >> us) +
+                   ((tx * TW) >> us)) * a.Co;
+    if constexpr (ASMDMA) {
+      c.rxa = cg_make_rsrc(c.xo, 0x7fffffffu);
+      c.rya = cg_make_rsrc(c.yo, 0x7fffffffu);
+      c.xb_addr = cg_lds_addr(smem + buf * BUF);
+      c.yb_addr = c.xb_addr + X_BYTES;
     }
+  };
+  auto stage_piece = [&](const StageCtx& c, int i) {   // ASMDMA only; i is a compile-time constant
+    if (i < HC_HSLOTS) {
+      if (wave + 8 * i < HC_HALO_PIECES) {
+        const int hy = hyx[i] & 0xffff, hx = hyx[i] >> 16;
+        const bool ok = (unsigned)(c.iy0 + hy) < (unsigned)a.Hin &&
+                        (unsigned)(c.ix0 + hx) < (unsigned)a.Win;
+        cg_dma16_asm(c.rxa, ok ? hrel[i] : HC_OOB, 0u, c.xb_addr + (wave + 8 * i) * 1024);
+      }
+    } else {
+      const int j = i - HC_HSLOTS;
+      cg_dma16_asm(c.rya, yrel[j], 0u, c.yb_addr + (wave * 4 + j) * 1024);
+    }
+  };
+  auto stage = [&](int buf, int sl) {
+    StageCtx c;
+    stage_prepare(c, buf, sl);
+    if constexpr (ASMDMA) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) hc_dma16(ry, yrel[j], 0, Yb + (wave * 4 + j) * 1024);
+      for (int i = 0; i < NPIECE; ++i) stage_piece(c, i);
+    } else {
+      unsigned char* Xb = smem + buf * BUF;
+      unsigned char* Yb = Xb + X_BYTES;
+      const __amdgpu_buffer_rsrc_t rx =
+          __builtin_amdgcn_make_buffer_rsrc((void*)c.xo, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t ry =
+          __builtin_amdgcn_make_buffer_rsrc((void*)c.yo, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < HC_HSLOTS; ++j) {
+        if (wave + 8 * j < HC_HALO_PIECES) {
+          const int hy = hyx[j] & 0xffff, hx = hyx[j] >> 16;
+          const bool ok = (unsigned)(c.iy0 + hy) < (unsigned)a.Hin &&
+                          (unsigned)(c.ix0 + hx) < (unsigned)a.Win;
+          hc_dma16(rx, ok ? hrel[j] : HC_OOB, 0, Xb + (wave + 8 * j) * 1024);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hc_dma16(ry, yrel[j], 0, Yb + (wave * 4 + j) * 1024);
+    }
   };
 
   // ---- transpose-read addressing: for k-step ks (16 pixels) this lane supplies pixel
@@ -873,7 +915,16 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
     const int buf = (sl - sbeg) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");   // slice landed for everybody; the other buffer is free
-    if (sl + 1 < send) stage(buf ^ 1, sl + 1);
+    // the next slice: all pieces at once (builtin DMA: hipcc waits for them before the first
+    // transposed read anyway), or spread over the first NPIECE k-steps below (inline-asm DMA: the 8
+    // waves no longer stall in the DMA issue queue together while the matrix pipes idle)
+    const bool more = sl + 1 < send;
+    StageCtx nctx;
+    if constexpr (ASMDMA) {
+      if (more) stage_prepare(nctx, buf ^ 1, sl + 1);
+    } else {
+      if (more) stage(buf ^ 1, sl + 1);
+    }
     const int boff = buf * BUF;
     int xb[4];
 #pragma unroll
@@ -884,6 +935,9 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
       constexpr int NT = TG == 0 ? 5 : 4;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
+        if constexpr (ASMDMA) {
+          if (ks < NPIECE && more) stage_piece(nctx, ks);
+        }
         const int kc = TWL == 5 ? (ks >> 1) * PITCH + (ks & 1) * 16 : ks * PITCH;
         const bf16x8_t yf = hc_tr_read2(lds + yb + ks * 2048);
         if (TG == 1 && want_bias)
@@ -1170,7 +1224,7 @@ __global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
 // above) and the dy tile (DMA, hwgrad's transpose-read image) are staged, 4 waves split the 16
 // k-steps; dw^T fragments are 8 two-byte LDS reads at constant offsets.  Partials per split
 // [K*Co + Co] (dw then dbias), reduced by the caller.
-template <int TWL>
+template <int TWL, bool ASMDMA>
 __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
   constexpr int TW = 1 << TWL, TH = 256 >> TWL, CI = WS_CI;
   constexpr int WC = (TW + 2) * CI, K = 9 * CI;
@@ -1203,11 +1257,18 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
     const int us = a.dy_up;
     const bf16_t* yo = a.dy + (((int64_t)n * (a.H >> us) + ((ty * TH) >> us)) * (a.W >> us) +
                                ((tx * TW) >> us)) * a.Co;
-    const __amdgpu_buffer_rsrc_t ry =
-        __builtin_amdgcn_make_buffer_rsrc((void*)yo, 0, 0x7fffffff, 0x00020000);
+    if constexpr (ASMDMA) {
+      const cg_i32x4_t rya = cg_make_rsrc(yo, 0x7fffffffu);
+      const uint32_t yaddr = cg_lds_addr(ysm + buf * Y_BYTES);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      hc_dma16(ry, yrel[j], 0, ysm + buf * Y_BYTES + (wave * 8 + j) * 1024);
+      for (int j = 0; j < 8; ++j) cg_dma16_asm(rya, yrel[j], 0u, yaddr + (wave * 8 + j) * 1024);
+    } else {
+      const __amdgpu_buffer_rsrc_t ry =
+          __builtin_amdgcn_make_buffer_rsrc((void*)yo, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        hc_dma16(ry, yrel[j], 0, ysm + buf * Y_BYTES + (wave * 8 + j) * 1024);
+    }
     ws_load_window<TWL>(a, n, ty, tx, win[buf], tid, 256);
   };
 
@@ -1318,6 +1379,17 @@ static unsigned long long* g_hconv_tdbg = nullptr;
 extern "C" void cg_debug_set_hconv_timing_buffer(void* p) { g_hconv_tdbg = (unsigned long long*)p; }
 #endif
 
+// out-channel tile: 128 (two 32-channel MFMA tiles per wave) unless that leaves at most
+// CGAMD_HCONV_BN64_MAX workgroups (half a chip of the 128 x 16x16 x 128 layers): 64-channel tiles
+// then double the grid, which buys more than the wider tile saves on a K loop of 18 slices
+static int hc_pick_bn(const cgConvGeom* g) {
+  static const int bn64_max = hc_env("CGAMD_HCONV_BN64_MAX", 160);
+  if (g->Co <= 64) return 64;
+  const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
+  const int64_t wgs128 = (int64_t)g->N * (Hp * Wp / 256) * cdiv(g->Co, 128) * g->U * g->U;
+  return wgs128 <= bn64_max ? 64 : 128;
+}
+
 bool cg_hconv_geom_ok(const cgConvGeom* g) {
   if (g->S != 1 || (g->U != 1 && g->U != 2)) return false;
   if (g->kh > 3 || g->kw > 3) return false;
@@ -1337,7 +1409,7 @@ bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in
   if (!enabled || !cg_hconv_geom_ok(g)) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
-  const int bn = g->Co <= 64 ? 64 : 128;
+  const int bn = hc_pick_bn(g);
   const int64_t wgs = (int64_t)g->N * (Hp * Wp / 256) * cdiv(g->Co, bn) * g->U * g->U;
   return wgs >= min_wgs;
 }
@@ -1389,7 +1461,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   const int TW = 1 << twl, TH = 256 >> twl;
   a.tiles_x = Wp / TW;
   a.tiles_y = Hp / TH;
-  const int bn = g->Co <= 64 ? 64 : 128;
+  const int bn = hc_pick_bn(g);
   a.ntiles = cdiv(g->Co, bn);
   a.out_f32 = out_is_f32;
   a.slope_out = slope_out;
@@ -1483,6 +1555,8 @@ void cg_hwgrad_launch_pooled(const cgConvGeom* g, const void* in, const void* ga
   HWgradArgs h;
   h.dy_up = dy_pooled ? 1 : 0;
   h.out_scale = dy_pooled ? 0.25f : 1.f;
+  static const int asm_dma = hc_env("CGAMD_ASM_DMA", 1);
+  h.asm_dma = asm_dma;
   h.in = (const bf16_t*)in;
   h.dy = (const bf16_t*)dy;
   h.N = g->N; h.Hin = g->Hin; h.Win = g->Win; h.Ci = g->Ci; h.Co = g->Co;
@@ -1502,13 +1576,19 @@ void cg_hwgrad_launch_pooled(const cgConvGeom* g, const void* in, const void* ga
   dim3 grid(p.tiles, p.splits);
   CgProfScope prof(CG_PROF_HWGRAD, g, st);
   const bool relu = gate_in != nullptr;
-  if (p.twl == 5) {
-    if (relu) hwgrad_kernel<true, 5><<<grid, 512, 0, st>>>(h);
-    else hwgrad_kernel<false, 5><<<grid, 512, 0, st>>>(h);
-  } else {
-    if (relu) hwgrad_kernel<true, 4><<<grid, 512, 0, st>>>(h);
-    else hwgrad_kernel<false, 4><<<grid, 512, 0, st>>>(h);
-  }
+#define HW_LAUNCH(TWL_)                                                               \
+  do {                                                                                \
+    if (asm_dma) {                                                                    \
+      if (relu) hwgrad_kernel<true, TWL_, true><<<grid, 512, 0, st>>>(h);             \
+      else hwgrad_kernel<false, TWL_, true><<<grid, 512, 0, st>>>(h);                 \
+    } else {                                                                          \
+      if (relu) hwgrad_kernel<true, TWL_, false><<<grid, 512, 0, st>>>(h);            \
+      else hwgrad_kernel<false, TWL_, false><<<grid, 512, 0, st>>>(h);                \
+    }                                                                                 \
+  } while (0)
+  if (p.twl == 5) HW_LAUNCH(5);
+  else HW_LAUNCH(4);
+#undef HW_LAUNCH
   if (p.splits > 1)
     cg_split_reduce4_pair(wsf, (int64_t)(KC / 4), dw, wsf + (size_t)p.splits * KC, g->Co / 4,
                           dbias, p.splits, accumulate, st);
@@ -1620,8 +1700,14 @@ void cg_wstem_wgrad_launch_pooled(const cgConvGeom* g, const void* in, const voi
   a.want_bias = want_bias;
   a.tiles_per_wg = tps;
   dim3 grid(cdiv(g->Co, 64), splits);
-  if (hc_tile_log(g->Ho, g->Wo) == 5) wstem_wgrad_kernel<5><<<grid, 256, 0, st>>>(a);
-  else wstem_wgrad_kernel<4><<<grid, 256, 0, st>>>(a);
+  static const int asm_dma = hc_env("CGAMD_ASM_DMA", 1);
+  if (asm_dma) {
+    if (hc_tile_log(g->Ho, g->Wo) == 5) wstem_wgrad_kernel<5, true><<<grid, 256, 0, st>>>(a);
+    else wstem_wgrad_kernel<4, true><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (hc_tile_log(g->Ho, g->Wo) == 5) wstem_wgrad_kernel<5, false><<<grid, 256, 0, st>>>(a);
+    else wstem_wgrad_kernel<4, false><<<grid, 256, 0, st>>>(a);
+  }
   *splits_out = splits;
 }
 

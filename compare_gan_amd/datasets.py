@@ -148,7 +148,7 @@ class ImageDatasetV2(object):
     if not os.path.exists(path):
       raise ValueError("Dataset %s: no %s (expected arrays `image` uint8 [N,h,w,c] and `label`)" % (
           self._name, path))
-    with np.load(path, allow_pickle=True) as f:
+    with np.load(path, allow_pickle=False) as f:
       images, labels = f["image"], f["label"]
     if len(images) != len(labels):
       raise ValueError("%s: %d images but %d labels" % (path, len(images), len(labels)))

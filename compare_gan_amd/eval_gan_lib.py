@@ -33,16 +33,12 @@ def _update_bn_accumulators(gan, generate_fn, batch_size, num_accu_examples):
   switches = [v for n, v in gan.store.vars.items() if "accu/update_accus" in n]
   if not switches:
     return False
-  for v in switches:
-    v.fill_(1)
-  gan.store.accu_fill = True    # host mirror of the switch (arch_ops.standardize_batch)
+  gan.store.set_accu_fill(True)    # the variables and their host mirror (arch_ops.standardize_batch)
   try:
     for _ in range(num_accu_examples // batch_size):
       generate_fn()
   finally:
-    gan.store.accu_fill = False
-    for v in switches:
-      v.fill_(0)
+    gan.store.set_accu_fill(False)
   return True
 
 

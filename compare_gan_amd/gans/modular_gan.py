@@ -74,6 +74,7 @@ _DP_OVERLAP = os.environ.get("CGAMD_DP_OVERLAP", "auto")
 _JOINT_G = os.environ.get("CGAMD_JOINT_G", "1") != "0"   # batched generator forwards (A/B switch)
 _DEFER_WGRAD = os.environ.get("CGAMD_DEFER_WGRAD", "1") != "0"   # grouped small-map weight gradients
 _DP_OVERLAP_MIN_BYTES = 32 << 20
+_NCCL_WATCHDOG_POLL_S = 0.1   # ProcessGroupNCCL's watchdog poll period (see _capture)
 
 
 class _OptimizerState(object):
@@ -300,6 +301,11 @@ class ModularGAN(AbstractGAN):
     self.g_opt = _OptimizerState(g_vars, self.get_gen_optimizer(), self._g_use_ema, self.device)
     self.d_opt = _OptimizerState(d_vars, self.get_disc_optimizer(), False, self.device)
     tpu_random.set_random_offset(seed, self.global_step)
+    # a forward pass of either network first waits for an update of ITS variables that may still
+    # be in flight on the communication stream (ops.prepare_module runs these before anything reads
+    # a variable): subclasses and new call sites need no join() of their own
+    self.store.before_call = {self.generator.name: self.g_opt.join,
+                              self.discriminator.name: self.d_opt.join}
     self._built = True
     return self
 
@@ -533,6 +539,7 @@ class ModularGAN(AbstractGAN):
       raise ValueError("Joining G forward passes is only supported for unrolled graphs.")
     # the random streams are keyed by (name, global_step): the calls between two G updates get
     # distinct names, as the reference's stateful random ops give them distinct draws
+    self._join_updates()
     f, l = self._preprocess(images, labels, int(self.global_step_disc.item()) % self._disc_iters)
     with ops.use_store(self.store):
       sampled_y = None
@@ -542,6 +549,10 @@ class ModularGAN(AbstractGAN):
       self.g_opt.join()
       f["generated"] = self.generator(f["z"], y=sampled_y, is_training=True)
       d_loss = self._train_discriminator(f, l)
+      # the counter is incremented on the stream the update ran on: under data-parallel overlap
+      # that is the communication stream, and .item() only synchronises the current one -- a stale
+      # value would make ranks disagree on whether the G update (and its all-reduce) happens
+      self.d_opt.join()
       if int(self.global_step_disc.item()) % self._disc_iters == 0:
         g_loss = self._train_generator(f, l, shared_forward=True)
       else:
@@ -650,13 +661,14 @@ class ModularGAN(AbstractGAN):
     self.d_opt.reserve_tables(d_updates)
     self.g_opt.reserve_tables(g_updates)
     if tpu_ops.data_parallel() and tpu_ops.thread_state() is None:
-      # The process group's watchdog thread polls the end events of the warm-up's eager
-      # collectives every 100 ms until it has seen them complete.  Once the captured collectives
-      # below pull RCCL's internal stream into the capture, such a query fails with
-      # hipErrorCapturedEvent and the watchdog aborts the process (seen about one run in three
-      # with a capture that reaches its first collective within 100 ms): let it drain first.
+      # The process group's watchdog thread retires the warm-up's eager collectives by querying
+      # their end events once per poll period (ProcessGroupNCCL: kWatchdogThreadSleepMillis =
+      # 100 ms).  Once the captured collectives below pull RCCL's internal stream into the capture,
+      # such a query fails with hipErrorCapturedEvent and the watchdog aborts the process.  After
+      # the device synchronize above every one of those collectives HAS completed, so waiting a
+      # little more than two poll periods is a bound, not a guess: the watchdog has seen them all.
       import time
-      time.sleep(0.5)
+      time.sleep(2.5 * _NCCL_WATCHDOG_POLL_S)
     self._graph = torch.cuda.CUDAGraph()
     graph_kwargs = {}
     if tpu_ops.num_replicas() > 1 or tpu_ops.force_data_parallel():

@@ -67,6 +67,8 @@ GP = ctypes.POINTER(ConvGeom)
 SIGNATURES = {
     "cg_abi_version": (c_int, []),
     "cg_last_error": (ctypes.c_char_p, []),
+    "cg_calib_mfma_bf16": (c_int, [c_int, c_int, vp, ctypes.POINTER(c_f64), vp]),
+    "cg_calib_copy": (c_int, [vp, vp, c_sz, vp]),
     "cg_prof_family_count": (c_int, []),
     "cg_prof_family_name": (ctypes.c_char_p, [c_int]),
     "cg_prof_enable": (c_int, [c_int]),

@@ -1156,6 +1156,42 @@ def pool2d(x, k, s, p, kind, Ho, Wo):
 
 
 # ------------------------------------------------------------------------------------------------
+# calibration microbenchmarks (bench.py: measured roofline denominators)
+# ------------------------------------------------------------------------------------------------
+def calibrate(device, mfma_ms=50.0, copy_mb=1024):
+    """{"mfma_bf16_tflops", "hbm_copy_gbs"} of THIS box, now: a pure MFMA loop of about `mfma_ms`
+    milliseconds on random operands and a float4 copy of `copy_mb` MiB (read + write counted),
+    each timed with stream events after one untimed run."""
+    sink = torch.zeros(4, dtype=F32, device=device)
+    fl = ctypes.c_double(0.0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def mfma(iters):
+        check(lib().cg_calib_mfma_bf16(2048, int(iters), _p(sink), ctypes.byref(fl), _stream()),
+              "cg_calib_mfma_bf16")
+    mfma(200)
+    torch.cuda.synchronize()
+    # 2048 blocks x 4 waves x 8 MFMAs x 32 cycles per round over 1024 SIMDs: 2048 cycles per round
+    iters = max(200, int(mfma_ms * 1e-3 * 2.0e9 / 2048))
+    ev[0].record()
+    mfma(iters)
+    ev[1].record()
+    n = int(copy_mb) << 20
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    check(lib().cg_calib_copy(_p(src), _p(dst), n, _stream()), "cg_calib_copy")
+    ev[2].record()
+    for _ in range(4):
+        check(lib().cg_calib_copy(_p(src), _p(dst), n, _stream()), "cg_calib_copy")
+    ev[3].record()
+    torch.cuda.synchronize()
+    t_m = ev[0].elapsed_time(ev[1]) * 1e-3
+    t_c = ev[2].elapsed_time(ev[3]) * 1e-3
+    return {"mfma_bf16_tflops": fl.value / t_m / 1e12, "mfma_ms": t_m * 1e3,
+            "hbm_copy_gbs": 4 * 2.0 * n / t_c / 1e9, "copy_mb": int(copy_mb)}
+
+
+# ------------------------------------------------------------------------------------------------
 # kernel-family timing (bench.py roofline leg)
 # ------------------------------------------------------------------------------------------------
 def prof_enable(on):

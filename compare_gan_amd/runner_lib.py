@@ -146,11 +146,16 @@ def _parse_gin_config(config_path):
 
 def save_checkpoint(gan, model_dir, step):
   path = os.path.join(model_dir, "model.ckpt-{}.pt".format(step))
-  torch.save({k: v.cpu() for k, v in gan.state_dict().items()}, path)
+  # every file appears under its final name complete (temp file + os.replace): a peer process or a
+  # continuous-eval job polling the directory never reads a half-written checkpoint or an empty marker
+  torch.save({k: v.cpu() for k, v in gan.state_dict().items()}, path + ".tmp")
+  os.replace(path + ".tmp", path)
   with open(os.path.join(model_dir, "operative_config-{}.gin".format(step)), "w") as f:
     f.write(gin.operative_config_str())
-  with open(os.path.join(model_dir, "checkpoint"), "w") as f:
+  marker = os.path.join(model_dir, "checkpoint")
+  with open(marker + ".tmp", "w") as f:
     f.write(os.path.basename(path) + "\n")
+  os.replace(marker + ".tmp", marker)
   return path
 
 
@@ -160,8 +165,26 @@ def latest_checkpoint(model_dir):
     return None
   with open(marker) as f:
     name = f.read().strip()
+  if not name:
+    return None
   path = os.path.join(model_dir, name)
-  return path if os.path.exists(path) else None
+  return path if os.path.isfile(path) else None
+
+
+def _barrier():
+  import torch.distributed as dist
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist.barrier()
+
+
+def _broadcast_from_rank0(value):
+  """`value` of rank 0 on every rank (a small picklable object)."""
+  import torch.distributed as dist
+  if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    return value
+  box = [value]
+  dist.broadcast_object_list(box, src=0)
+  return box[0]
 
 
 def _run_eval(gan, checkpoint_path, task_manager, options, num_averaging_runs, device):
@@ -216,7 +239,10 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
   bsz = options["batch_size"] // world              # runner_lib.py:84-85
   gan.build(batch_size=bsz, device=device, seed=seed)
   start = 0
-  ckpt = latest_checkpoint(run_config.model_dir)
+  # rank 0 decides where to resume and tells the others: ranks looking at the directory on their own
+  # could disagree while rank 0 writes checkpoint 0
+  ckpt = _broadcast_from_rank0(
+      latest_checkpoint(run_config.model_dir) if tpu_ops.replica_id() == 0 else None)
   if ckpt is not None:                              # README.md:93-94 resume
     gan.load_state_dict(torch.load(ckpt, map_location=device))
     start = int(gan.global_step.item())
@@ -224,6 +250,7 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
   batches = dataset.train_batches(bsz * num_sub, seed=dataset._seed + tpu_ops.replica_id())  # pylint: disable=protected-access
   if start == 0 and tpu_ops.replica_id() == 0:
     save_checkpoint(gan, run_config.model_dir, 0)
+  _barrier()
   t0, last = time.time(), start
   for step in range(start, options["training_steps"]):
     images, labels = next(batches)
@@ -247,4 +274,5 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
     for checkpoint_path in task_manager.unevaluated_checkpoints(
         eval_every_steps=eval_every_steps if eval_every_steps > 0 else None):
       _run_eval(gan, checkpoint_path, task_manager, options, num_eval_averaging_runs, device)
+  _barrier()    # nobody tears the process group down while rank 0 still evaluates
   return gan

@@ -53,6 +53,14 @@ int cg_prof_enable(int on);
 int cg_prof_reset(void);
 int cg_prof_collect(int family, double* total_ms, int64_t* launches, double* flops, double* bytes);
 
+/* Calibration microbenchmarks for the roofline denominators of bench.py (the
+ * boxes of a pool differ in sustained clocks, so fractions are also reported against what THIS box
+ * reaches): a pure v_mfma_f32_32x32x16_bf16 loop (`blocks` workgroups of 4 waves, `iters` rounds of
+ * 8 independent MFMAs per wave on random operands; *flops = what the launch executes) and a float4
+ * copy of `bytes` (multiple of 16) bytes.  The caller times them with stream events. */
+int cg_calib_mfma_bf16(int blocks, int iters, float* sink, double* flops, cgStream stream);
+int cg_calib_copy(const void* src, void* dst, size_t bytes, cgStream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Generalised convolution geometry.
  *
