@@ -52,12 +52,16 @@ class VarStore(object):
   """name -> tensor, created on first use in call order (abstract_arch.py:71-74 AUTO_REUSE)."""
 
   def __init__(self, dtype=torch.float64, seed=0, weights_initializer="normal",
-               weights_stddev=0.02, emulate_bf16=False):
+               weights_stddev=0.02, emulate_bf16=False, device="cpu"):
     # emulate_bf16: snap every tensor the HIP path STORES in bf16 (activations, their gradients,
     # MFMA weight operands) to the bf16 grid, keeping all arithmetic in fp64.  ReLU networks have
     # discontinuous gradients, so the exact-fp64 oracle and a bf16 pipeline disagree by O(sqrt(eps))
     # through flipped ReLU masks; this mode removes that effect and isolates real defects.
     self.emulate_bf16 = emulate_bf16
+    # device: where the variables live.  "cpu" is the oracle proper; a CUDA device runs the SAME
+    # restatement in fp64 on plain torch ops (no libcgamd kernel) for the parity tests at the
+    # benchmark's batch sizes, where the CPU needs minutes per case (tests/ only)
+    self.device = torch.device(device)
     self.vars = {}
     self.trainable = []
     self.dtype = dtype
@@ -83,7 +87,7 @@ class VarStore(object):
 
   def get(self, name, shape, init, trainable=True):
     if name not in self.vars:
-      v = init(tuple(shape)).to(self.dtype)
+      v = init(tuple(shape)).to(self.dtype).to(self.device)
       if trainable:
         v.requires_grad_(True)
         self.trainable.append(name)
@@ -151,12 +155,33 @@ def same_pads(size, k, stride):
 
 def conv2d_same(x, w, stride):
   """tf.nn.conv2d(x, w, strides=[1,s,s,1], padding='SAME')  (arch_ops.py:568).  x NHWC, w HWIO."""
+  if x.is_cuda:
+    return conv2d_same_gemm(x, w, stride)
   kh, kw = w.shape[0], w.shape[1]
   _, pt, pb = same_pads(x.shape[1], kh, stride)
   _, pl, pr = same_pads(x.shape[2], kw, stride)
   xp = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
   y = F.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride)
   return y.permute(0, 2, 3, 1)
+
+
+def conv2d_same_gemm(x, w, stride):
+  """The same convolution as one matrix product per filter tap (the shifted, strided view of the
+  padded input times w[r, s]): every step is a plain tensor op, so it runs in fp64 on any device
+  and differentiates to any order.  tests/test_oracle_direct.py pins it to conv2d_same and to the
+  direct-loop restatement (oracle/direct.py)."""
+  kh, kw, ci, co = w.shape
+  n, h, wd, _ = x.shape
+  ho, pt, pb = same_pads(h, kh, stride)
+  wo, pl, pr = same_pads(wd, kw, stride)
+  xp = F.pad(x, (0, 0, pl, pr, pt, pb))
+  out = None
+  for r in range(kh):
+    for s in range(kw):
+      v = xp[:, r:r + (ho - 1) * stride + 1:stride, s:s + (wo - 1) * stride + 1:stride, :]
+      t = v.reshape(-1, ci) @ w[r, s]
+      out = t if out is None else out + t
+  return out.reshape(n, ho, wo, co)
 
 
 def conv2d_transpose_same(x, w, out_hw, stride):

@@ -27,10 +27,13 @@ def build_product(config, batch_size, device, seed=3, bindings=()):
     return gan, options, dataset
 
 
-def mirror_to_oracle(gan, dtype=torch.float64, **store_kwargs):
-    vs = oops.VarStore(dtype=dtype, **store_kwargs)
+def mirror_to_oracle(gan, dtype=torch.float64, device="cpu", **store_kwargs):
+    """The product's variables as an oracle VarStore.  device != "cpu": the restatement runs in fp64
+    on plain torch ops on that device (oracle/arch_ops.py VarStore.device) -- the checker for the
+    parity tests at the benchmark's batch sizes."""
+    vs = oops.VarStore(dtype=dtype, device=device, **store_kwargs)
     for name, v in gan.store.vars.items():
-        t = v.detach().to("cpu").to(dtype).clone()
+        t = v.detach().to(device).to(dtype).clone()
         if name in gan.store.trainable:
             t.requires_grad_(True)
             vs.trainable.append(name)

@@ -270,6 +270,99 @@ def test_deferred_wgrads_match_immediate(K, dev):
         assert_close_f32(b, a.double().cpu(), "deferred vs immediate", rtol=1e-4, abs_rms=1e-4)
 
 
+FUSED_FULL_SIZE = [
+    # name, N, H, W, Ci, Co, relu_in, residual -- the pooled convolutions of the ResNet5-128 D-step at
+    # the benchmark's batch (2 x 64 images): B0 conv2 and its RGB shortcut at 128x128, B1 shortcut
+    ("B0_conv2_128x128", 128, 128, 128, 64, 64, True, True),
+    ("B0_rgb_shortcut_128x128", 128, 128, 128, 3, 64, False, False),
+    ("B1_shortcut_64x64", 128, 64, 64, 64, 128, False, False),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_FULL_SIZE, ids=[c[0] for c in FUSED_FULL_SIZE])
+def test_conv_pool_fused_full_size(K, dev, case):
+    """ConvPoolFn at the sizes bench.py's resnet128_dstep leg runs: the pooled
+    epilogue (FUSE = 2 / wstem pooled), the data gradient through the up-sampled read of the pooled
+    dy (in_up) and the weight / bias gradients from the pooled dy (pooled hwgrad / wstem_wgrad),
+    against fp64 autograd over per-tap GEMMs in plain torch on the device."""
+    from compare_gan_amd.hip import functional as Fn
+    name, N, H, W, Ci, Co, relu_in, with_res = case
+    g = torch.Generator(device=dev).manual_seed(sum(ord(c) for c in name))
+    xb = torch.randn((N, H, W, Ci), generator=g, device=dev).to(BF16)
+    wb = (torch.randn((3, 3, Ci, Co), generator=g, device=dev) / math.sqrt(9 * Ci)).to(BF16)
+    bias = torch.randn(Co, generator=g, device=dev)
+    rb = torch.randn((N, H // 2, W // 2, Co), generator=g, device=dev).to(BF16)
+    dyb = torch.randn((N, H // 2, W // 2, Co), generator=g, device=dev).to(BF16)
+    geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+    assert K.gconv_pool_supported(geom)
+    # reference
+    xr = xb.double().requires_grad_(True)
+    wr = wb.double().requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    conv = oops.conv2d_same_gemm(torch.relu(xr) if relu_in else xr, wr, 1) + br
+    ref = F.avg_pool2d(conv.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + rb.double()
+    gx_r, gw_r, gb_r = torch.autograd.grad((ref * dyb.double()).sum(), [xr, wr, br])
+    ref = ref.detach()
+    del conv
+    # product
+    xd = xb.clone().requires_grad_(True)
+    wd = wb.float().requires_grad_(True)
+    bd = bias.clone().requires_grad_(True)
+    y = Fn.conv_pool(xd, wd, bd, residual_p=rb if with_res else None,
+                     gate_in=xd if relu_in else None,
+                     spec=Fn.ConvSpec(geom, slope_in=0.0 if relu_in else None))
+    _close_on_device(y, ref, name + " pooled fwd", 2.0 * 2.0 ** -8, 2.0 ** -8)
+    gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], grad_outputs=dyb)
+    _close_on_device(gw, gw_r, name + " wgrad from pooled dy", 2e-4, 2e-4)
+    _close_on_device(gb, gb_r, name + " dbias from pooled dy", 2e-4, 2e-4)
+    if Ci > 3:   # the image itself needs no gradient in a D sub-step without a penalty
+        _close_on_device(gx, gx_r, name + " dgrad (in_up)", 2.0 * 2.0 ** -8, 2.0 ** -8)
+
+
+@pytest.mark.parametrize("case", [
+    # name, N, H, W, Ci, Co, up, per_sample: generator layers of the D-step leg (batch 64)
+    ("G_64x64_c128", 64, 64, 64, 128, 128, 1, False),
+    ("G_up_32to64_c256_128", 64, 32, 32, 256, 128, 2, False),
+    ("G_128x128_c64", 64, 128, 128, 64, 64, 1, False),
+], ids=lambda c: c[0])
+def test_gconv_fused_batch_norm_full_size(K, dev, case):
+    """cg_gconv_fused (FUSE = 1: batch-norm + ReLU prologue in LDS, statistics epilogue) at the
+    generator's sizes in bench.py's legs, against the fp64 restatement on the device."""
+    from tests.util import bf16_round
+    name, N, H, W, Ci, Co, up, per_sample = case
+    g = torch.Generator(device=dev).manual_seed(sum(ord(c) for c in name))
+    xb = torch.randn((N, H, W, Ci), generator=g, device=dev).to(BF16)
+    wb = (torch.randn((3, 3, Ci, Co), generator=g, device=dev) / math.sqrt(9 * Ci)).to(BF16)
+    bias = torch.randn(Co, generator=g, device=dev)
+    gamma = 1.0 + 0.3 * torch.randn(Ci, generator=g, device=dev)
+    beta = 0.3 * torch.randn(Ci, generator=g, device=dev)
+    x64 = xb.double()
+    mean = x64.mean(dim=(0, 1, 2)).float()
+    var = (x64.pow(2).mean(dim=(0, 1, 2)) - x64.mean(dim=(0, 1, 2)).pow(2)).float()
+    geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, up)
+    assert K.gconv_fused_rows(geom) > 0
+    bt_f, _ = K.weight_prep(wb.float())
+    act = bf16_round(torch.relu((x64 - mean.double()) * torch.rsqrt(var.double() + 1e-5) *
+                                gamma.double() + beta.double()))
+    if up == 2:
+        z = act.new_zeros((N, 2 * H, 2 * W, Ci))
+        z[:, ::2, ::2, :] = act
+        act = z
+    ref = oops.conv2d_same_gemm(act, wb.double(), 1) + bias.double()
+    del act
+    out, part = K.gconv_fused(geom, xb, bt_f, bias=bias,
+                              bn=(mean, var, gamma, beta, 1e-5, per_sample), want_stats=True)
+    _close_on_device(out, ref, name + " fused fwd", 3.0 * 2.0 ** -8, 2.0 ** -6)
+    stored = out.double()
+    m2, v2 = K.bn_finalize(part, N * geom.Ho * geom.Wo)
+    m_ref = stored.mean(dim=(0, 1, 2))
+    _close_on_device(m2, m_ref, name + " fused mean", 1e-4, 1e-4)
+    _close_on_device(v2, stored.pow(2).mean(dim=(0, 1, 2)) - m_ref.pow(2), name + " fused var", 1e-3,
+                     1e-4)
+
+
 @pytest.mark.parametrize("size", [8, 32])
 @pytest.mark.parametrize("slope", [0.0, 0.2])
 def test_gconv_gates_residual(K, dev, slope, size):
