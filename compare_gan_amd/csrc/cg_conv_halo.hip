@@ -567,7 +567,11 @@ constexpr int RW_PIECES = 26;             // 6 x 34 = 204 halo rows -> 26 pieces
 constexpr int RW_HB = RW_PIECES * 1024;   // one window buffer
 constexpr int RW_SLOTS = 7;               // pieces per wave (4 waves)
 
-template <bool RELU>
+// POOL: 2x2 average pooling in the epilogue (the wave's two tile rows are vertical neighbours:
+// acc[0] + acc[1] in registers, horizontal pairs from the staging rows); a.in_up: the input is the
+// pooled-resolution tensor read through its nearest-neighbour up-sampling (data gradient of a pooled
+// convolution, with a.out_scale = 1/4) -- the two forms of hconv_kernel<64, *, 5, 2>
+template <bool RELU, bool POOL>
 __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
   constexpr int TW = 32, TH = 4, PITCH = TW + 2, HROWS = (TH + 2) * PITCH;
   constexpr int SP = 32 * 4 + 16;         // epilogue staging row pitch (32 channels fp32 + pad)
@@ -597,7 +601,10 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
     const int row = (wave + 4 * j) * 8 + (lane >> 3);
     const int hy = row / PITCH, hx = row - hy * PITCH;
     const int c = (lane & 7) ^ ((hx >> 1) & 7);
-    hrel[j] = (uint32_t)(((hy * a.Win + hx) * 64 + c * 8) * 2);
+    // in_up: window pixel (iy0 + hy, ix0 + hx) with iy0, ix0 odd lives at ((iy0 + hy) >> 1, ...) of
+    // the half-resolution tensor = (hy + 1) >> 1 rows below the row of iy0 (see stage())
+    hrel[j] = a.in_up ? (uint32_t)(((((hy + 1) >> 1) * (a.Win >> 1) + ((hx + 1) >> 1)) * 64 + c * 8) * 2)
+                      : (uint32_t)(((hy * a.Win + hx) * 64 + c * 8) * 2);
     hyx[j] = row < HROWS ? (hy | (hx << 16)) : 0x7fff7fff;
   }
   auto stage = [&](int buf, int t) {
@@ -605,8 +612,11 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
     const int tx = t - q * a.tiles_x;
     const int n = (int)fdiv((uint32_t)q, a.dTy);
     const int ty = q - n * a.tiles_y;
-    const int iy0 = ty * TH - a.pt, ix0 = tx * TW - a.pl;
-    const bf16_t* xo = a.in + (((int64_t)n * a.Hin + iy0) * a.Win + ix0) * 64;
+    const int iy0 = ty * TH - a.pt, ix0 = tx * TW - a.pl;   // pt = pl = 1: both odd
+    const bf16_t* xo =
+        a.in_up ? a.in + (((int64_t)n * (a.Hin >> 1) + ((iy0 - 1) >> 1)) * (a.Win >> 1) +
+                          ((ix0 - 1) >> 1)) * 64
+                : a.in + (((int64_t)n * a.Hin + iy0) * a.Win + ix0) * 64;
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc((void*)xo, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -652,9 +662,24 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
     // stores too and retires in order, so leaving exactly those stores outstanding (4 bf16 / 8 fp32
     // store instructions per wave and tile) waits for the window without draining the stores
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (a.out_f32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (POOL) {   // one pooled pixel x 8 channels per lane: 1 bf16 / 2 fp32 store instructions
+      if (a.out_f32) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else if (a.out_f32) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");   // window landed; everyone is done with the other buffer
+    // pooled form: this lane's residual leaves BEFORE the next window's DMA pieces, so that waiting
+    // for it in the epilogue (vmcnt retires in order) does not drain them
+    uint4 res_pool = make_uint4(0u, 0u, 0u, 0u);
+    if (POOL && a.residual) {
+      const int q0 = (int)fdiv((uint32_t)t, a.dTx);
+      const int tx0 = t - q0 * a.tiles_x;
+      const int n0 = (int)fdiv((uint32_t)q0, a.dTy);
+      const int ty0 = q0 - n0 * a.tiles_y;
+      const int oy = ((ty0 * TH) >> 1) + wm, ox = ((tx0 * TW) >> 1) + rl;
+      res_pool = *reinterpret_cast<const uint4*>(
+          a.residual + ((int64_t)(n0 * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Co + co);
+    }
     if (t + (int)gridDim.x < ntiles) stage(buf ^ 1, t + gridDim.x);
     const unsigned char* Hb = smem + buf * RW_HB + hb0;
 
@@ -684,6 +709,45 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
     const int tx = t - q * a.tiles_x;
     const int n = (int)fdiv((uint32_t)q, a.dTy);
     const int ty = q - n * a.tiles_y;
+    if constexpr (POOL) {
+      // vertical pairs in registers, horizontal pairs from staging rows 2 x2 / 2 x2 + 1; lane ->
+      // (pooled column x2 = lane / 4, channel group g8): bias before the pooling average is the same
+      // as after it, the residual lives at the pooled resolution
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+        *reinterpret_cast<float4*>(Sw + frow * SP + (qq * 8 + 4 * half) * 4) =
+            make_float4(acc[0][qq * 4 + 0] + acc[1][qq * 4 + 0], acc[0][qq * 4 + 1] + acc[1][qq * 4 + 1],
+                        acc[0][qq * 4 + 2] + acc[1][qq * 4 + 2], acc[0][qq * 4 + 3] + acc[1][qq * 4 + 3]);
+      __builtin_amdgcn_wave_barrier();
+      const int x2 = rl;   // 0..15
+      const unsigned char* r0 = Sw + (2 * x2) * SP + g8 * 32;
+      const float4 a0 = *reinterpret_cast<const float4*>(r0);
+      const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16);
+      const float4 b0 = *reinterpret_cast<const float4*>(r0 + SP);
+      const float4 b1 = *reinterpret_cast<const float4*>(r0 + SP + 16);
+      float v[8] = {0.25f * (a0.x + b0.x) + bv[0], 0.25f * (a0.y + b0.y) + bv[1],
+                    0.25f * (a0.z + b0.z) + bv[2], 0.25f * (a0.w + b0.w) + bv[3],
+                    0.25f * (a1.x + b1.x) + bv[4], 0.25f * (a1.y + b1.y) + bv[5],
+                    0.25f * (a1.z + b1.z) + bv[6], 0.25f * (a1.w + b1.w) + bv[7]};
+      const int oy = ((ty * TH) >> 1) + wm, ox = ((tx * TW) >> 1) + x2;
+      const int64_t o = ((int64_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Co + co;
+      if (a.residual) {
+        float rv[8];
+        unpack8_bf16(res_pool, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (a.out_f32) {
+        float* op = reinterpret_cast<float*>(a.out) + o;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    const float osc = a.out_scale;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -699,8 +763,8 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
         const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
         const int oy = ty * TH + wm * 2 + i, ox = tx * TW + row;
         const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
-        float v[8] = {lo.x + bv[0], lo.y + bv[1], lo.z + bv[2], lo.w + bv[3],
-                      hi.x + bv[4], hi.y + bv[5], hi.z + bv[6], hi.w + bv[7]};
+        float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
+                      hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
         if (a.self_gate) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -1390,6 +1454,12 @@ static int hc_pick_bn(const cgConvGeom* g) {
   return wgs128 <= bn64_max ? 64 : 128;
 }
 
+static bool hconv_rw_geom_ok(const cgConvGeom* g);
+static void hconv_rw_launch_ex(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                               int out_is_f32, const float* bias, const void* gate_in,
+                               const void* gate_out, float slope_out, const void* residual,
+                               int pool, int in_up, float out_scale, hipStream_t st);
+
 bool cg_hconv_geom_ok(const cgConvGeom* g) {
   if (g->S != 1 || (g->U != 1 && g->U != 2)) return false;
   if (g->kh > 3 || g->kw > 3) return false;
@@ -1430,6 +1500,19 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
                            int out_is_f32, const float* bias, const void* gate_in,
                            const void* gate_out, float slope_out, const void* residual,
                            const cgConvFusion* fu, hipStream_t st) {
+  // 64 -> 64 channels with a pooled epilogue / a pooled-resolution input and no batch-norm fusion:
+  // the register-resident-weight kernel (B0 conv2 of the ResNet5 discriminator and its data gradient)
+  static const int rw_fused = hc_env("CGAMD_HCONV_RW_FUSED", 1);
+  static const int rw_min_tiles = hc_env("CGAMD_HCONV_RW_MIN", 512);
+  if (rw_fused && fu && (fu->pool_out || fu->in_up) && !(fu->pool_out && fu->in_up) &&
+      !fu->bn_mean && !fu->stats_out && hconv_rw_geom_ok(g) &&
+      (int64_t)g->N * (g->Ho / 4) * (g->Wo / 32) >= rw_min_tiles &&
+      !(fu->pool_out && gate_out)) {
+    hconv_rw_launch_ex(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
+                       fu->pool_out ? 1 : 0, fu->in_up ? 1 : 0,
+                       fu->out_scale != 0.f ? fu->out_scale : 1.f, st);
+    return;
+  }
   HConvArgs a;
   a.bn_mean = fu ? fu->bn_mean : nullptr;
   a.bn_var = fu ? fu->bn_var : nullptr;
@@ -1725,12 +1808,31 @@ bool cg_hconv_rw_supported(const cgConvGeom* g, const void* in, const void* gate
   return (int64_t)g->N * (g->Ho / 4) * (g->Wo / 32) >= min_tiles;
 }
 
+static bool hconv_rw_geom_ok(const cgConvGeom* g) {
+  if (g->S != 1 || g->U != 1 || g->kh != 3 || g->kw != 3 || g->Ci != 64 || g->Co != 64) return false;
+  if (g->Ho != g->Hin || g->Wo != g->Win || g->pt != 1 || g->pl != 1) return false;
+  if ((g->Wo % 32) != 0 || (g->Ho % 4) != 0) return false;
+  if ((int64_t)6 * g->Win * 64 * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
 void cg_hconv_rw_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
                         int out_is_f32, const float* bias, const void* gate_in,
                         const void* gate_out, float slope_out, const void* residual,
                         hipStream_t st) {
+  hconv_rw_launch_ex(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, 0, 0,
+                     1.f, st);
+}
+
+static void hconv_rw_launch_ex(const cgConvGeom* g, const void* in, const void* bt, void* out,
+                               int out_is_f32, const float* bias, const void* gate_in,
+                               const void* gate_out, float slope_out, const void* residual,
+                               int pool, int in_up, float out_scale, hipStream_t st) {
   HConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.pool = pool;
+  a.in_up = in_up;
+  a.out_scale = out_scale;
   a.in = (const bf16_t*)in;
   a.bt = (const bf16_t*)bt;
   a.out = out;
@@ -1754,6 +1856,11 @@ void cg_hconv_rw_launch(const cgConvGeom* g, const void* in, const void* bt, voi
   const int ntiles = g->N * a.tiles_y * a.tiles_x;
   const int grid = ntiles < 512 ? ntiles : 512;
   CgProfScope prof(CG_PROF_HCONV_64, g, st);
-  if (gate_in) hconv_rw_kernel<true><<<grid, 256, 0, st>>>(a);
-  else hconv_rw_kernel<false><<<grid, 256, 0, st>>>(a);
+  if (pool) {
+    if (gate_in) hconv_rw_kernel<true, true><<<grid, 256, 0, st>>>(a);
+    else hconv_rw_kernel<false, true><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (gate_in) hconv_rw_kernel<true, false><<<grid, 256, 0, st>>>(a);
+    else hconv_rw_kernel<false, false><<<grid, 256, 0, st>>>(a);
+  }
 }

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const void* __restrict__ 
                                                        const void* __restrict__ bp,
                                                        const double* __restrict__ mean,
                                                        double* __restrict__ c, int M, int N,
-                                                       int64_t K, int ta, int tb, double scale) {
+                                                       int64_t K, int ta, int tb, double scale,
+                                                       double eye) {
   __shared__ double As[GK][GT + 1];
   __shared__ double Bs[GK][GT + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const void* __restrict__ 
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
-      if (i < M && j < N) c[(int64_t)i * N + j] = acc[u][v] * scale;
+      if (i < M && j < N) c[(int64_t)i * N + j] = acc[u][v] * scale + (i == j ? eye : 0.0);
     }
 }
 
@@ -521,7 +522,7 @@ extern "C" int cg_mean_cov_f64(const float* x, int64_t n, int d, double* mean, d
                                                      mean);
   CG_CHECK_LAUNCH("cg_mean_cov_f64(mean)");
   dim3 g2(cdiv(d, GT), cdiv(d, GT));
-  gemm_f64_kernel<1><<<g2, 256, 0, st>>>(x, x, mean, cov, d, d, n, 1, 0, 1.0 / (double)(n - 1));
+  gemm_f64_kernel<1><<<g2, 256, 0, st>>>(x, x, mean, cov, d, d, n, 1, 0, 1.0 / (double)(n - 1), 0.0);
   CG_CHECK_LAUNCH("cg_mean_cov_f64(cov)");
   return CG_OK;
 }
@@ -531,8 +532,97 @@ extern "C" int cg_gemm_f64(const double* a, const double* b, double* c, int m, i
   if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0)
     CG_FAIL(CG_ERR_BAD_ARG, "cg_gemm_f64: bad argument");
   dim3 grid(cdiv(n, GT), cdiv(m, GT));
-  gemm_f64_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, nullptr, c, m, n, k, ta, tb, 1.0);
+  gemm_f64_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, nullptr, c, m, n, k, ta, tb, 1.0,
+                                                            0.0);
   CG_CHECK_LAUNCH("cg_gemm_f64");
+  return CG_OK;
+}
+
+extern "C" int cg_gemm_f64_ex(const double* a, const double* b, double* c, int m, int n, int k,
+                              int ta, int tb, double alpha, double beta_eye, cgStream stream) {
+  if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0)
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gemm_f64_ex: bad argument");
+  dim3 grid(cdiv(n, GT), cdiv(m, GT));
+  gemm_f64_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, nullptr, c, m, n, k, ta, tb, alpha,
+                                                            beta_eye);
+  CG_CHECK_LAUNCH("cg_gemm_f64_ex");
+  return CG_OK;
+}
+
+// out = alpha * a + beta_eye * I  (n x n, fp64)
+__global__ void axpby_eye_f64_kernel(const double* __restrict__ a, double alpha, double eye,
+                                     double* __restrict__ out, int n) {
+  const int64_t total = (int64_t)n * n, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    out[i] = alpha * a[i] + (r == c ? eye : 0.0);
+  }
+}
+
+extern "C" int cg_axpby_eye_f64(const double* a, double alpha, double beta_eye, double* out, int n,
+                                cgStream stream) {
+  if (!a || !out || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_axpby_eye_f64: bad argument");
+  int64_t b = ((int64_t)n * n + 255) / 256;
+  if (b > 4096) b = 4096;
+  axpby_eye_f64_kernel<<<(int)b, 256, 0, (hipStream_t)stream>>>(a, alpha, beta_eye, out, n);
+  CG_CHECK_LAUNCH("cg_axpby_eye_f64");
+  return CG_OK;
+}
+
+// out[0] = trace(a), out[1] = sum of squares of a, out[2] = smallest diagonal entry (n x n, fp64);
+// deterministic two-stage sums
+constexpr int MS_BLOCKS = 256;
+__global__ __launch_bounds__(256) void mat_stats_part_kernel(const double* __restrict__ a, int n,
+                                                             double* __restrict__ part) {
+  __shared__ double sm[3][4];
+  const int64_t total = (int64_t)n * n, stride = (int64_t)gridDim.x * blockDim.x;
+  double tr = 0.0, sq = 0.0, dmin = 1e300;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const double v = a[i];
+    sq += v * v;
+    if (i % (n + 1) == 0) {
+      tr += v;
+      dmin = fmin(dmin, v);
+    }
+  }
+  tr = wave_sum_d(tr);
+  sq = wave_sum_d(sq);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmin = fmin(dmin, __shfl_xor(dmin, o, 64));
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][w] = tr;
+    sm[1][w] = sq;
+    sm[2][w] = dmin;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 3 + 0] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    part[blockIdx.x * 3 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    part[blockIdx.x * 3 + 2] = fmin(fmin(sm[2][0], sm[2][1]), fmin(sm[2][2], sm[2][3]));
+  }
+}
+__global__ void mat_stats_final_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  double tr = 0.0, sq = 0.0, dmin = 1e300;
+  for (int b = 0; b < MS_BLOCKS; ++b) {
+    tr += part[b * 3 + 0];
+    sq += part[b * 3 + 1];
+    dmin = fmin(dmin, part[b * 3 + 2]);
+  }
+  out[0] = tr;
+  out[1] = sq;
+  out[2] = dmin;
+}
+
+extern "C" size_t cg_mat_stats_workspace_bytes(void) { return MS_BLOCKS * 3 * sizeof(double); }
+extern "C" int cg_mat_stats_f64(const double* a, int n, double* out2, void* ws, size_t ws_bytes,
+                                cgStream stream) {   // out2: three doubles
+  if (!a || !out2 || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_mat_stats_f64: bad argument");
+  if (!ws || ws_bytes < cg_mat_stats_workspace_bytes())
+    CG_FAIL(CG_ERR_WORKSPACE, "cg_mat_stats_f64: workspace too small");
+  mat_stats_part_kernel<<<MS_BLOCKS, 256, 0, (hipStream_t)stream>>>(a, n, (double*)ws);
+  mat_stats_final_kernel<<<1, 1, 0, (hipStream_t)stream>>>((const double*)ws, out2);
+  CG_CHECK_LAUNCH("cg_mat_stats_f64");
   return CG_OK;
 }
 

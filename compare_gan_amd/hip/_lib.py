@@ -163,6 +163,10 @@ SIGNATURES = {
     "cg_mean_cov_workspace_bytes": (c_sz, [c_i64, c_int]),
     "cg_mean_cov_f64": (c_int, [vp, c_i64, c_int, vp, vp, vp, c_sz, vp]),
     "cg_gemm_f64": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    "cg_gemm_f64_ex": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_f64, c_f64, vp]),
+    "cg_axpby_eye_f64": (c_int, [vp, c_f64, c_f64, vp, c_int, vp]),
+    "cg_mat_stats_workspace_bytes": (c_sz, []),
+    "cg_mat_stats_f64": (c_int, [vp, c_int, vp, vp, c_sz, vp]),
     "cg_poly3_kernel_workspace_bytes": (c_sz, []),
     "cg_poly3_kernel_sums_f64": (c_int, [vp, c_int, c_int, c_f64, vp, vp, c_sz, vp]),
     "cg_rowscale_f64": (c_int, [vp, vp, vp, c_int, c_int, vp]),

@@ -1064,15 +1064,39 @@ def mean_cov_f64(x):
     return mean, cov
 
 
-def gemm_f64(a, b, ta=False, tb=False):
+def gemm_f64(a, b, ta=False, tb=False, alpha=1.0, eye=0.0):
+    """alpha * op(a) @ op(b) + eye * I (fp64)."""
     _req(a, F64, "a")
     _req(b, F64, "b")
     m, k = (a.shape[1], a.shape[0]) if ta else a.shape
     n = b.shape[0] if tb else b.shape[1]
     c = torch.empty((m, n), dtype=F64, device=a.device)
-    check(lib().cg_gemm_f64(_p(a), _p(b), _p(c), m, n, k, int(ta), int(tb), _stream()),
-          "cg_gemm_f64")
+    if alpha == 1.0 and eye == 0.0:
+        check(lib().cg_gemm_f64(_p(a), _p(b), _p(c), m, n, k, int(ta), int(tb), _stream()),
+              "cg_gemm_f64")
+    else:
+        check(lib().cg_gemm_f64_ex(_p(a), _p(b), _p(c), m, n, k, int(ta), int(tb), float(alpha),
+                                   float(eye), _stream()), "cg_gemm_f64_ex")
     return c
+
+
+def axpby_eye_f64(a, alpha, eye):
+    """alpha * a + eye * I for a square fp64 matrix."""
+    _req(a, F64, "a")
+    out = torch.empty_like(a)
+    check(lib().cg_axpby_eye_f64(_p(a), float(alpha), float(eye), _p(out), a.shape[0], _stream()),
+          "cg_axpby_eye_f64")
+    return out
+
+
+def mat_stats_f64(a):
+    """Device tensor [trace(a), sum(a * a), min diagonal entry] of a square fp64 matrix."""
+    _req(a, F64, "a")
+    out = torch.empty((3,), dtype=F64, device=a.device)
+    ws = _ws(lib().cg_mat_stats_workspace_bytes(), a)
+    check(lib().cg_mat_stats_f64(_p(a), a.shape[0], _p(out), _p(ws), ws.numel(), _stream()),
+          "cg_mat_stats_f64")
+    return out
 
 
 def poly3_kernel_sums_f64(gram, dim):

@@ -526,6 +526,21 @@ int cg_mean_cov_f64(const float* x, int64_t n, int d, double* mean, double* cov,
 /* C = op(A) * op(B), fp64 row-major, A [m,k] (or [k,m] if ta), B [k,n] (or [n,k] if tb). */
 int cg_gemm_f64(const double* a, const double* b, double* c, int m, int n, int k, int ta, int tb,
                 cgStream stream);
+/* C = alpha * op(A) * op(B) + beta_eye * I, and the pieces of the inverse-free Newton-Schulz
+ * iteration for the symmetric square root of a well-conditioned covariance (metrics/fid_score.py
+ * replaces tfgan's SVD-based _symmetric_matrix_square_root, fid_score.py:49-51 of the reference, by
+ * GEMMs where every eigenvalue is provably above tfgan's 1e-10 threshold):
+ *   cg_axpby_eye_f64: out = alpha * a + beta_eye * I (n x n);
+ *   cg_mat_stats_f64: out3[0] = trace(a), out3[1] = sum of squares of a (Frobenius norm squared),
+ *                     out3[2] = smallest diagonal entry (an upper bound of the smallest eigenvalue
+ *                     of a symmetric matrix); ws >= cg_mat_stats_workspace_bytes(). */
+int cg_gemm_f64_ex(const double* a, const double* b, double* c, int m, int n, int k, int ta, int tb,
+                   double alpha, double beta_eye, cgStream stream);
+int cg_axpby_eye_f64(const double* a, double alpha, double beta_eye, double* out, int n,
+                     cgStream stream);
+size_t cg_mat_stats_workspace_bytes(void);
+int cg_mat_stats_f64(const double* a, int n, double* out3, void* ws, size_t ws_bytes,
+                     cgStream stream);
 /* out[r, :] = a[r, :] * scale[r] (fp64): diag(f(w)) V when rebuilding a matrix function from its
  * eigen-decomposition (the symmetric square roots of the FID, metrics/fid_score.py:49-51). */
 int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows, int cols,

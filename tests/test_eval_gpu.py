@@ -56,6 +56,50 @@ def test_kid_matches_oracle(dev, n_real, n_gen, d, mbs):
     assert got2 == got and (np.isnan(err) if n_real // mbs < 5 else err >= 0)
 
 
+@pytest.mark.parametrize("n,d,cond", [(1500, 256, 1e3), (4000, 512, 1e6), (3000, 2048, 1e4)])
+def test_fid_newton_schulz_path(dev, n, d, cond):
+    """The GEMM-only square-root path (metrics/fid_score.py: _sqrt_newton_schulz) on full-rank
+    covariances with a prescribed condition number: it must certify itself, agree with the Jacobi
+    path to 1e-9 and with the oracle (tfgan's SVD rule) to 1e-6 relative; a covariance with
+    eigenvalues under tfgan's 1e-10 threshold must be REFUSED (the rule is active there) and still
+    come out right through the Jacobi fallback."""
+    from compare_gan_amd.metrics import fid_score
+    rng = np.random.RandomState(n + d)
+    # features with singular values spread geometrically over `cond`^(1/2)
+    basis = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    scales = np.geomspace(1.0, cond ** -0.5, d)
+    a = (rng.standard_normal((n, d)) * scales) @ basis.T + rng.standard_normal((1, d))
+    b = (rng.standard_normal((n, d)) * scales[::-1]) @ basis.T * 0.9
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    old = fid_score._SOLVER
+    try:
+        fid_score._SOLVER = "auto"
+        got = fid_score.frechet_distance(a, b, device=dev)
+        assert fid_score.LAST_SOLVER == {"sqrt_sigma": "newton-schulz", "trace_sqrt": "newton-schulz"}
+        fid_score._SOLVER = "jacobi"
+        jac = fid_score.frechet_distance(a, b, device=dev)
+        assert fid_score.LAST_SOLVER["sqrt_sigma"] == "jacobi"
+    finally:
+        fid_score._SOLVER = old
+    assert abs(got - jac) <= 1e-9 * abs(jac), (got, jac)
+    if d <= 512:
+        ref = ofid.frechet_distance(a, b)
+        assert abs(got - ref) <= 1e-6 * abs(ref), (got, ref)
+    # eigenvalues of 1e-12 (below the 1e-10 rule): not certifiable -> Jacobi, same answer as forced
+    tiny = a.copy()
+    tiny[:, : d // 4] *= 1e-6
+    try:
+        fid_score._SOLVER = "auto"
+        g2 = fid_score.frechet_distance(tiny, b, device=dev)
+        used = dict(fid_score.LAST_SOLVER)
+        fid_score._SOLVER = "jacobi"
+        j2 = fid_score.frechet_distance(tiny, b, device=dev)
+    finally:
+        fid_score._SOLVER = old
+    assert used["sqrt_sigma"] == "jacobi", used
+    assert abs(g2 - j2) <= 1e-9 * abs(j2)
+
+
 def test_inception_score_matches_oracle(dev):
     from compare_gan_amd.metrics import inception_score
     rng = np.random.RandomState(3)

@@ -538,6 +538,10 @@ def test_gconv_fused_statistics_groups(K, dev, case):
     ("pool_c64_128", 2, 32, 32, 64, 128, True, True),
     ("pool_c128_64_16", 3, 16, 16, 128, 64, True, False),
     ("pool_c64_64_16", 2, 16, 16, 64, 64, False, True),
+    # 64 -> 64 on 32-wide maps: the register-resident-weight kernel's pooled / up-sampled-input forms
+    # when CGAMD_HCONV_RW_MIN lets these small grids take it (variant "hconv_all" below)
+    ("pool_c64_64_32x64", 2, 32, 64, 64, 64, True, True),
+    ("pool_c64_64_64x32_plain", 1, 64, 32, 64, 64, False, False),
     ("pool_c96", 2, 32, 32, 96, 192, True, True),
     ("pool_rgb_64", 2, 32, 32, 3, 64, True, False),
     ("pool_rgb_128_16", 3, 16, 16, 3, 128, False, False),
@@ -1025,7 +1029,8 @@ def test_conv_kernel_variants(dev, variant):
     env.update(variant[1])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
-                        "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual or test_stem_relu_gate"],
+                        "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual or "
+                        "test_stem_relu_gate or (test_conv_pool_fused and not full_size)"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
 
