@@ -90,8 +90,6 @@ class AbstractDiscriminator(_Module):
     self._batch_norm_fn = batch_norm_fn
     self._layer_norm = layer_norm
     self._spectral_norm = spectral_norm
-    if layer_norm:
-      raise NotImplementedError("D.layer_norm=True has no HIP kernel (unused by example configs).")
 
   def __call__(self, x, y, is_training, reuse=None):
     del reuse

@@ -715,8 +715,18 @@ def conditional_batch_norm(inputs, y, is_training, use_sn, center=True, scale=Tr
 
 
 def layer_norm(input_, is_training, scope):
-  raise NotImplementedError(
-      "layer_norm (arch_ops.py:448-450) is not used by any example config and has no HIP kernel.")
+  """tf.contrib.layers.layer_norm(input_, trainable=is_training, scope=scope) (arch_ops.py:448-450)
+  with the library's defaults: statistics per sample over (H, W, C) (begin_norm_axis = 1),
+  `beta` (zeros) and `gamma` (ones) per channel (begin_params_axis = -1), variance_epsilon 1e-12;
+  the variables are <scope>/beta and <scope>/gamma, trainable iff is_training."""
+  input_ = as_tensor(input_)
+  with variable_scope(scope):
+    c = input_.shape[-1]
+    beta = get_variable("beta", [c], constant(0.0), trainable=bool(is_training))
+    gamma = get_variable("gamma", [c], constant(1.0), trainable=bool(is_training))
+  if input_.is_meta:
+    return input_
+  return Fn.layer_norm(input_, gamma, beta, 1e-12)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -29,10 +29,10 @@ class BigGanResNetBlock(resnet_ops.ResNetBlock):
       inputs_main = inputs
       if self._add_shortcut and resnet_ops._FORK:   # pylint: disable=protected-access
         inputs, inputs_main = ops.fork(inputs)
-      outputs = self.batch_norm_relu(inputs_main, z=z, y=y, is_training=is_training, name="bn1")
+      outputs = self._norm_relu(inputs_main, z, y, is_training, "bn1", "ln1")
       outputs = self._get_conv(outputs, self._in_channels, self._out_channels, self._scale1,
                                suffix="conv1")
-      outputs = self.batch_norm_relu(outputs, z=z, y=y, is_training=is_training, name="bn2")
+      outputs = self._norm_relu(outputs, z, y, is_training, "bn2", "ln2")
       outputs = self._get_conv(outputs, self._out_channels, self._out_channels, self._scale2,
                                suffix="conv2")   # pooled when scale2 == "down"
       if self._add_shortcut:

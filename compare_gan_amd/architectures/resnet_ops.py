@@ -63,11 +63,19 @@ class ResNetBlock(object):
     self._spectral_norm = spectral_norm
     self.batch_norm = batch_norm
     self.batch_norm_relu = batch_norm_relu
-    if layer_norm:
-      raise NotImplementedError("layer_norm has no HIP kernel (unused by example configs).")
 
   def __call__(self, inputs, z, y, is_training):
     return self.apply(inputs=inputs, z=z, y=y, is_training=is_training)
+
+  def _norm_relu(self, inputs, z, y, is_training, bn_name, ln_name):
+    """batch_norm -> [layer_norm] -> ReLU (resnet_ops.py:159-165,169-175).  Without layer norm the
+    ReLU stays fused (batch-norm kernel or the consumer convolution's input gate); with it the
+    batch norm runs bare, the layer norm follows and the ReLU is left pending for the convolution."""
+    if not self._layer_norm:
+      return self.batch_norm_relu(inputs, z=z, y=y, is_training=is_training, name=bn_name)
+    output = self.batch_norm(inputs, z=z, y=y, is_training=is_training, name=bn_name)
+    output = ops.layer_norm(output, is_training=is_training, scope=ln_name)
+    return ops.Act(output, 0.0)
 
   def _get_conv(self, inputs, in_channels, out_channels, scale, suffix, kernel_size=(3, 3),
                 strides=(1, 1), residual=None, pool=True):
@@ -112,10 +120,10 @@ class ResNetBlock(object):
         inputs_main = inputs
       shortcut = self._get_conv(inputs, self._in_channels, self._out_channels, self._scale,
                                 suffix="conv_shortcut", pool=fuse)
-      output = self.batch_norm_relu(inputs_main, z=z, y=y, is_training=is_training, name="bn1")
+      output = self._norm_relu(inputs_main, z, y, is_training, "bn1", "ln1")
       output = self._get_conv(output, self._in_channels, self._out_channels, self._scale1,
                               suffix="conv1")
-      output = self.batch_norm_relu(output, z=z, y=y, is_training=is_training, name="bn2")
+      output = self._norm_relu(output, z, y, is_training, "bn2", "ln2")
       # conv2 + shortcut in one epilogue; pool(conv2) + pool(shortcut) == pool(conv2 + shortcut)
       output = self._get_conv(output, self._out_channels, self._out_channels, self._scale2,
                               suffix="conv2", residual=shortcut, pool=fuse)

@@ -470,6 +470,35 @@ def batch_norm_act(x, gamma, beta, mean=None, var=None, eps=1e-5, per_sample=Fal
   return BatchNormActFn.apply(x, gamma, beta, mean, var, eps, per_sample, relu, sync_fn, moving)
 
 
+class LayerNormFn(torch.autograd.Function):
+  """tf.contrib.layers.layer_norm (arch_ops.py:448-450): statistics per sample over (H, W, C),
+  gamma / beta per channel.  First-order (no example config combines it with a gradient penalty
+  whose second-order terms would cross it)."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, eps):
+    shape = x.shape
+    x3 = x.contiguous().reshape(shape[0], -1, shape[-1])
+    y3, mean, rstd = K.layer_norm_fwd(x3, gamma.contiguous(), beta.contiguous(), eps)
+    ctx.shape = shape
+    ctx.save_for_backward(x3, mean, rstd, gamma)
+    return y3.reshape(shape)
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dy):
+    x3, mean, rstd, gamma = ctx.saved_tensors
+    want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+    dx, dg, db = K.layer_norm_bwd(x3, _bf16(dy).reshape(x3.shape), mean, rstd, gamma.contiguous(),
+                                  want_params=want)
+    return (dx.reshape(ctx.shape), dg if ctx.needs_input_grad[1] else None,
+            db if ctx.needs_input_grad[2] else None, None)
+
+
+def layer_norm(x, gamma, beta, eps=1e-12):
+  return LayerNormFn.apply(x, gamma, beta, eps)
+
+
 # ------------------------------------------------------------------------------------------------
 # stand-alone leaky ReLU (only where the consumer cannot take an input gate)
 # ------------------------------------------------------------------------------------------------

@@ -754,6 +754,35 @@ def cast_bf16_to_f32(x):
     return y
 
 
+def layer_norm_fwd(x3, gamma, beta, eps=1e-12):
+    """x3 bf16 [N, M, C] -> (y, mean [N], rstd [N])."""
+    _req(x3, BF16, "x")
+    _req(gamma, F32, "gamma")
+    _req(beta, F32, "beta")
+    N, M, C = x3.shape
+    y = torch.empty_like(x3)
+    mean = torch.empty((N,), dtype=F32, device=x3.device)
+    rstd = torch.empty((N,), dtype=F32, device=x3.device)
+    check(lib().cg_layer_norm_fwd(_p(x3), N, M, C, _p(gamma), _p(beta), float(eps), _p(y), _p(mean),
+                                  _p(rstd), _stream()), "cg_layer_norm_fwd")
+    return y, mean, rstd
+
+
+def layer_norm_bwd(x3, dy3, mean, rstd, gamma, want_params=True):
+    """-> (dx, dgamma, dbeta); the parameter gradients are None unless want_params."""
+    _req(x3, BF16, "x")
+    _req(dy3, BF16, "dy")
+    N, M, C = x3.shape
+    dx = torch.empty_like(x3)
+    dg = torch.empty((C,), dtype=F32, device=x3.device) if want_params else None
+    db = torch.empty((C,), dtype=F32, device=x3.device) if want_params else None
+    ws = _ws(lib().cg_layer_norm_bwd_workspace_bytes(N, C), x3)
+    check(lib().cg_layer_norm_bwd(_p(x3), _p(dy3), _p(mean), _p(rstd), _p(gamma), N, M, C, _p(dx),
+                                  _p(dg), _p(db), _p(ws), ws.numel(), _stream()),
+          "cg_layer_norm_bwd")
+    return dx, dg, db
+
+
 def colsum(x2):
     _req(x2, BF16, "x")
     rows, C = x2.shape

@@ -396,6 +396,19 @@ int cg_cast_f32_to_bf16(const float* x, void* y, int64_t n, cgStream stream);
 int cg_cast_bf16_to_f32(const void* x, float* y, int64_t n, cgStream stream);
 /* y = x * a + b elementwise on fp32 -> bf16 (sndcgan.py:108 `x * 2.0 - 1.0`, plus cast). */
 int cg_affine_f32_to_bf16(const float* x, float a, float b, void* y, int64_t n, cgStream stream);
+/* Layer normalisation (arch_ops.py:448-450: tf.contrib.layers.layer_norm defaults -- statistics per
+ * sample over (H, W, C), gamma / beta per channel, variance_epsilon 1e-12; used when D.layer_norm =
+ * True, resnet_ops.py:162-173):
+ *   y[n,p,c] = ((x[n,p,c] - mean_n) * rstd_n) * gamma[c] + beta[c],  rstd_n = rsqrt(var_n + eps)
+ * x, y, dy, dx bf16 [N, M, C] (C % 8 == 0); gamma, beta, dgamma, dbeta fp32 [C]; mean, rstd fp32 [N]
+ * (written by the forward, read by the backward).  dgamma / dbeta may be NULL.
+ * ws >= cg_layer_norm_bwd_workspace_bytes(N, C). */
+int cg_layer_norm_fwd(const void* x, int N, int64_t M, int C, const float* gamma, const float* beta,
+                      float eps, void* y, float* mean, float* rstd, cgStream stream);
+size_t cg_layer_norm_bwd_workspace_bytes(int N, int C);
+int cg_layer_norm_bwd(const void* x, const void* dy, const float* mean, const float* rstd,
+                      const float* gamma, int N, int64_t M, int C, void* dx, float* dgamma,
+                      float* dbeta, void* ws, size_t ws_bytes, cgStream stream);
 /* Column sums of a [rows, C] bf16 matrix into fp32 [C] (bias gradients).
  * ws >= cg_colsum_workspace_bytes(rows, C). */
 size_t cg_colsum_workspace_bytes(int64_t rows, int C);

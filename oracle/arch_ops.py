@@ -435,6 +435,20 @@ def self_modulated_batch_norm(vs, x, z, is_training, use_sn, name, bn_cfg, sn_cf
 # ------------------------------------------------------------------------------------------------
 # Self-attention (arch_ops.py:709-758)
 # ------------------------------------------------------------------------------------------------
+def layer_norm(vs, x, is_training, scope):
+  """tf.contrib.layers.layer_norm(x, trainable=is_training, scope=scope) (arch_ops.py:448-450) with
+  the library defaults: moments over axes [1, rank) per sample, beta (zeros) / gamma (ones) over
+  the last axis, tf.nn.batch_normalization with variance_epsilon = 1e-12."""
+  c = x.shape[-1]
+  beta = vs.get(scope + "/beta", (c,), vs.const_init(0.0), trainable=bool(is_training))
+  gamma = vs.get(scope + "/gamma", (c,), vs.const_init(1.0), trainable=bool(is_training))
+  xin = vs.q_in(x)
+  axes = tuple(range(1, x.dim()))
+  mean = xin.mean(dim=axes, keepdim=True)
+  var = ((xin - mean) ** 2).mean(dim=axes, keepdim=True)
+  return vs.q((xin - mean) * torch.rsqrt(var + 1e-12) * gamma + beta)
+
+
 def non_local_block(vs, x, name, use_sn, sn_cfg):
   n, h, w, c = x.shape
   ca, cg = c // 8, c // 2

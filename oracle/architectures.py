@@ -49,6 +49,16 @@ def _batch_norm(vs, cfg, x, name, z=None, y=None, is_training=True, use_sn=None,
   raise ValueError("unknown batch_norm_fn %r" % fn)
 
 
+def _norm_relu(vs, cfg, x, scope, bn_name, ln_name, z, y, is_training):
+  """batch_norm -> [layer_norm] -> relu (resnet_ops.py:159-165,169-175; resnet_biggan.py:120-136)."""
+  if not cfg.layer_norm:
+    return _batch_norm(vs, cfg, x, scope + "/" + bn_name, z=z, y=y, is_training=is_training,
+                       relu=True)
+  out = _batch_norm(vs, cfg, x, scope + "/" + bn_name, z=z, y=y, is_training=is_training)
+  out = ops.layer_norm(vs, out, is_training, scope + "/" + ln_name)
+  return torch.relu(out)
+
+
 def _get_conv(vs, cfg, x, in_ch, out_ch, scale, suffix, scope, kernel=(3, 3), residual=None,
               pool=True):
   """resnet_ops.py:112-134.  residual / pool=False let the caller form pool(conv2 + shortcut),
@@ -75,9 +85,9 @@ def resnet_block(vs, cfg, x, scope, in_ch, out_ch, scale, is_gen_block, z, y, is
   scale1 = scale if is_gen_block else "none"
   scale2 = "none" if is_gen_block else scale
   shortcut = _get_conv(vs, cfg, x, in_ch, out_ch, scale, "conv_shortcut", scope, pool=False)
-  out = _batch_norm(vs, cfg, x, scope + "/bn1", z=z, y=y, is_training=is_training, relu=True)
+  out = _norm_relu(vs, cfg, x, scope, "bn1", "ln1", z, y, is_training)
   out = _get_conv(vs, cfg, out, in_ch, out_ch, scale1, "conv1", scope)
-  out = _batch_norm(vs, cfg, out, scope + "/bn2", z=z, y=y, is_training=is_training, relu=True)
+  out = _norm_relu(vs, cfg, out, scope, "bn2", "ln2", z, y, is_training)
   # output += shortcut (resnet_ops.py:181), pooled once when the block downsamples
   out = _get_conv(vs, cfg, out, out_ch, out_ch, scale2, "conv2", scope, residual=shortcut,
                   pool=False)
@@ -94,9 +104,9 @@ def biggan_block(vs, cfg, x, scope, in_ch, out_ch, scale, is_gen_block, z, y, is
         in_ch, x.shape[-1]))
   scale1 = scale if is_gen_block else "none"
   scale2 = "none" if is_gen_block else scale
-  out = _batch_norm(vs, cfg, x, scope + "/bn1", z=z, y=y, is_training=is_training, relu=True)
+  out = _norm_relu(vs, cfg, x, scope, "bn1", "ln1", z, y, is_training)
   out = _get_conv(vs, cfg, out, in_ch, out_ch, scale1, "conv1", scope)
-  out = _batch_norm(vs, cfg, out, scope + "/bn2", z=z, y=y, is_training=is_training, relu=True)
+  out = _norm_relu(vs, cfg, out, scope, "bn2", "ln2", z, y, is_training)
   out = _get_conv(vs, cfg, out, out_ch, out_ch, scale2, "conv2", scope)
   if add_shortcut:
     sc_in = x

@@ -1,7 +1,9 @@
 """HBM traffic per kernel launch from two rocprofv3 --pmc passes of bench.py (FETCH_SIZE and
 WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 
-usage: python scripts/pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json
+usage: python scripts/pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json [WORKLOAD]
+(WORKLOAD, e.g. cifar / resnet128_dstep: the table is merged into OUT.json["workloads"][WORKLOAD],
+which is what bench.py reads for `roofline.traffic` and the D-step leg's `traffic`)
 
 Correction (MI355X_MICROARCH.md "HBM"): on gfx950 FETCH_SIZE tallies the 128-B read requests of a
 wide coalesced stream at 64 B, i.e. reports half the bytes -> hbm_bytes = (2 * FETCH_SIZE +
@@ -14,6 +16,8 @@ FAMILIES = [
     (r"hconv_kernel<128", "hconv_kernel<128, *>"),
     (r"hconv(_rw)?_kernel", "hconv_kernel<64, *>"),
     (r"hwgrad_kernel", "hwgrad_kernel<*>"),
+    (r"sconv_kernel", "sconv_kernel<*>"),
+    (r"swgrad_kernel", "swgrad_kernel<*>"),
     (r"wstem_fwd_kernel", "stem_fwd_kernel<*>"),
     (r"wstem_wgrad_kernel", "stem_wgrad_kernel<*>"),
     (r"fast_conv(_sk)?_kernel<128, 128", "fast_conv_kernel<128, 128, *>"),
@@ -52,6 +56,7 @@ def collect(d, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else None
     fs, ws = collect(fetch, "FETCH_SIZE"), collect(write, "WRITE_SIZE")
     res = {}
     for fam in sorted(set(fs) | set(ws)):
@@ -62,10 +67,19 @@ def main():
         res[fam] = {"launches_fetch_pass": f_n, "launches_write_pass": w_n,
                     "FETCH_SIZE_KiB_raw": round(f_avg, 2), "WRITE_SIZE_KiB": round(w_avg, 2),
                     "hbm_bytes_per_launch": int((2.0 * f_avg + w_avg) * 1024)}
-    json.dump({"correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE "
-                             "counts 128-B requests at 64 B; MI355X_MICROARCH.md HBM section)",
-               "workload": "bench.py --no-graph (same kernels as the captured step, eager launches)",
-               "families": res}, open(out, "w"), indent=1, sort_keys=True)
+    table = {"correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE "
+                           "counts 128-B requests at 64 B; MI355X_MICROARCH.md HBM section)",
+             "workload": "eager launches of the same kernels as the captured step",
+             "families": res}
+    if workload:
+        doc = {"workloads": {}}
+        if os.path.exists(out):
+            doc = json.load(open(out))
+            doc.setdefault("workloads", {})
+        doc["workloads"][workload] = table
+        json.dump(doc, open(out, "w"), indent=1, sort_keys=True)
+    else:
+        json.dump(table, open(out, "w"), indent=1, sort_keys=True)
     for fam, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:14]:
         print("%-36s %8.2f MB/launch (%d launches)" % (fam, v["hbm_bytes_per_launch"] / 1e6,
                                                        v["launches_fetch_pass"]))

@@ -215,6 +215,39 @@ def test_gconv_full_size_shapes(K, dev, case):
     _close_on_device(db, dy2.sum(dim=0), name + " dbias", 2e-4, 2e-4)
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 8, 64), (2, 16, 16, 128), (4, 4, 4, 512), (2, 32, 32, 72)])
+def test_layer_norm(K, dev, shape):
+    """cg_layer_norm_fwd / _bwd (arch_ops.py:448-450: tf.contrib.layers.layer_norm defaults --
+    per-sample moments over (H, W, C), per-channel gamma / beta, variance_epsilon 1e-12) and the
+    autograd Function, against the oracle's restatement with fp64 autograd."""
+    from compare_gan_amd.hip import functional as Fn
+    from oracle import arch_ops as oops2
+    g = _gen(sum(shape))
+    x64, xb = rand_bf16(shape, g, 1.5)
+    x64 = x64 + 0.25
+    xb = x64.float().to(BF16)
+    x64 = xb.double()
+    c = shape[-1]
+    gamma = (1.0 + 0.3 * torch.randn(c, generator=g)).float()
+    beta = (0.3 * torch.randn(c, generator=g)).float()
+    dy64, dyb = rand_bf16(shape, g)
+    vs = oops2.VarStore()
+    vs.vars["ln/beta"] = beta.double().requires_grad_(True)
+    vs.vars["ln/gamma"] = gamma.double().requires_grad_(True)
+    xr = x64.clone().requires_grad_(True)
+    ref = oops2.layer_norm(vs, xr, True, "ln")
+    gx, gg, gb = torch.autograd.grad((ref * dy64).sum(), [xr, vs.vars["ln/gamma"], vs.vars["ln/beta"]])
+    xd = xb.to(dev).requires_grad_(True)
+    gd = gamma.to(dev).requires_grad_(True)
+    bd = beta.to(dev).requires_grad_(True)
+    y = Fn.layer_norm(xd, gd, bd)
+    assert_close_bf16(y, ref.detach(), "layer_norm fwd")
+    dx, dg, db = torch.autograd.grad(y, [xd, gd, bd], grad_outputs=dyb.to(dev))
+    assert_close_bf16(dx, gx, "layer_norm dx", ulps=3.0, abs_rms=2.0 ** -7)
+    assert_close_f32(dg, gg, "layer_norm dgamma", rtol=2e-3, abs_rms=2e-3)
+    assert_close_f32(db, gb, "layer_norm dbeta", rtol=2e-3, abs_rms=2e-3)
+
+
 def test_gwgrad_multi_grouped(K, dev):
     """cg_gwgrad_multi: the weight (+ bias) gradients of several layers in one call -- the small-map
     ones share a launch (swgrad_kernel), the others run through cg_gwgrad -- against the fp64 oracle

@@ -56,8 +56,11 @@ def test_pmc_traffic_summary(tmp_path):
 
 def test_bench_reads_the_committed_traffic_summary():
     bench = _load(os.path.join(ROOT, "bench.py"), "bench_module")
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-    for family in ("fast_conv_kernel<64, 128, *>", "hconv_kernel<128, *>", "hwgrad_kernel<*>",
-                   "halo_wgrad_kernel<*>"):
-        assert bench.pmc_traffic(family) == summary["families"][family]["hbm_bytes_per_launch"] > 0
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["workloads"]
+    for family in ("hconv_kernel<128, *>", "hwgrad_kernel<*>", "sconv_kernel<*>", "swgrad_kernel<*>"):
+        assert bench.pmc_traffic(family) == \
+            summary["cifar"]["families"][family]["hbm_bytes_per_launch"] > 0
+    for family in ("hconv_kernel<128, *>", "hwgrad_kernel<*>", "hconv_kernel<64, *>"):
+        assert bench.pmc_traffic(family, "resnet128_dstep") == \
+            summary["resnet128_dstep"]["families"][family]["hbm_bytes_per_launch"] > 0
     assert bench.pmc_traffic("no_such_kernel") is None
