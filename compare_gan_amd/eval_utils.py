@@ -87,7 +87,12 @@ def sample_fake_dataset(generate_fn, num_batches):
 
 def _load_inception_weight_file(path):
   """{name: tensor} from a .npz / .safetensors / torch file in inception.py's layouts
-  (HWIO conv kernels, biases, logits/kernel [2048, 1008])."""
+  (HWIO conv kernels, biases, logits/kernel [2048, 1008]), or from the frozen 2015 Inception
+  GraphDef itself (`.pb`: eval_utils.py:41-49 of the reference; compare_gan_amd/graphdef.py decodes
+  it and folds its batch norms into the kernels)."""
+  if path.endswith(".pb"):
+    from compare_gan_amd import graphdef
+    return {k: torch.from_numpy(v) for k, v in graphdef.inception_weights_from_graphdef(path).items()}
   if path.endswith(".npz"):
     with np.load(path) as z:
       return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
