@@ -9,6 +9,7 @@ test-set size, optional BN accumulator fill with 204,800 samples, per-task mean 
 import numpy as np
 import torch
 
+from compare_gan_amd import eval_shard
 from compare_gan_amd import eval_utils
 from compare_gan_amd import gin
 from compare_gan_amd import utils
@@ -27,26 +28,38 @@ def z_generator(shape, distribution_fn=random_uniform, minval=-1.0, maxval=1.0, 
                                        stddev=stddev, name=name, device=device)
 
 
-def _update_bn_accumulators(gan, generate_fn, batch_size, num_accu_examples):
+def _update_bn_accumulators(gan, generate_fn, batch_size, num_accu_examples, first_index=1,
+                            rank=0, world=1):
   """Fills the accumulator statistics of batch norms configured with use_moving_averages=False
-  (eval_gan_lib.py:65-92).  Returns True if there were accumulators."""
+  (eval_gan_lib.py:65-92) with batches first_index .. first_index + n - 1; with world > 1 the
+  batches are dealt round-robin and the per-rank sums all-reduced (eval_shard.allreduce_deltas).
+  Returns the number of batches consumed (0 if there are no accumulators)."""
   switches = [v for n, v in gan.store.vars.items() if "accu/update_accus" in n]
   if not switches:
-    return False
+    return 0
+  num = num_accu_examples // batch_size
+  accus = [v for n, v in sorted(gan.store.vars.items())
+           if "accu/accu_mean" in n or "accu/accu_variance" in n or "accu/accu_counter" in n]
+  before = [v.detach().clone() for v in accus] if world > 1 else None
   gan.store.set_accu_fill(True)    # the variables and their host mirror (arch_ops.standardize_batch)
   try:
-    for _ in range(num_accu_examples // batch_size):
-      generate_fn()
+    for i in eval_shard.shard_indices(num, rank, world):
+      generate_fn(first_index + i)
   finally:
     gan.store.set_accu_fill(False)
-  return True
+  eval_shard.allreduce_deltas(accus, before, world)
+  return num
 
 
 def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800,
-                 num_test_examples=None):
+                 num_test_examples=None, shard=None):
   """Evaluates `gan` (built, weights loaded) with the given tasks -> {metric_mean/_std/_list}.
 
-  Raises eval_utils.NanFoundError if the generator output has NaNs (eval_gan_lib.py:95-212)."""
+  Raises eval_utils.NanFoundError if the generator output has NaNs (eval_gan_lib.py:95-212).
+  With an initialised process group of W > 1 ranks (all holding the same weights; every rank must
+  call this) the generator / Inception batches are sharded over the ranks and the features
+  all-gathered (compare_gan_amd/eval_shard.py); every rank returns the same result.  shard=False
+  evaluates on the calling rank alone."""
   np.random.seed(42)
   dataset = gan._dataset  # pylint: disable=protected-access
   if num_test_examples is None:
@@ -54,55 +67,67 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
   batch_size = 64
   num_batches = int(np.ceil(num_test_examples / batch_size))
   device = gan.device
-  # the same latent variables for each evaluation: a dedicated counter-based stream, seed 42
+  rank, world = eval_shard.rank_world(shard)
+  if num_batches < world:
+    rank, world = 0, 1          # fewer batches than ranks: not worth a collective
+  # the same latent variables for each evaluation: a dedicated counter-based stream, seed 42; batch
+  # `index` is a pure function of its index (the name keys the stream), which is what lets ranks
+  # take batches independently
   eval_step = torch.zeros((), dtype=torch.int64, device=device)
   saved = (tpu_random._st()["seed"], tpu_random._st()["step"])  # pylint: disable=protected-access
   tpu_random.set_random_offset(42, eval_step)
-  counter = [0]
+  next_index = 1
 
-  def generate():
-    counter[0] += 1
-    z = z_generator(shape=[batch_size, gan._z_dim], name="eval_z/%d" % counter[0],  # pylint: disable=protected-access
+  def generate(index):
+    z = z_generator(shape=[batch_size, gan._z_dim], name="eval_z/%d" % index,  # pylint: disable=protected-access
                     device=device)
     labels = None
     if gan.conditional:
-      labels = tpu_random.labels(batch_size, dataset.num_classes, "eval_labels/%d" % counter[0],
-                                 device)
+      labels = tpu_random.labels(batch_size, dataset.num_classes, "eval_labels/%d" % index, device)
     return gan.generate(z, labels)
 
   import time
-  timing = {"accumulators": 0.0, "sample": 0.0, "inception": 0.0, "stats": 0.0}
+  timing = {"accumulators": 0.0, "sample": 0.0, "inception": 0.0, "gather": 0.0, "stats": 0.0,
+            "ranks": world}
 
   def tick():
     torch.cuda.synchronize(device)
     return time.perf_counter()
 
+  transform = lambda images: eval_utils.inception_transform_np(images, batch_size)
   try:
     t0 = tick()
-    _update_bn_accumulators(gan, generate, batch_size, num_accu_examples)
+    next_index += _update_bn_accumulators(gan, generate, batch_size, num_accu_examples, next_index,
+                                          rank, world)
     timing["accumulators"] = tick() - t0
     if not eval_tasks:
       return None
     fake_dsets = []
     for i in range(num_averaging_runs):
-      t0 = tick()
-      fake_dset = eval_utils.EvalDataSample(eval_utils.sample_fake_dataset(generate, num_batches))
-      t1 = tick()
-      timing["sample"] += t1 - t0
-      activations, logits = eval_utils.inception_transform_np(fake_dset.images, batch_size)
-      timing["inception"] += tick() - t1
+      images, activations, logits, nan_found = eval_shard.sharded_fake_features(
+          lambda index: eval_utils.to_eval_images(generate(index)), transform, num_batches,
+          next_index, rank, world, keep_images=(world == 1 and i == 0), timing=timing, tick=tick)
+      next_index += num_batches
+      if nan_found:
+        raise eval_utils.NanFoundError("Detected NaN in fake images.")
+      fake_dset = eval_utils.EvalDataSample(images)
       fake_dset.set_inception_features(activations=activations, logits=logits)
       fake_dset.set_num_examples(num_test_examples)
-      if i != 0:
-        fake_dset.discard_images()
       fake_dsets.append(fake_dset)
   finally:
     tpu_random.set_random_offset(*saved)
 
   t0 = tick()
+  chunk = eval_shard.row_chunk(num_test_examples, world, batch_size)
+  lo, hi = (rank * chunk, min((rank + 1) * chunk, num_test_examples)) if world > 1 else \
+           (0, num_test_examples)
   real_dset = eval_utils.EvalDataSample(
-      eval_utils.get_real_images(dataset=dataset, num_examples=num_test_examples, device=device))
-  real_dset.activations, _ = eval_utils.inception_transform_np(real_dset.images, batch_size)
+      eval_utils.get_real_images(dataset=dataset, num_examples=num_test_examples, device=device,
+                                 rows=(lo, hi)))
+  local_act, _ = eval_utils.inception_transform_np(real_dset.images, batch_size)
+  if world > 1:
+    real_dset.discard_images()    # only this rank's rows: nothing downstream may mistake them for the set
+  real_dset.activations = eval_shard.gather_rows(local_act, num_test_examples, rank, world, chunk)
   real_dset.set_num_examples(num_test_examples)
   t1 = tick()
   timing["inception"] += t1 - t0

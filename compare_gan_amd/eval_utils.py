@@ -54,7 +54,7 @@ def _to_three_channels(images):
 
 
 def get_real_images(dataset, num_examples, split=None, failure_on_insufficient_examples=True,
-                    device="cuda:0"):
+                    device="cuda:0", rows=None):
   """num_examples real images with values in [0, 255] (eval_utils.py:87-141): the first examples
   of the dataset's eval split -- the on-disk arrays (datasets.use_data_dir) or the synthetic
   source.  Only the default eval split exists here."""
@@ -66,7 +66,14 @@ def get_real_images(dataset, num_examples, split=None, failure_on_insufficient_e
     if failure_on_insufficient_examples:
       raise
     raise NotImplementedError("partial eval splits are not supported")
-  images = torch.from_numpy(arrays).to(device)
+  if rows is not None:        # a rank's share of a sharded evaluation (eval_shard.py)
+    arrays = arrays[rows[0]:rows[1]]
+  images = torch.from_numpy(np.ascontiguousarray(arrays)).to(device)
+  return to_eval_images(images)
+
+
+def to_eval_images(images):
+  """[B, H, W, C] in [0, 1] -> three channels in [0, 255]."""
   from compare_gan_amd.hip import kernels as K
   return _to_three_channels(K.scale_f32(images.contiguous(), None, 255.0))
 

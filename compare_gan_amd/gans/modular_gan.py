@@ -74,6 +74,33 @@ _DP_OVERLAP = os.environ.get("CGAMD_DP_OVERLAP", "auto")
 _JOINT_G = os.environ.get("CGAMD_JOINT_G", "1") != "0"   # batched generator forwards (A/B switch)
 _DEFER_WGRAD = os.environ.get("CGAMD_DEFER_WGRAD", "1") != "0"   # grouped small-map weight gradients
 _DP_OVERLAP_MIN_BYTES = 32 << 20
+# With the overlap on, the gradients leave in _DP_BUCKETS buckets (each at least
+# _DP_BUCKET_MIN_BYTES) DURING the backward pass that produces them: a bucket's all-reduce starts
+# as soon as its last gradient exists (tensor hooks), the last layers first -- see plan_buckets().
+_DP_BUCKETS = int(os.environ.get("CGAMD_DP_BUCKETS", "2"))
+_DP_BUCKET_MIN_BYTES = int(os.environ.get("CGAMD_DP_BUCKET_MIN_MB", "16")) << 20
+
+
+def plan_buckets(numels, num_buckets, min_bytes):
+  """Splits the variables of a network (creation = forward order, `numels` elements each, fp32)
+  into at most `num_buckets` CONTIGUOUS index ranges of about equal bytes, none smaller than
+  `min_bytes` -- returned in LAUNCH order: the backward pass produces the gradients of the last
+  layers first, so the first bucket to leave is the tail of the list.  Contiguous ranges keep each
+  bucket one slice of the flat gradient buffer (one collective per bucket, one multi-tensor Adam
+  over the whole buffer afterwards).  xGMI rings are per-link bound, so the buckets stay large:
+  two ~equal halves hide half of the all-reduce behind the rest of the backward pass at the cost
+  of one extra ring latency."""
+  total = 4 * sum(numels)
+  n = max(1, min(int(num_buckets), int(total // max(1, min_bytes)), len(numels)))
+  target = total / n
+  ranges, hi, acc = [], len(numels), 0
+  for i in range(len(numels) - 1, -1, -1):
+    acc += 4 * numels[i]
+    if len(ranges) < n - 1 and acc >= target and i > 0:
+      ranges.append((i, hi))
+      hi, acc = i, 0
+  ranges.append((0, hi))
+  return ranges
 _NCCL_WATCHDOG_POLL_S = 0.1   # ProcessGroupNCCL's watchdog poll period (see _capture)
 
 
@@ -95,6 +122,83 @@ class _OptimizerState(object):
     self.device = device
     self._comm = None
     self._inflight = None
+    self._buckets = None       # plan_buckets() ranges, launch order
+    self._armed = None         # per-backward state of the bucketed all-reduce (see arm())
+    self._hooks = None
+
+  # -- gradient buckets leaving during the backward pass ----------------------------------------------
+  def _make_flat(self):
+    if self.flat is None:
+      self.flat = torch.empty(sum(p.numel() for p in self.params), dtype=torch.float32,
+                              device=self.device)
+      self.flat_views, self.flat_offsets = [], []
+      off = 0
+      for p in self.params:
+        self.flat_views.append(self.flat[off:off + p.numel()].view(p.shape))
+        self.flat_offsets.append(off)
+        off += p.numel()
+
+  def _overlap(self):
+    self._make_flat()
+    return _DP_OVERLAP == "1" or (_DP_OVERLAP == "auto" and
+                                  self.flat.numel() * 4 >= _DP_OVERLAP_MIN_BYTES)
+
+  def arm(self):
+    """Call right before the backward pass whose gradients apply_gradients() will consume.  Data
+    parallel with the overlap on: from now on each gradient reports in through a tensor hook, and a
+    bucket whose gradients are all there is flattened and all-reduced on the communication stream
+    while the backward pass continues on the main stream.  Otherwise a no-op."""
+    self._armed = None
+    if not (tpu_ops.data_parallel() and tpu_ops.thread_state() is None and _DP_BUCKETS > 1):
+      return
+    if not self._overlap():
+      return
+    if self._buckets is None:
+      self._buckets = plan_buckets([p.numel() for p in self.params], _DP_BUCKETS,
+                                   _DP_BUCKET_MIN_BYTES)
+    if len(self._buckets) < 2:
+      return
+    if self._hooks is None:
+      self._hooks = [p.register_hook(lambda g, i=i: self._on_grad(i, g))
+                     for i, p in enumerate(self.params)]
+    self.join()                  # the buffer of the previous update must have been consumed
+    owner = [0] * len(self.params)
+    for b, (lo, hi) in enumerate(self._buckets):
+      for i in range(lo, hi):
+        owner[i] = b
+    self._armed = {"grads": [None] * len(self.params), "owner": owner,
+                   "missing": [hi - lo for lo, hi in self._buckets],
+                   "launched": [False] * len(self._buckets), "order": []}
+
+  def _on_grad(self, i, grad):
+    st = self._armed
+    if st is None or st["grads"][i] is not None:
+      return None
+    st["grads"][i] = grad
+    b = st["owner"][i]
+    st["missing"][b] -= 1
+    if st["missing"][b] == 0 and not st["launched"][b]:
+      self._launch_bucket(b, st["grads"])
+    return None
+
+  def _launch_bucket(self, b, grads):
+    """flatten + all-reduce of bucket b on the communication stream, behind everything enqueued so
+    far on the stream that produced its gradients (and the weight-gradient side stream)."""
+    st = self._armed
+    lo, hi = self._buckets[b]
+    Fn.join_wgrad_stream()      # deferred / side-stream weight gradients of this bucket
+    main, comm = torch.cuda.current_stream(), self._comm_stream()
+    comm.wait_stream(main)
+    a, z = self.flat_offsets[lo], self.flat_offsets[hi - 1] + self.params[hi - 1].numel()
+    with torch.cuda.stream(comm):
+      K.flatten_multi([g.contiguous() for g in grads[lo:hi]], self.flat[a:z])
+      tpu_ops.cross_replica_sum_(self.flat[a:z])
+    st["launched"][b] = True
+    st["order"].append(b)
+    self._inflight = True
+
+  def disarm(self):
+    self._armed = None
 
   def _ensure(self, grads):
     if torch.cuda.is_current_stream_capturing():
@@ -143,19 +247,28 @@ class _OptimizerState(object):
       K.counter_add(step, 1)
       return
     world = tpu_ops.num_replicas()
-    if self.flat is None:
-      self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32,
-                              device=self.device)
-      self.flat_views = []
-      off = 0
-      for g in grads:
-        self.flat_views.append(self.flat[off:off + g.numel()].view(g.shape))
-        off += g.numel()
+    self._make_flat()
+    st, self._armed = self._armed, None
+    if st is not None:
+      # buckets left during the backward pass (arm()); the ones that could not -- a variable
+      # without gradient never reports in -- leave now, then the update follows on the same stream
+      self._armed = st
+      for b in range(len(self._buckets)):
+        if not st["launched"][b]:
+          self._launch_bucket(b, grads)
+      self._armed = None
+      self.last_bucket_order = st["order"]
+      # the update writes the variables: behind the last main-stream kernel that reads them
+      self._comm_stream().wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self._comm_stream()):
+        self._ensure(self.flat_views).adam(o.learning_rate, o.beta1, o.beta2, o.epsilon,
+                                           1.0 / world, step, ema_decay=ema, ema_start=ema_start)
+        K.counter_add(step, 1)
+      self._inflight = grads
+      return
     self.join()                  # the bucket of the previous update must have been consumed
     main = torch.cuda.current_stream()
-    overlap = _DP_OVERLAP == "1" or (_DP_OVERLAP == "auto" and
-                                     self.flat.numel() * 4 >= _DP_OVERLAP_MIN_BYTES)
-    comm = self._comm_stream() if overlap else main
+    comm = self._comm_stream() if self._overlap() else main
     if comm is not main:
       comm.wait_stream(main)
     with torch.cuda.stream(comm):
@@ -423,6 +536,7 @@ class ModularGAN(AbstractGAN):
       self.create_loss(features, labels)
     # torch.autograd.grad hands the gradients over directly: no AccumulateGrad nodes, whose
     # stream affinity would break hipGraph capture (they run on the stream they were created on)
+    self.d_opt.arm()
     with Fn.deferred_wgrads(self._wgrads_deferrable() and self.penalty_loss is None):
       grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
                                   allow_unused=True)
@@ -449,6 +563,7 @@ class ModularGAN(AbstractGAN):
         self.g_opt.join()
         features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
+    self.g_opt.arm()
     with Fn.deferred_wgrads(self._wgrads_deferrable()):
       grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
                                   allow_unused=True)

@@ -78,11 +78,10 @@ def l2_penalty(discriminator):
     kernels = [v for n, v in discriminator.trainable_variables if n.endswith("/kernel")]
   if not kernels:
     raise ValueError("l2_penalty: the discriminator has no kernels")
-  total = None
-  for w in kernels:
-    t = Fn.HalfSumSqFn.apply(w).reshape(1)
-    total = t if total is None else Fn.add_f32(total, t)
-  return Fn.ScaleF32Fn.apply(total, 1.0 / len(kernels)).reshape(())
+  if kernels[0].is_meta:
+    return kernels[0].new_zeros(())
+  # one multi-tensor reduction over all kernels (three launches instead of three per kernel)
+  return Fn.L2LossMeanFn.apply(*kernels)
 
 
 @gin.configurable("penalty", whitelist=["fn"])

@@ -789,6 +789,36 @@ class HalfSumSqFn(torch.autograd.Function):
     return K.scale_f32(w, up.reshape(1).to(F32).contiguous()).reshape(w.shape)
 
 
+class L2LossMeanFn(torch.autograd.Function):
+  """mean_k tf.nn.l2_loss(w_k) = (1 / K) sum_k sum(w_k^2) / 2 over a LIST of fp32 tensors
+  (penalty_lib.py:85-102) in three launches whatever K is: one multi-tensor gather into a flat
+  buffer, one sum of squares, one scale; the backward is one scale of the flat buffer, handed back
+  as per-tensor views."""
+
+  @staticmethod
+  def forward(ctx, *ws):
+    ws = [w.contiguous() for w in ws]
+    flat = torch.empty(sum(w.numel() for w in ws), dtype=F32, device=ws[0].device)
+    K.flatten_multi(ws, flat)
+    ctx.shapes = [w.shape for w in ws]
+    ctx.save_for_backward(flat)
+    return K.scale_f32(K.moments_f32(flat)[1:2].contiguous(), None, 0.5 / len(ws)).reshape(())
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, up):
+    flat, = ctx.saved_tensors
+    g = K.scale_f32(flat, up.reshape(1).to(F32).contiguous(), 1.0 / len(ctx.shapes))
+    out, off = [], 0
+    for shp in ctx.shapes:
+      n = 1
+      for d in shp:
+        n *= d
+      out.append(g[off:off + n].view(shp))
+      off += n
+    return tuple(out)
+
+
 class AttentionFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, theta, phi, g):

@@ -199,16 +199,20 @@ def _run_eval(gan, checkpoint_path, task_manager, options, num_averaging_runs, d
   gan.load_state_dict(sd)
   from compare_gan_amd.tpu import tpu_ops
   in_context = tpu_ops._STATE["enabled"]  # pylint: disable=protected-access
-  tpu_ops.enable_cross_replica(False)     # evaluation runs on replica 0 alone: no collectives
+  # no collectives INSIDE the networks (each rank runs different evaluation batches on the same
+  # weights); the ranks share the batches and exchange features (eval_shard.py), every rank gets
+  # the result and rank 0 records it
+  tpu_ops.enable_cross_replica(False)
   try:
     result_dict = eval_gan_lib.evaluate_gan(gan, eval_tasks, num_averaging_runs)
-  except eval_utils.NanFoundError as nan_found_error:
+  except eval_utils.NanFoundError as nan_found_error:   # raised on all ranks together
     result_dict = {}
     print("NanFoundError:", nan_found_error)
   finally:
     tpu_ops.enable_cross_replica(in_context)
   default_value = eval_gan_lib.NAN_DETECTED
-  task_manager.add_eval_result(checkpoint_path, result_dict, default_value)
+  if tpu_ops.replica_id() == 0:
+    task_manager.add_eval_result(checkpoint_path, result_dict, default_value)
   return result_dict
 
 
@@ -270,9 +274,14 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
       save_checkpoint(gan, run_config.model_dir, done)
   if tpu_ops.replica_id() == 0:
     task_manager.mark_training_done()
-  if schedule == "eval_after_train" and tpu_ops.replica_id() == 0:
-    for checkpoint_path in task_manager.unevaluated_checkpoints(
-        eval_every_steps=eval_every_steps if eval_every_steps > 0 else None):
+  if schedule == "eval_after_train":
+    _barrier()  # the last checkpoint and the training-done marker are on disk
+    # rank 0 picks the checkpoints; every rank evaluates its share of each one's batches
+    todo = _broadcast_from_rank0(
+        list(task_manager.unevaluated_checkpoints(
+            eval_every_steps=eval_every_steps if eval_every_steps > 0 else None))
+        if tpu_ops.replica_id() == 0 else None)
+    for checkpoint_path in todo:
       _run_eval(gan, checkpoint_path, task_manager, options, num_eval_averaging_runs, device)
-  _barrier()    # nobody tears the process group down while rank 0 still evaluates
+  _barrier()    # nobody tears the process group down while another rank still works
   return gan

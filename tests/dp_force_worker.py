@@ -48,7 +48,7 @@ def main():
     # autograd-thread collectives (cross-replica batch norm backward) AFTER an earlier capture in
     # the same process made the group's watchdog thread query a captured event
     # (hipErrorCapturedEvent, torch 2.10 / RCCL 2.26); launchers capture once, group up first
-    init, base, gan = run(dev, local_bn, capture=(mode == "local"))
+    init, base, gan = run(dev, local_bn, capture=(mode in ("local", "buckets")))
     stage("single replica done")
     assert gan.d_opt.flat is None          # no bucket without data parallelism
     del gan
@@ -65,6 +65,26 @@ def main():
         bad = [k for k in base if not torch.equal(base[k], forced[k])]
         assert not bad, "one-rank data parallel differs from single replica: %s" % bad[:5]
         del gan
+    if mode == "buckets":
+        # the gradients leave in three buckets DURING the backward pass (tensor hooks -> flatten +
+        # ncclAllReduce per bucket on the communication stream, captured in the hipGraph): every
+        # variable bit-identical to the single replica, and the buckets left tail first
+        from compare_gan_amd.gans import modular_gan as mg
+        mg._DP_OVERLAP, mg._DP_BUCKETS, mg._DP_BUCKET_MIN_BYTES = "1", 3, 1 << 16
+        _, forced, gan = run(dev, local_bn)
+        stage("one-rank data parallel, bucketed all-reduce in the backward pass done")
+        for opt in (gan.d_opt, gan.g_opt):
+            assert opt._buckets is not None and len(opt._buckets) == 3, opt._buckets
+            assert opt._buckets[0][1] == len(opt.params) and opt._buckets[-1][0] == 0
+            assert sorted(opt.last_bucket_order) == [0, 1, 2], opt.last_bucket_order
+            assert opt.last_bucket_order[0] == 0, opt.last_bucket_order   # the tail leaves first
+        bad = [k for k in base if not torch.equal(base[k], forced[k])]
+        assert not bad, "bucketed data parallel differs from single replica: %s" % bad[:5]
+        # eager (no capture) as well
+        _, eager, gan2 = run(dev, local_bn, capture=False)
+        bad = [k for k in base if not torch.equal(base[k], eager[k])]
+        assert not bad, "bucketed data parallel (eager) differs: %s" % bad[:5]
+        del gan, gan2
     if mode == "sync":
         # default bindings: cross-replica batch norm through SyncMoments on the one-rank group
         _, synced, gan = run(dev, ())

@@ -293,3 +293,33 @@ def test_in_process_replicas_all_reduce():
     t.join(60)
   assert not any(t.is_alive() for t in threads)
   assert sorted(seen) == ["RuntimeError", "ValueError"]
+
+
+def test_plan_buckets_contiguous_tail_first_and_balanced():
+  """modular_gan.plan_buckets: the gradient buckets that leave during the backward pass."""
+  from compare_gan_amd.gans.modular_gan import plan_buckets
+  rng = np.random.default_rng(3)
+  for trial in range(50):
+    n = int(rng.integers(1, 60))
+    numels = [int(x) for x in rng.integers(1, 5_000_000, size=n)]
+    nb = int(rng.integers(1, 6))
+    min_bytes = int(rng.integers(1, 32)) << 20
+    ranges = plan_buckets(numels, nb, min_bytes)
+    total = 4 * sum(numels)
+    assert 1 <= len(ranges) <= max(1, min(nb, total // min_bytes, n))
+    assert ranges[0][1] == n and ranges[-1][0] == 0          # launch order: the tail first
+    for (lo, hi), (lo2, hi2) in zip(ranges[:-1], ranges[1:]):
+      assert hi2 == lo and lo2 < hi2                           # contiguous, no gaps, no overlap
+    assert sorted(i for lo, hi in ranges for i in range(lo, hi)) == list(range(n))
+    if len(ranges) > 1:
+      target = total / len(ranges)
+      biggest = 4 * max(numels)
+      for lo, hi in ranges[:-1]:
+        got = 4 * sum(numels[lo:hi])
+        assert target <= got < target + biggest              # closes as soon as the target is met
+  # a network below 2 x min_bytes is one bucket (= the single flat all-reduce of round 2)
+  assert plan_buckets([1000, 2000, 3000], 4, 16 << 20) == [(0, 3)]
+  # BigGAN-sized example: 70 M parameters in two ~140 MB halves
+  numels = [4_000_000] * 17 + [1_000_000] * 2
+  r = plan_buckets(numels, 2, 16 << 20)
+  assert len(r) == 2 and abs(4 * sum(numels[r[0][0]:]) - 4 * sum(numels[:r[1][1]])) <= 2 * 16_000_000

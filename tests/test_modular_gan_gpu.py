@@ -328,7 +328,8 @@ def test_wgangp_step_resnet5(dev, emulate):
 def _biggan_family_forward_and_gradients(dev, label, bind, g_over, d_over, arch=None,
                                          min_g_grads=40, fwd_tol=(0.05, 5e-3),
                                          d_tol=(0.98, 0.2), g_tol=(0.97, 0.3), check_u=True,
-                                         bsz=2, g_step=True, oracle_device="cpu"):
+                                         bsz=2, g_step=True, oracle_device="cpu",
+                                         image_shape=None):
     """Generator forward, D sub-step and G sub-step losses and gradients of a BigGAN-family
     architecture under biggan_imagenet128.gin against the bf16-storage oracle (128x128)."""
     from compare_gan_amd.architectures import arch_ops as ops
@@ -346,6 +347,8 @@ def _biggan_family_forward_and_gradients(dev, label, bind, g_over, d_over, arch=
                                     **d_over))
     if arch is not None:
         overrides["architecture"] = arch
+    if image_shape is not None:
+        overrides["image_shape"] = image_shape
     ora = U.build_oracle(config, vs, **overrides)
     rng = np.random.RandomState(11)
     images = torch.from_numpy(rng.uniform(size=(bsz,) + dataset.image_shape).astype(np.float32))
@@ -443,6 +446,21 @@ def test_biggan_at_the_benchmark_batch(dev):
         # measured in round 3: generator output max / mean |diff| 0.016 / 1.1e-3, worst D-step gradient
         # cosine 0.99951, worst G-step 0.99961, power-iteration vectors within 3.3e-7
         fwd_tol=(0.03, 2e-3), d_tol=(0.999, 0.06), g_tol=(0.999, 0.06))
+
+
+def test_biggan_256px(dev):
+    """resnet_biggan at 256x256 (resnet_biggan.py:205-221,344-361: seven blocks, attention at 64x64
+    in G after B4 and at 128x128 in D after B1 -- 16,384 queries x 4,096 keys), width ch = 32 (the
+    attention kernel needs key width ch / 8 >= 4), batch
+    2, z_dim 140 (seven 20-dim chunks of the hierarchical z): generator forward, D and G sub-steps
+    against the bf16-storage oracle resident on the device.  Nothing above 128 px had run before
+    round 3."""
+    _biggan_family_forward_and_gradients(
+        dev, "biggan-256px",
+        ['dataset.name = "imagenet_256"', "options.z_dim = 140",
+         "resnet_biggan.Generator.ch = 32", "resnet_biggan.Discriminator.ch = 32"],
+        dict(hierarchical_z=True, embed_y=True, ch=32), dict(project_y=True, ch=32), bsz=2,
+        oracle_device=dev, image_shape=(256, 256, 3), min_g_grads=40)
 
 
 def test_biggan_deep_forward_and_gradients(dev):
