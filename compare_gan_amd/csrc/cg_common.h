@@ -128,6 +128,7 @@ bool cg_prof_enabled();
 // useful MACs x 2 (structural zeros of a zero-inserted input are not counted) and the minimum bf16
 // HBM traffic 2 * (in + out + weights) bytes of one launch
 void cg_conv_algorithmic_cost(const cgConvGeom* g, double* flops, double* bytes);
+void cg_prof_tag_geom(const cgConvGeom* g);
 struct CgProfScope {
   int fam;
   hipStream_t st;
@@ -135,6 +136,7 @@ struct CgProfScope {
     if (cg_prof_enabled()) {
       double f, b;
       cg_conv_algorithmic_cost(g, &f, &b);
+      cg_prof_tag_geom(g);
       cg_prof_begin(fam, f, b, st);
     }
   }

@@ -1,5 +1,7 @@
 // Thread-local error string + ABI version.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string>
 #include <vector>
 #include "cg_common.h"
 
@@ -20,6 +22,7 @@ namespace {
 struct ProfSlot {
   std::vector<hipEvent_t> ev;   // start/stop pairs
   std::vector<double> flops, bytes;
+  std::vector<std::string> tags;   // geometry of the launch (CGAMD_PROF_LOG)
   double total_ms = 0, total_flops = 0, total_bytes = 0;
   int64_t launches = 0;
 };
@@ -37,6 +40,13 @@ const char* const g_prof_names[CG_PROF_COUNT] = {
 
 bool cg_prof_enabled() { return g_prof_on; }
 
+// geometry tag of the NEXT cg_prof_begin on this thread (written to CGAMD_PROF_LOG at collect time)
+static thread_local char g_prof_tag[128] = {0};
+void cg_prof_tag_geom(const cgConvGeom* g) {
+  snprintf(g_prof_tag, sizeof(g_prof_tag), "N%d %dx%dx%d->%dx%dx%d k%dx%d S%d U%d", g->N, g->Hin,
+           g->Win, g->Ci, g->Ho, g->Wo, g->Co, g->kh, g->kw, g->S, g->U);
+}
+
 void cg_prof_begin(int family, double flops, double bytes, hipStream_t st) {
   if (!g_prof_on || family < 0 || family >= CG_PROF_COUNT) return;
   ProfSlot& p = g_prof[family];
@@ -47,6 +57,8 @@ void cg_prof_begin(int family, double flops, double bytes, hipStream_t st) {
   p.ev.push_back(b);
   p.flops.push_back(flops);
   p.bytes.push_back(bytes);
+  p.tags.push_back(g_prof_tag);
+  g_prof_tag[0] = 0;
   hipEventRecord(a, st);
 }
 
@@ -70,10 +82,15 @@ extern "C" int cg_prof_collect(int family, double* total_ms, int64_t* launches, 
                                double* bytes) {
   if (family < 0 || family >= CG_PROF_COUNT) CG_FAIL(CG_ERR_BAD_ARG, "cg_prof_collect: family");
   ProfSlot& p = g_prof[family];
+  const char* log_path = getenv("CGAMD_PROF_LOG");   // per-launch lines: family;geometry;us;GFLOP
+  FILE* log = (log_path && *log_path && !p.ev.empty()) ? fopen(log_path, "a") : nullptr;
   for (size_t i = 0; i + 1 < p.ev.size(); i += 2) {
     hipEventSynchronize(p.ev[i + 1]);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
+      if (log)
+        fprintf(log, "%s;%s;%.2f;%.3f\n", g_prof_names[family], p.tags[i / 2].c_str(), ms * 1e3,
+                p.flops[i / 2] * 1e-9);
       p.total_ms += ms;
       p.total_flops += p.flops[i / 2];
       p.total_bytes += p.bytes[i / 2];
@@ -82,9 +99,11 @@ extern "C" int cg_prof_collect(int family, double* total_ms, int64_t* launches, 
     hipEventDestroy(p.ev[i]);
     hipEventDestroy(p.ev[i + 1]);
   }
+  if (log) fclose(log);
   p.ev.clear();
   p.flops.clear();
   p.bytes.clear();
+  p.tags.clear();
   if (total_ms) *total_ms = p.total_ms;
   if (launches) *launches = p.launches;
   if (flops) *flops = p.total_flops;

@@ -243,6 +243,71 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// "Thin" 1x1 convolutions: at most 8 input channels (K <= 8), e.g. the data gradient of the
+// discriminators' final linear layer (dy [B, 1] x W^T -> [B, 512]; arch_ops.py:538-556 under
+// tf.gradients).  One MFMA tile would be 1/64 full and the generic kernel's element-wise epilogue
+// dominated (52-72 us for ONE workgroup, profiles/r03_dstep_launches.txt); here a thread owns one
+// pixel x 8 consecutive output channels: <= 8 FMAs per output, 16-byte stores.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)a.M * groups) return;
+  const int m = (int)(idx / groups), co = (int)(idx - (int64_t)m * groups) * 8;
+  float x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    x[k] = 0.f;
+    if (k < a.Ci) {
+      bf16_t v = a.in[(int64_t)m * a.Ci + k];
+      if (a.gate_in) {
+        const float g = bf2f(a.gate_in[(int64_t)m * a.Ci + k]);
+        if (!(g > 0.f)) v = f2bf(bf2f(v) * a.slope_in);   // rounded like the staged operand
+      }
+      x[k] = bf2f(v);
+    }
+  }
+  float val[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    val[e] = 0.f;
+    if (co + e < a.Co) {
+      float w[8];
+      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp), w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) val[e] += x[k] * w[k];   // Kp == 8, padding is zero
+      if (a.bias) val[e] += a.bias[co + e];
+    }
+  }
+  const int64_t o = (int64_t)m * a.Co + co;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (co + e >= a.Co) continue;
+    if (a.self_gate) {
+      if (!(val[e] > 0.f)) val[e] *= a.slope_out;
+    } else if (a.gate_out) {
+      if (!(bf2f(a.gate_out[o + e]) > 0.f)) val[e] *= a.slope_out;
+    }
+    if (a.residual) val[e] += bf2f(a.residual[o + e]);
+  }
+  if (co + 8 <= a.Co && (a.Co & 7) == 0) {
+    if (a.out_f32) {
+      float* op = reinterpret_cast<float*>(a.out) + o;
+      *reinterpret_cast<float4*>(op) = make_float4(val[0], val[1], val[2], val[3]);
+      *reinterpret_cast<float4*>(op + 4) = make_float4(val[4], val[5], val[6], val[7]);
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(val);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (co + e >= a.Co) continue;
+      if (a.out_f32) reinterpret_cast<float*>(a.out)[o + e] = val[e];
+      else reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val[e]);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // Weight gradient.
 // -------------------------------------------------------------------------------------------
 struct GWgradArgs {
@@ -671,6 +736,13 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   const bool vec = (g->Ci % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
   CgProfScope prof(CG_PROF_GCONV_GENERIC, g, st);
+  if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Ci <= 8 && a.Kp == 8) {
+    const int groups = cdiv(g->Co, 8);
+    const int64_t threads = (int64_t)a.M * groups;
+    thin_conv_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(a, groups);
+    CG_CHECK_LAUNCH("cg_gconv(thin)");
+    return CG_OK;
+  }
   if (g->Co > 64)
     launch_gconv<128, 128, 2, 2>(a, vec, st);
   else if (g->Co > 32)

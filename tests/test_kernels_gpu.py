@@ -109,6 +109,11 @@ CONV_CASES = [
     ("small_8x8", 3, 8, 8, 128, 192, 3, 1, 1),
     ("small_16x8", 2, 16, 8, 128, 64, 3, 1, 1),
     ("small_16x16", 2, 16, 16, 64, 128, 3, 1, 1),
+    # thin 1x1 convolutions (K <= 8: thin_conv_kernel): the final linear layer of a discriminator
+    # (its data gradient is 1 -> 512), a 4-channel 1x1 with a vector store, and a ragged channel tail
+    ("thin_linear", 128, 1, 1, 512, 1, 1, 1, 1),
+    ("thin_1x1_c4", 3, 5, 5, 4, 40, 1, 1, 1),
+    ("thin_co12", 2, 3, 3, 8, 12, 1, 1, 1),
 ]
 
 
