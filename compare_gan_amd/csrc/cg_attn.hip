@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void attn_bwd_k_kernel(
 // Dk / Dv are zero-padded to DKP / DVP in LDS.
 // -------------------------------------------------------------------------------------------
 constexpr int AT = 64;          // keys (fwd, bwd_q) / queries (bwd_k) per LDS stage
-constexpr int ATP = AT + 8;     // padded row of the transposed tiles
+constexpr int ATP = AT + 4;     // padded row of the transposed tiles: 34 dwords -> the 2-byte
+                                // transposed stores of a wave hit 32 distinct banks, the 8-byte
+                                // fragment reads are 2-way (their minimum)
 
 __device__ __forceinline__ bf16x8_t pack_bf16x8(const float* v) {
   s16x8_t r;
@@ -252,22 +254,50 @@ __device__ __forceinline__ bf16x8_t read_perm(const bf16_t* row, int off) {
   uint4 q = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return __builtin_bit_cast(bf16x8_t, q);
 }
-// row-major [rows][D] global tile -> LDS row-major (ld = DP + 8) with zero padding, rows r0..r0+AT
+// Staging of a [AT rows][D] global tile (row-major, D % 4 == 0) goes through REGISTERS: the 8-byte
+// chunks of the NEXT tile are loaded right after the barrier that publishes the current one and
+// stay in flight while it is multiplied (the round-2 kernels loaded and stored element by element
+// between two barriers: 24 dependent 2-byte round trips per tile, 10x the MFMA time of the tile).
+// DP: padded width (multiple of 16): chunk c of thread t is row (t + 256 c) / (DP/4), channels
+// 4 ((t + 256 c) % (DP/4)) ..+3, zero beyond D.
 template <int DP>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int D, int64_t row0,
-                                           bf16_t* dst) {
-  for (int i = threadIdx.x; i < AT * DP; i += 256) {
-    const int r = i / DP, d = i - r * DP;
-    dst[r * (DP + 8) + d] = d < D ? src[(row0 + r) * D + d] : (bf16_t)0;
+struct TileRegs {
+  static constexpr int CH = DP / 4;
+  static constexpr int N = AT * CH / 256;
+  static_assert((AT * CH) % 256 == 0, "tile chunks must divide over 256 threads");
+  uint2 r[N];
+};
+template <int DP>
+__device__ __forceinline__ void tile_load(TileRegs<DP>& t, const bf16_t* __restrict__ src, int D,
+                                          int64_t row0) {
+#pragma unroll
+  for (int c = 0; c < TileRegs<DP>::N; ++c) {
+    const int i = threadIdx.x + c * 256;
+    const int row = i / TileRegs<DP>::CH, d = (i - row * TileRegs<DP>::CH) * 4;
+    t.r[c] = d < D ? *reinterpret_cast<const uint2*>(src + (row0 + row) * D + d) : make_uint2(0u, 0u);
   }
 }
-// same tile transposed: dst[d][r], D rows padded to DPT (multiple of 32) zero rows
-template <int DPT>
-__device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ src, int D, int64_t row0,
-                                           bf16_t* dst) {
-  for (int i = threadIdx.x; i < AT * DPT; i += 256) {
-    const int r = i / DPT, d = i - r * DPT;
-    dst[d * ATP + r] = d < D ? src[(row0 + r) * D + d] : (bf16_t)0;
+// row-major LDS image, pitch DS + 8 elements; only channels < DS are kept (DS <= DP)
+template <int DP, int DS>
+__device__ __forceinline__ void tile_store_rows(const TileRegs<DP>& t, bf16_t* dst) {
+#pragma unroll
+  for (int c = 0; c < TileRegs<DP>::N; ++c) {
+    const int i = threadIdx.x + c * 256;
+    const int row = i / TileRegs<DP>::CH, d = (i - row * TileRegs<DP>::CH) * 4;
+    if (DS == DP || d < DS) *reinterpret_cast<uint2*>(dst + row * (DS + 8) + d) = t.r[c];
+  }
+}
+// transposed LDS image dst[d][row], pitch ATP
+template <int DP>
+__device__ __forceinline__ void tile_store_cols(const TileRegs<DP>& t, bf16_t* dst) {
+#pragma unroll
+  for (int c = 0; c < TileRegs<DP>::N; ++c) {
+    const int i = threadIdx.x + c * 256;
+    const int row = i / TileRegs<DP>::CH, d = (i - row * TileRegs<DP>::CH) * 4;
+    dst[(d + 0) * ATP + row] = (bf16_t)(t.r[c].x & 0xffffu);
+    dst[(d + 1) * ATP + row] = (bf16_t)(t.r[c].x >> 16);
+    dst[(d + 2) * ATP + row] = (bf16_t)(t.r[c].y & 0xffffu);
+    dst[(d + 3) * ATP + row] = (bf16_t)(t.r[c].y >> 16);
   }
 }
 // register fragment of a global row-major matrix: row = lane & 31, columns kd*16 + (lane>>5)*8 + e
@@ -302,11 +332,19 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(
 #pragma unroll
     for (int v = 0; v < 16; ++v) o[t][v] = 0.f;
   float m = -3.0e38f, l = 0.f;
+  TileRegs<DKP> kreg;
+  TileRegs<DVP> vreg;
+  tile_load<DKP>(kreg, phi, Dk, (int64_t)b * Lk);
+  tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk);
   for (int k0 = 0; k0 < Lk; k0 += AT) {
+    __syncthreads();   // every wave is done with the previous tile
+    tile_store_rows<DKP, DKP>(kreg, Ks);
+    tile_store_cols<DVP>(vreg, Vt);
     __syncthreads();
-    stage_rows<DKP>(phi, Dk, (int64_t)b * Lk + k0, Ks);
-    stage_cols<DVP>(g, Dv, (int64_t)b * Lk + k0, Vt);
-    __syncthreads();
+    if (k0 + AT < Lk) {
+      tile_load<DKP>(kreg, phi, Dk, (int64_t)b * Lk + k0 + AT);
+      tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk + k0 + AT);
+    }
 #pragma unroll
     for (int sub = 0; sub < AT / 32; ++sub) {
       f32x16_t s;
@@ -389,12 +427,20 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int v = 0; v < 16; ++v) dq[t][v] = 0.f;
+  TileRegs<KT * 32> kreg;
+  TileRegs<DVP> vreg;
+  tile_load<KT * 32>(kreg, phi, Dk, (int64_t)b * Lk);
+  tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk);
   for (int k0 = 0; k0 < Lk; k0 += AT) {
     __syncthreads();
-    stage_rows<DKP>(phi, Dk, (int64_t)b * Lk + k0, Ks);
-    stage_cols<KT * 32>(phi, Dk, (int64_t)b * Lk + k0, Kt);
-    stage_rows<DVP>(g, Dv, (int64_t)b * Lk + k0, Vs);
+    tile_store_rows<KT * 32, DKP>(kreg, Ks);
+    tile_store_cols<KT * 32>(kreg, Kt);
+    tile_store_rows<DVP, DVP>(vreg, Vs);
     __syncthreads();
+    if (k0 + AT < Lk) {
+      tile_load<KT * 32>(kreg, phi, Dk, (int64_t)b * Lk + k0 + AT);
+      tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk + k0 + AT);
+    }
 #pragma unroll
     for (int sub = 0; sub < AT / 32; ++sub) {
       f32x16_t s, dp;
@@ -470,17 +516,34 @@ __global__ __launch_bounds__(256) void attn_bwd_k_mfma_kernel(
   for (int t = 0; t < VT; ++t)
 #pragma unroll
     for (int v = 0; v < 16; ++v) dv[t][v] = 0.f;
+  TileRegs<KT * 32> qreg;
+  TileRegs<DVP> oreg;
+  float lreg = 0.f, dreg = 0.f;
+  tile_load<KT * 32>(qreg, theta, Dk, (int64_t)b * Lq);
+  tile_load<DVP>(oreg, dout, Dv, (int64_t)b * Lq);
+  if (threadIdx.x < AT) {
+    lreg = lse[(int64_t)b * Lq + threadIdx.x];
+    dreg = delta[(int64_t)b * Lq + threadIdx.x];
+  }
   for (int q0 = 0; q0 < Lq; q0 += AT) {
     __syncthreads();
-    stage_rows<DKP>(theta, Dk, (int64_t)b * Lq + q0, Qs);
-    stage_cols<KT * 32>(theta, Dk, (int64_t)b * Lq + q0, Qt);
-    stage_rows<DVP>(dout, Dv, (int64_t)b * Lq + q0, Os);
-    stage_cols<DVP>(dout, Dv, (int64_t)b * Lq + q0, Ot);
+    tile_store_rows<KT * 32, DKP>(qreg, Qs);
+    tile_store_cols<KT * 32>(qreg, Qt);
+    tile_store_rows<DVP, DVP>(oreg, Os);
+    tile_store_cols<DVP>(oreg, Ot);
     if (threadIdx.x < AT) {
-      sls[threadIdx.x] = lse[(int64_t)b * Lq + q0 + threadIdx.x];
-      sdl[threadIdx.x] = delta[(int64_t)b * Lq + q0 + threadIdx.x];
+      sls[threadIdx.x] = lreg;
+      sdl[threadIdx.x] = dreg;
     }
     __syncthreads();
+    if (q0 + AT < Lq) {
+      tile_load<KT * 32>(qreg, theta, Dk, (int64_t)b * Lq + q0 + AT);
+      tile_load<DVP>(oreg, dout, Dv, (int64_t)b * Lq + q0 + AT);
+      if (threadIdx.x < AT) {
+        lreg = lse[(int64_t)b * Lq + q0 + AT + threadIdx.x];
+        dreg = delta[(int64_t)b * Lq + q0 + AT + threadIdx.x];
+      }
+    }
 #pragma unroll
     for (int sub = 0; sub < AT / 32; ++sub) {
       // S[q][key], dP[q][key]: lane owns key `col`, queries 4*half + (v & 3) + 8*(v >> 2)

@@ -2103,7 +2103,11 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     const char* e = getenv("CGAMD_CONV_T128_MIN");
     return e ? atoi(e) : 513;
   }();
-  if (tiles128 >= t128_min) {
+  // ... except when the 128-row tiles fit ONE round of single-resident workgroups (<= 256, deep
+  // ring) and the 64-row tiles would need two: same MFMA time per CU, half the weight traffic
+  // (BigGAN's 4x4x1536 layers, K = 13824: 295 -> 172 us, profiles/r03_biggan_launches.txt)
+  const int tiles64 = cdiv(a.Mp, 64) * a.ntiles * phases;
+  if (tiles128 >= t128_min || (tiles128 <= 256 && tiles64 > 256 && tiles64 <= 384)) {
     a.mtiles = cdiv(a.Mp, 128);
     dim3 grid(a.mtiles * a.ntiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_128x128, g, st);

@@ -243,45 +243,24 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
-// "Thin" 1x1 convolutions: at most 8 input channels (K <= 8), e.g. the data gradient of the
-// discriminators' final linear layer (dy [B, 1] x W^T -> [B, 512]; arch_ops.py:538-556 under
-// tf.gradients).  One MFMA tile would be 1/64 full and the generic kernel's element-wise epilogue
-// dominated (52-72 us for ONE workgroup, profiles/r03_dstep_launches.txt); here a thread owns one
-// pixel x 8 consecutive output channels: <= 8 FMAs per output, 16-byte stores.
+// VALU kernels for the 1x1 problems no MFMA tile fits (profiles/r03_dstep_launches.txt,
+// r03_biggan_launches.txt: the generic kernel spent 35-210 us on each of them):
+//  * "thin": at most 8 input channels (K <= 8) -- the data gradient of a discriminator's final
+//    linear layer (dy [B, 1] x W^T, arch_ops.py:538-556 under tf.gradients), the 1x1 shortcut of
+//    BigGAN's first discriminator block on the pooled RGB image (resnet_biggan.py:285-300);
+//  * "small linear": linear layers on at most 512 rows whose K is not a multiple of 8 -- the
+//    conditional-batch-norm projections of [z chunk, label embedding] (148 -> C, arch_ops.py:
+//    362-372) and the label embedding itself (1000 -> 128).
+// A thread owns 8 consecutive output channels; thin: of THIN_PIX pixels, with its 8 x K weights in
+// registers; small linear: of one row, lanes of a wave share the channel group (weight loads are
+// wave-uniform) and differ in the row.
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)a.M * groups) return;
-  const int m = (int)(idx / groups), co = (int)(idx - (int64_t)m * groups) * 8;
-  float x[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    x[k] = 0.f;
-    if (k < a.Ci) {
-      bf16_t v = a.in[(int64_t)m * a.Ci + k];
-      if (a.gate_in) {
-        const float g = bf2f(a.gate_in[(int64_t)m * a.Ci + k]);
-        if (!(g > 0.f)) v = f2bf(bf2f(v) * a.slope_in);   // rounded like the staged operand
-      }
-      x[k] = bf2f(v);
-    }
-  }
-  float val[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    val[e] = 0.f;
-    if (co + e < a.Co) {
-      float w[8];
-      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp), w);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) val[e] += x[k] * w[k];   // Kp == 8, padding is zero
-      if (a.bias) val[e] += a.bias[co + e];
-    }
-  }
-  const int64_t o = (int64_t)m * a.Co + co;
+__device__ __forceinline__ void vconv_store8(const GConvArgs& a, int64_t m, int co, float* val) {
+  const int64_t o = m * a.Co + co;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     if (co + e >= a.Co) continue;
+    if (a.bias) val[e] += a.bias[co + e];
     if (a.self_gate) {
       if (!(val[e] > 0.f)) val[e] *= a.slope_out;
     } else if (a.gate_out) {
@@ -305,6 +284,86 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups)
       else reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val[e]);
     }
   }
+}
+__device__ __forceinline__ float vconv_in(const GConvArgs& a, int64_t off) {
+  bf16_t v = a.in[off];
+  if (a.gate_in) {
+    const float g = bf2f(a.gate_in[off]);
+    if (!(g > 0.f)) v = f2bf(bf2f(v) * a.slope_in);   // rounded like the staged operand
+  }
+  return bf2f(v);
+}
+
+constexpr int THIN_PIX = 8;
+__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups) {
+  // thread -> (pixel block, channel group): consecutive lanes take consecutive channel groups of the
+  // same pixels, so a wave's stores cover whole pixel rows
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pb = idx / groups;
+  const int co = (int)(idx - pb * groups) * 8;
+  const int64_t m0 = pb * THIN_PIX;
+  if (m0 >= a.M) return;
+  float w[8][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (co + e < a.Co) {
+      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp), w[e]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[e][k] = 0.f;
+    }
+  }
+  // all inputs of the pixel block first (independent loads), then the arithmetic
+  float x[THIN_PIX][8];
+#pragma unroll
+  for (int i = 0; i < THIN_PIX; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      x[i][k] = (k < a.Ci && m0 + i < a.M) ? vconv_in(a, (m0 + i) * a.Ci + k) : 0.f;
+#pragma unroll
+  for (int i = 0; i < THIN_PIX; ++i) {
+    if (m0 + i >= a.M) continue;
+    float val[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      val[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) val[e] += x[i][k] * w[e][k];   // Kp == 8, padding is zero
+    }
+    vconv_store8(a, m0 + i, co, val);
+  }
+}
+
+__global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a, int groups) {
+  // one WAVE per (row, 8-channel group): the lanes split K in 8-element pieces (K = 148: 19 lanes,
+  // one round trip to memory), then a butterfly sum.  4 waves of a block take 4 consecutive groups.
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x;
+  const int g = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (g >= groups) return;   // wave-uniform
+  const int co = g * 8;
+  float val[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) val[e] = 0.f;
+  const int64_t xrow = (int64_t)m * a.Ci;
+  for (int k0 = lane * 8; k0 < a.Ci; k0 += 512) {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (k0 + k < a.Ci) ? vconv_in(a, xrow + k0 + k) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (co + e >= a.Co) continue;   // wave-uniform
+      float w[8];
+      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp + k0), w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) val[e] += x[k] * w[k];   // bt rows are zero-padded to Kp
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) val[e] += __shfl_xor(val[e], off, 64);
+  if (lane == 0) vconv_store8(a, m, co, val);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -738,9 +797,17 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   CgProfScope prof(CG_PROF_GCONV_GENERIC, g, st);
   if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Ci <= 8 && a.Kp == 8) {
     const int groups = cdiv(g->Co, 8);
-    const int64_t threads = (int64_t)a.M * groups;
+    const int64_t threads = (int64_t)cdiv(a.M, THIN_PIX) * groups;
     thin_conv_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(a, groups);
     CG_CHECK_LAUNCH("cg_gconv(thin)");
+    return CG_OK;
+  }
+  if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Hin == 1 && g->Win == 1 &&
+      a.M <= 512 && !vec) {
+    const int groups = cdiv(g->Co, 8);
+    dim3 grid(a.M, cdiv(groups, 4));
+    small_linear_kernel<<<grid, 256, 0, st>>>(a, groups);
+    CG_CHECK_LAUNCH("cg_gconv(small linear)");
     return CG_OK;
   }
   if (g->Co > 64)

@@ -114,6 +114,12 @@ CONV_CASES = [
     ("thin_linear", 128, 1, 1, 512, 1, 1, 1, 1),
     ("thin_1x1_c4", 3, 5, 5, 4, 40, 1, 1, 1),
     ("thin_co12", 2, 3, 3, 8, 12, 1, 1, 1),
+    ("thin_rgb_1x1", 3, 16, 16, 3, 96, 1, 1, 1),
+    # small linear layers with K % 8 != 0 (small_linear_kernel): conditional-BN projection, label
+    # embedding, ragged rows / channels
+    ("lin_148", 64, 1, 1, 148, 192, 1, 1, 1),
+    ("lin_1000", 70, 1, 1, 1000, 128, 1, 1, 1),
+    ("lin_ragged", 5, 1, 1, 21, 20, 1, 1, 1),
 ]
 
 
