@@ -3,6 +3,8 @@
 // v1: streaming online-softmax on the vector ALU (Dk = C/8 is 12..48, too thin for MFMA K);
 // four lanes cooperate on one query (forward, dtheta) or one key (dphi, dg), each owning a
 // quarter of the value / key channels; K/V (resp. Q/dO) tiles of 64 rows are staged in LDS.
+#include <stdlib.h>
+
 #include "cg_common.h"
 
 namespace {
@@ -260,40 +262,46 @@ __device__ __forceinline__ bf16x8_t read_perm(const bf16_t* row, int off) {
 // between two barriers: 24 dependent 2-byte round trips per tile, 10x the MFMA time of the tile).
 // DP: padded width (multiple of 16): chunk c of thread t is row (t + 256 c) / (DP/4), channels
 // 4 ((t + 256 c) % (DP/4)) ..+3, zero beyond D.
-template <int DP>
+template <int DP, int NT>
 struct TileRegs {
   static constexpr int CH = DP / 4;
-  static constexpr int N = AT * CH / 256;
-  static_assert((AT * CH) % 256 == 0, "tile chunks must divide over 256 threads");
+  static constexpr int TOTAL = AT * CH;
+  static constexpr int N = (TOTAL + NT - 1) / NT;
   uint2 r[N];
 };
-template <int DP>
-__device__ __forceinline__ void tile_load(TileRegs<DP>& t, const bf16_t* __restrict__ src, int D,
+template <int DP, int NT>
+__device__ __forceinline__ void tile_load(TileRegs<DP, NT>& t, const bf16_t* __restrict__ src, int D,
                                           int64_t row0) {
+  using T = TileRegs<DP, NT>;
 #pragma unroll
-  for (int c = 0; c < TileRegs<DP>::N; ++c) {
-    const int i = threadIdx.x + c * 256;
-    const int row = i / TileRegs<DP>::CH, d = (i - row * TileRegs<DP>::CH) * 4;
-    t.r[c] = d < D ? *reinterpret_cast<const uint2*>(src + (row0 + row) * D + d) : make_uint2(0u, 0u);
+  for (int c = 0; c < T::N; ++c) {
+    const int i = threadIdx.x + c * NT;
+    const int row = i / T::CH, d = (i - row * T::CH) * 4;
+    t.r[c] = (d < D && (T::TOTAL % NT == 0 || i < T::TOTAL))
+                 ? *reinterpret_cast<const uint2*>(src + (row0 + row) * D + d) : make_uint2(0u, 0u);
   }
 }
 // row-major LDS image, pitch DS + 8 elements; only channels < DS are kept (DS <= DP)
-template <int DP, int DS>
-__device__ __forceinline__ void tile_store_rows(const TileRegs<DP>& t, bf16_t* dst) {
+template <int DP, int DS, int NT>
+__device__ __forceinline__ void tile_store_rows(const TileRegs<DP, NT>& t, bf16_t* dst) {
+  using T = TileRegs<DP, NT>;
 #pragma unroll
-  for (int c = 0; c < TileRegs<DP>::N; ++c) {
-    const int i = threadIdx.x + c * 256;
-    const int row = i / TileRegs<DP>::CH, d = (i - row * TileRegs<DP>::CH) * 4;
-    if (DS == DP || d < DS) *reinterpret_cast<uint2*>(dst + row * (DS + 8) + d) = t.r[c];
+  for (int c = 0; c < T::N; ++c) {
+    const int i = threadIdx.x + c * NT;
+    const int row = i / T::CH, d = (i - row * T::CH) * 4;
+    if ((DS == DP || d < DS) && (T::TOTAL % NT == 0 || i < T::TOTAL))
+      *reinterpret_cast<uint2*>(dst + row * (DS + 8) + d) = t.r[c];
   }
 }
 // transposed LDS image dst[d][row], pitch ATP
-template <int DP>
-__device__ __forceinline__ void tile_store_cols(const TileRegs<DP>& t, bf16_t* dst) {
+template <int DP, int NT>
+__device__ __forceinline__ void tile_store_cols(const TileRegs<DP, NT>& t, bf16_t* dst) {
+  using T = TileRegs<DP, NT>;
 #pragma unroll
-  for (int c = 0; c < TileRegs<DP>::N; ++c) {
-    const int i = threadIdx.x + c * 256;
-    const int row = i / TileRegs<DP>::CH, d = (i - row * TileRegs<DP>::CH) * 4;
+  for (int c = 0; c < T::N; ++c) {
+    const int i = threadIdx.x + c * NT;
+    const int row = i / T::CH, d = (i - row * T::CH) * 4;
+    if (T::TOTAL % NT != 0 && i >= T::TOTAL) continue;
     dst[(d + 0) * ATP + row] = (bf16_t)(t.r[c].x & 0xffffu);
     dst[(d + 1) * ATP + row] = (bf16_t)(t.r[c].x >> 16);
     dst[(d + 2) * ATP + row] = (bf16_t)(t.r[c].y & 0xffffu);
@@ -312,9 +320,10 @@ __device__ __forceinline__ bf16x8_t load_frag(const bf16_t* __restrict__ src, in
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-// forward: grid (Lq/128, B); wave -> 32 queries.
-template <int DKP, int DVP>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(
+// forward: grid (Lq / (32 NW), B); wave -> 32 queries.  NW = 8 waves halve the staging work and the
+// barriers per query.
+template <int DKP, int DVP, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(
     const bf16_t* __restrict__ theta, const bf16_t* __restrict__ phi, const bf16_t* __restrict__ g,
     int Lq, int Lk, int Dk, int Dv, bf16_t* __restrict__ out, float* __restrict__ lse) {
   constexpr int KD = DKP / 16, VT = DVP / 32;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(
   __shared__ __attribute__((aligned(16))) bf16_t Vt[DVP * ATP];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int64_t q = (int64_t)b * Lq + blockIdx.x * 128 + wave * 32 + col;
+  const int64_t q = (int64_t)b * Lq + blockIdx.x * (32 * NW) + wave * 32 + col;
   bf16x8_t qf[KD];
 #pragma unroll
   for (int kd = 0; kd < KD; ++kd) qf[kd] = load_frag(theta, Dk, q, kd, half);
@@ -332,18 +341,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(
 #pragma unroll
     for (int v = 0; v < 16; ++v) o[t][v] = 0.f;
   float m = -3.0e38f, l = 0.f;
-  TileRegs<DKP> kreg;
-  TileRegs<DVP> vreg;
-  tile_load<DKP>(kreg, phi, Dk, (int64_t)b * Lk);
-  tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk);
+  TileRegs<DKP, NW * 64> kreg;
+  TileRegs<DVP, NW * 64> vreg;
+  tile_load<DKP, NW * 64>(kreg, phi, Dk, (int64_t)b * Lk);
+  tile_load<DVP, NW * 64>(vreg, g, Dv, (int64_t)b * Lk);
   for (int k0 = 0; k0 < Lk; k0 += AT) {
     __syncthreads();   // every wave is done with the previous tile
-    tile_store_rows<DKP, DKP>(kreg, Ks);
-    tile_store_cols<DVP>(vreg, Vt);
+    tile_store_rows<DKP, DKP, NW * 64>(kreg, Ks);
+    tile_store_cols<DVP, NW * 64>(vreg, Vt);
     __syncthreads();
     if (k0 + AT < Lk) {
-      tile_load<DKP>(kreg, phi, Dk, (int64_t)b * Lk + k0 + AT);
-      tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk + k0 + AT);
+      tile_load<DKP, NW * 64>(kreg, phi, Dk, (int64_t)b * Lk + k0 + AT);
+      tile_load<DVP, NW * 64>(vreg, g, Dv, (int64_t)b * Lk + k0 + AT);
     }
 #pragma unroll
     for (int sub = 0; sub < AT / 32; ++sub) {
@@ -402,9 +411,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(
   if (half == 0) lse[q] = m + __logf(l);
 }
 
-// dtheta: grid (Lq/128, B); wave -> 32 queries, loops over the keys.
-template <int DKP, int DVP>
-__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(
+// dtheta: grid (Lq / (32 NW), B); wave -> 32 queries, loops over the keys.
+template <int DKP, int DVP, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_q_mfma_kernel(
     const bf16_t* __restrict__ theta, const bf16_t* __restrict__ phi, const bf16_t* __restrict__ g,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int Lq, int Lk, int Dk, int Dv,
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(
   __shared__ __attribute__((aligned(16))) bf16_t Vs[AT * (DVP + 8)];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int64_t q = (int64_t)b * Lq + blockIdx.x * 128 + wave * 32 + col;
+  const int64_t q = (int64_t)b * Lq + blockIdx.x * (32 * NW) + wave * 32 + col;
   bf16x8_t qf[KD], dof[VD];
 #pragma unroll
   for (int kd = 0; kd < KD; ++kd) qf[kd] = load_frag(theta, Dk, q, kd, half);
@@ -427,19 +436,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int v = 0; v < 16; ++v) dq[t][v] = 0.f;
-  TileRegs<KT * 32> kreg;
-  TileRegs<DVP> vreg;
-  tile_load<KT * 32>(kreg, phi, Dk, (int64_t)b * Lk);
-  tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk);
+  TileRegs<KT * 32, NW * 64> kreg;
+  TileRegs<DVP, NW * 64> vreg;
+  tile_load<KT * 32, NW * 64>(kreg, phi, Dk, (int64_t)b * Lk);
+  tile_load<DVP, NW * 64>(vreg, g, Dv, (int64_t)b * Lk);
   for (int k0 = 0; k0 < Lk; k0 += AT) {
     __syncthreads();
-    tile_store_rows<KT * 32, DKP>(kreg, Ks);
-    tile_store_cols<KT * 32>(kreg, Kt);
-    tile_store_rows<DVP, DVP>(vreg, Vs);
+    tile_store_rows<KT * 32, DKP, NW * 64>(kreg, Ks);
+    tile_store_cols<KT * 32, NW * 64>(kreg, Kt);
+    tile_store_rows<DVP, DVP, NW * 64>(vreg, Vs);
     __syncthreads();
     if (k0 + AT < Lk) {
-      tile_load<KT * 32>(kreg, phi, Dk, (int64_t)b * Lk + k0 + AT);
-      tile_load<DVP>(vreg, g, Dv, (int64_t)b * Lk + k0 + AT);
+      tile_load<KT * 32, NW * 64>(kreg, phi, Dk, (int64_t)b * Lk + k0 + AT);
+      tile_load<DVP, NW * 64>(vreg, g, Dv, (int64_t)b * Lk + k0 + AT);
     }
 #pragma unroll
     for (int sub = 0; sub < AT / 32; ++sub) {
@@ -486,9 +495,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(
     }
 }
 
-// dphi, dg: grid (Lk/128, B); wave -> 32 keys, loops over the queries.
-template <int DKP, int DVP>
-__global__ __launch_bounds__(256) void attn_bwd_k_mfma_kernel(
+// dphi, dg: grid (Lk / (32 NW), B); wave -> 32 keys, loops over the queries.
+template <int DKP, int DVP, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_k_mfma_kernel(
     const bf16_t* __restrict__ theta, const bf16_t* __restrict__ phi, const bf16_t* __restrict__ g,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int Lq, int Lk, int Dk, int Dv, bf16_t* __restrict__ dphi,
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(256) void attn_bwd_k_mfma_kernel(
   __shared__ float sls[AT], sdl[AT];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int64_t k = (int64_t)b * Lk + blockIdx.x * 128 + wave * 32 + col;
+  const int64_t k = (int64_t)b * Lk + blockIdx.x * (32 * NW) + wave * 32 + col;
   bf16x8_t kf[KD], vf[VD];
 #pragma unroll
   for (int kd = 0; kd < KD; ++kd) kf[kd] = load_frag(phi, Dk, k, kd, half);
@@ -516,29 +525,29 @@ __global__ __launch_bounds__(256) void attn_bwd_k_mfma_kernel(
   for (int t = 0; t < VT; ++t)
 #pragma unroll
     for (int v = 0; v < 16; ++v) dv[t][v] = 0.f;
-  TileRegs<KT * 32> qreg;
-  TileRegs<DVP> oreg;
+  TileRegs<KT * 32, NW * 64> qreg;
+  TileRegs<DVP, NW * 64> oreg;
   float lreg = 0.f, dreg = 0.f;
-  tile_load<KT * 32>(qreg, theta, Dk, (int64_t)b * Lq);
-  tile_load<DVP>(oreg, dout, Dv, (int64_t)b * Lq);
+  tile_load<KT * 32, NW * 64>(qreg, theta, Dk, (int64_t)b * Lq);
+  tile_load<DVP, NW * 64>(oreg, dout, Dv, (int64_t)b * Lq);
   if (threadIdx.x < AT) {
     lreg = lse[(int64_t)b * Lq + threadIdx.x];
     dreg = delta[(int64_t)b * Lq + threadIdx.x];
   }
   for (int q0 = 0; q0 < Lq; q0 += AT) {
     __syncthreads();
-    tile_store_rows<KT * 32, DKP>(qreg, Qs);
-    tile_store_cols<KT * 32>(qreg, Qt);
-    tile_store_rows<DVP, DVP>(oreg, Os);
-    tile_store_cols<DVP>(oreg, Ot);
+    tile_store_rows<KT * 32, DKP, NW * 64>(qreg, Qs);
+    tile_store_cols<KT * 32, NW * 64>(qreg, Qt);
+    tile_store_rows<DVP, DVP, NW * 64>(oreg, Os);
+    tile_store_cols<DVP, NW * 64>(oreg, Ot);
     if (threadIdx.x < AT) {
       sls[threadIdx.x] = lreg;
       sdl[threadIdx.x] = dreg;
     }
     __syncthreads();
     if (q0 + AT < Lq) {
-      tile_load<KT * 32>(qreg, theta, Dk, (int64_t)b * Lq + q0 + AT);
-      tile_load<DVP>(oreg, dout, Dv, (int64_t)b * Lq + q0 + AT);
+      tile_load<KT * 32, NW * 64>(qreg, theta, Dk, (int64_t)b * Lq + q0 + AT);
+      tile_load<DVP, NW * 64>(oreg, dout, Dv, (int64_t)b * Lq + q0 + AT);
       if (threadIdx.x < AT) {
         lreg = lse[(int64_t)b * Lq + q0 + AT + threadIdx.x];
         dreg = delta[(int64_t)b * Lq + q0 + AT + threadIdx.x];
@@ -617,23 +626,37 @@ bool attn_mfma_ok(int Lq, int Lk, int Dk, int Dv) {
   return (Lq % 128) == 0 && (Lk % 128) == 0 && Dk <= 64 && Dv <= 128 && (Dk % 4) == 0 &&
          (Dv % 4) == 0;
 }
+// 8-wave workgroups (256 rows) when the rows divide and the grid still fills the chip twice over
+// (CGAMD_ATTN_NW8=0/1 forces)
+bool attn_nw8(int L, int B) {
+  const char* e = getenv("CGAMD_ATTN_NW8");   // read per call: the tests toggle it in-process
+  const int env = e ? atoi(e) : -1;
+  if (L % 256) return false;
+  if (env >= 0) return env != 0;
+  return (int64_t)(L / 256) * B >= 512;
+}
 // padded sizes: DKP in {16, 32, 64}; DVP in {32, 64, 96, 128}
 #define CG_ATTN_DISPATCH(KERNEL, GRID, ...)                                                   \
   do {                                                                                        \
+    if (nw8) CG_ATTN_DISPATCH_NW(KERNEL, 8, GRID, __VA_ARGS__);                               \
+    else CG_ATTN_DISPATCH_NW(KERNEL, 4, GRID, __VA_ARGS__);                                   \
+  } while (0)
+#define CG_ATTN_DISPATCH_NW(KERNEL, NW, GRID, ...)                                            \
+  do {                                                                                        \
     const int dkp_ = Dk <= 16 ? 16 : (Dk <= 32 ? 32 : 64);                                    \
     const int dvp_ = (Dv + 31) / 32 * 32;                                                     \
-    if (dkp_ == 16 && dvp_ == 32) KERNEL<16, 32><<<GRID, 256, 0, st>>>(__VA_ARGS__);          \
-    else if (dkp_ == 16 && dvp_ == 64) KERNEL<16, 64><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
-    else if (dkp_ == 16 && dvp_ == 96) KERNEL<16, 96><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
-    else if (dkp_ == 16) KERNEL<16, 128><<<GRID, 256, 0, st>>>(__VA_ARGS__);                  \
-    else if (dkp_ == 32 && dvp_ == 32) KERNEL<32, 32><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
-    else if (dkp_ == 32 && dvp_ == 64) KERNEL<32, 64><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
-    else if (dkp_ == 32 && dvp_ == 96) KERNEL<32, 96><<<GRID, 256, 0, st>>>(__VA_ARGS__);     \
-    else if (dkp_ == 32) KERNEL<32, 128><<<GRID, 256, 0, st>>>(__VA_ARGS__);                  \
-    else if (dvp_ == 32) KERNEL<64, 32><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
-    else if (dvp_ == 64) KERNEL<64, 64><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
-    else if (dvp_ == 96) KERNEL<64, 96><<<GRID, 256, 0, st>>>(__VA_ARGS__);                   \
-    else KERNEL<64, 128><<<GRID, 256, 0, st>>>(__VA_ARGS__);                                  \
+    if (dkp_ == 16 && dvp_ == 32) KERNEL<16, 32, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);          \
+    else if (dkp_ == 16 && dvp_ == 64) KERNEL<16, 64, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 16 && dvp_ == 96) KERNEL<16, 96, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 16) KERNEL<16, 128, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);                  \
+    else if (dkp_ == 32 && dvp_ == 32) KERNEL<32, 32, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 32 && dvp_ == 64) KERNEL<32, 64, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 32 && dvp_ == 96) KERNEL<32, 96, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);     \
+    else if (dkp_ == 32) KERNEL<32, 128, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);                  \
+    else if (dvp_ == 32) KERNEL<64, 32, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);                   \
+    else if (dvp_ == 64) KERNEL<64, 64, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);                   \
+    else if (dvp_ == 96) KERNEL<64, 96, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);                   \
+    else KERNEL<64, 128, NW><<<GRID, NW * 64, 0, st>>>(__VA_ARGS__);                                  \
   } while (0)
 
 int check_attn(int B, int Lq, int Lk, int Dk, int Dv, const char* who) {
@@ -654,7 +677,8 @@ extern "C" int cg_attention_fwd(const void* theta, const void* phi, const void* 
   if (!theta || !phi || !g || !out || !lse) CG_FAIL(CG_ERR_BAD_ARG, "cg_attention_fwd: null");
   hipStream_t st = (hipStream_t)stream;
   if (attn_mfma_ok(Lq, Lk, Dk, Dv)) {
-    dim3 mgrid(Lq / 128, B);
+    const bool nw8 = attn_nw8(Lq, B);
+    dim3 mgrid(Lq / (nw8 ? 256 : 128), B);
     CG_ATTN_DISPATCH(attn_fwd_mfma_kernel, mgrid, (const bf16_t*)theta, (const bf16_t*)phi,
                      (const bf16_t*)g, Lq, Lk, Dk, Dv, (bf16_t*)out, lse);
     CG_CHECK_LAUNCH("cg_attention_fwd(mfma)");
@@ -690,10 +714,13 @@ extern "C" int cg_attention_bwd(const void* theta, const void* phi, const void* 
                                                     Dv, delta);
   CG_CHECK_LAUNCH("cg_attention_bwd(delta)");
   if (attn_mfma_ok(Lq, Lk, Dk, Dv)) {
-    dim3 mq(Lq / 128, B), mk(Lk / 128, B);
+    bool nw8 = attn_nw8(Lq, B);
+    dim3 mq(Lq / (nw8 ? 256 : 128), B);
     CG_ATTN_DISPATCH(attn_bwd_q_mfma_kernel, mq, (const bf16_t*)theta, (const bf16_t*)phi,
                      (const bf16_t*)g, (const bf16_t*)dout, lse, delta, Lq, Lk, Dk, Dv,
                      (bf16_t*)dtheta);
+    nw8 = attn_nw8(Lk, B);
+    dim3 mk(Lk / (nw8 ? 256 : 128), B);
     CG_ATTN_DISPATCH(attn_bwd_k_mfma_kernel, mk, (const bf16_t*)theta, (const bf16_t*)phi,
                      (const bf16_t*)g, (const bf16_t*)dout, lse, delta, Lq, Lk, Dk, Dv,
                      (bf16_t*)dphi, (bf16_t*)dg);

@@ -295,14 +295,15 @@ __device__ __forceinline__ float vconv_in(const GConvArgs& a, int64_t off) {
 }
 
 constexpr int THIN_PIX = 8;
-__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups) {
-  // thread -> (pixel block, channel group): consecutive lanes take consecutive channel groups of the
-  // same pixels, so a wave's stores cover whole pixel rows
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t pb = idx / groups;
-  const int co = (int)(idx - pb * groups) * 8;
-  const int64_t m0 = pb * THIN_PIX;
-  if (m0 >= a.M) return;
+// block = gpb channel groups x ppb pixels (gpb * ppb <= 256): thread -> (pixel slot t / gpb, group
+// blockIdx.y * gpb + t % gpb); iteration i covers the ppb consecutive pixels blockIdx.x * THIN_PIX *
+// ppb + i * ppb ..: the stores of a block iteration are one contiguous span of pixel rows
+__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups, int gpb, int ppb) {
+  const int gl = threadIdx.x % gpb, ps = threadIdx.x / gpb;
+  const int g = blockIdx.y * gpb + gl;
+  if (g >= groups || ps >= ppb) return;
+  const int co = g * 8;
+  const int64_t m0 = (int64_t)blockIdx.x * THIN_PIX * ppb + ps;
   float w[8][8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -313,16 +314,19 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups)
       for (int k = 0; k < 8; ++k) w[e][k] = 0.f;
     }
   }
-  // all inputs of the pixel block first (independent loads), then the arithmetic
+  // all inputs of the thread's pixels first (independent loads), then the arithmetic
   float x[THIN_PIX][8];
 #pragma unroll
   for (int i = 0; i < THIN_PIX; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      x[i][k] = (k < a.Ci && m0 + i < a.M) ? vconv_in(a, (m0 + i) * a.Ci + k) : 0.f;
+    for (int k = 0; k < 8; ++k) {
+      const int64_t m = m0 + (int64_t)i * ppb;
+      x[i][k] = (k < a.Ci && m < a.M) ? vconv_in(a, m * a.Ci + k) : 0.f;
+    }
 #pragma unroll
   for (int i = 0; i < THIN_PIX; ++i) {
-    if (m0 + i >= a.M) continue;
+    const int64_t m = m0 + (int64_t)i * ppb;
+    if (m >= a.M) continue;
     float val[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -330,29 +334,32 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups)
 #pragma unroll
       for (int k = 0; k < 8; ++k) val[e] += x[i][k] * w[e][k];   // Kp == 8, padding is zero
     }
-    vconv_store8(a, m0 + i, co, val);
+    vconv_store8(a, m, co, val);
   }
 }
 
-__global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a, int groups) {
-  // one WAVE per (row, 8-channel group): the lanes split K in 8-element pieces (K = 148: 19 lanes,
-  // one round trip to memory), then a butterfly sum.  4 waves of a block take 4 consecutive groups.
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x;
-  const int g = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (g >= groups) return;   // wave-uniform
-  const int co = g * 8;
+// block = 64 rows x ONE 8-channel group; wave w takes the 8-element K pieces w, w + 4, ... (the
+// weight loads of a wave are uniform), lane -> row; the four partial sums meet in LDS.  The 8 weight
+// rows of a group are read once per 64 rows (a wave per output re-read them per row: 100 MB of L2
+// traffic for a 0.5 MB matrix).
+__global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a) {
+  __shared__ float part[4][64][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + lane;
+  const int co = blockIdx.y * 8;
+  const bool mok = m < a.M;
   float val[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) val[e] = 0.f;
-  const int64_t xrow = (int64_t)m * a.Ci;
-  for (int k0 = lane * 8; k0 < a.Ci; k0 += 512) {
+  const int64_t xrow = (int64_t)(mok ? m : 0) * a.Ci;
+#pragma unroll 2
+  for (int k0 = wave * 8; k0 < a.Ci; k0 += 32) {
     float x[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = (k0 + k < a.Ci) ? vconv_in(a, xrow + k0 + k) : 0.f;
+    for (int k = 0; k < 8; ++k) x[k] = (mok && k0 + k < a.Ci) ? vconv_in(a, xrow + k0 + k) : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (co + e >= a.Co) continue;   // wave-uniform
+      if (co + e >= a.Co) continue;   // block-uniform
       float w[8];
       unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp + k0), w);
 #pragma unroll
@@ -360,10 +367,14 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a, int grou
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
+  for (int e = 0; e < 8; ++e) part[wave][lane][e] = val[e];
+  __syncthreads();
+  if (wave == 0 && mok) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) val[e] += __shfl_xor(val[e], off, 64);
-  if (lane == 0) vconv_store8(a, m, co, val);
+    for (int e = 0; e < 8; ++e)
+      val[e] = (part[0][lane][e] + part[1][lane][e]) + (part[2][lane][e] + part[3][lane][e]);
+    vconv_store8(a, m, co, val);
+  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -797,16 +808,16 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   CgProfScope prof(CG_PROF_GCONV_GENERIC, g, st);
   if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Ci <= 8 && a.Kp == 8) {
     const int groups = cdiv(g->Co, 8);
-    const int64_t threads = (int64_t)cdiv(a.M, THIN_PIX) * groups;
-    thin_conv_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(a, groups);
+    const int gpb = groups < 64 ? groups : 64, ppb = 256 / gpb;
+    dim3 grid(cdiv(a.M, THIN_PIX * ppb), cdiv(groups, gpb));
+    thin_conv_kernel<<<grid, 256, 0, st>>>(a, groups, gpb, ppb);
     CG_CHECK_LAUNCH("cg_gconv(thin)");
     return CG_OK;
   }
   if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Hin == 1 && g->Win == 1 &&
       a.M <= 512 && !vec) {
-    const int groups = cdiv(g->Co, 8);
-    dim3 grid(a.M, cdiv(groups, 4));
-    small_linear_kernel<<<grid, 256, 0, st>>>(a, groups);
+    dim3 grid(cdiv(a.M, 64), cdiv(g->Co, 8));
+    small_linear_kernel<<<grid, 256, 0, st>>>(a);
     CG_CHECK_LAUNCH("cg_gconv(small linear)");
     return CG_OK;
   }

@@ -2,7 +2,7 @@
 # round 3: attention kernels with register-staged tiles, small-linear / thin kernels v2, tile policy
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "thin or lin_ or gemm_1x1 or attention or fast_" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "thin or lin_ or gemm_1x1 or attention or fast_ or c96 or halo_4x4" 2>&1 | tail -4
 rm -f gpurun_out/r3u_launches.txt
 CGAMD_PROF_LOG=$R/gpurun_out/r3u_launches.txt timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fid --no-roofline --legs biggan128 > gpurun_out/r3u_bench.json 2> gpurun_out/r3u_bench.err
 python - <<PY

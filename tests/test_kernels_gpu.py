@@ -948,6 +948,19 @@ def test_rng_matches_oracle_bitstream(K, dev):
                                   (2, 128, 128, 48, 128),      # MFMA path, Dk padded to 64
                                   (2, 96, 40, 12, 48)])         # ragged lengths: streaming fallback
 def test_attention(K, dev, dims):
+    _attention_case(K, dev, dims)
+
+
+@pytest.mark.parametrize("nw8", ["0", "1"])
+@pytest.mark.parametrize("dims", [(2, 512, 256, 12, 48), (1, 1024, 512, 24, 96), (1, 256, 256, 40, 128)])
+def test_attention_workgroup_forms(K, dev, dims, nw8, monkeypatch):
+    """4-wave (128 rows) and 8-wave (256 rows) workgroups of the MFMA kernels, forced either way
+    (the policy picks 8 waves only on grids of >= 512 workgroups, i.e. at the benchmark sizes)."""
+    monkeypatch.setenv("CGAMD_ATTN_NW8", nw8)
+    _attention_case(K, dev, dims)
+
+
+def _attention_case(K, dev, dims):
     B, Lq, Lk, Dk, Dv = dims
     g = _gen(31)
     t64, tb = rand_bf16((B, Lq, Dk), g, 0.5)
