@@ -405,6 +405,229 @@ __global__ __launch_bounds__(256) void bjacobi_round_kernel(double* __restrict__
     }
   }
 }
+// ---- the block round as three kernels ---------------------------------------------------------
+// The fused round above runs nb / 2 = 64 workgroups at d = 2048 (a quarter of the CUs), each a
+// serial chain of 32 + 64 chunk loads: 88 us per round, 15 k rounds per FID
+// (profiles/r02_fid10k_kernel_stats.csv).  Split by phase the same arithmetic fills the chip:
+//   gram  : (pair, column split) -> partial Gram matrices of the pair's 32 rows   [nb/2 x GS groups]
+//   sweep : pair -> sum of the partials, one cyclic sweep on it, rotation product J [nb/2 groups]
+//   apply : (pair, chunk range of G | V) -> rows <- J rows                          [nb/2 x AS groups]
+// Sums run in the same order as in the fused kernel within a split; the partials of the GS splits
+// are added in a fixed order: deterministic.
+__device__ __forceinline__ void bj_pair(int i, int nb, int round, int* P, int* Q) {
+  const int m = nb - 1;
+  int p, q;
+  if (i == 0) { p = nb - 1; q = round % m; }
+  else { p = (round + i) % m; q = (round - i + m) % m; }
+  if (p > q) { const int x = p; p = q; q = x; }
+  *P = p; *Q = q;
+}
+__global__ __launch_bounds__(256) void bj_gram_kernel(const double* __restrict__ g, int d, int nb,
+                                                      int round, int gs,
+                                                      double* __restrict__ mpart,
+                                                      const int* __restrict__ flags) {
+  if (flags[0]) return;
+  __shared__ double Tt[JCW][JR + 2];
+  __shared__ double Mp[4][JR][JR + 1];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  int P, Q;
+  bj_pair(blockIdx.x, nb, round, &P, &Q);
+  auto grow = [&](int r) -> int64_t { return (int64_t)(r < JB ? P * JB + r : Q * JB + r - JB); };
+  const int cbeg = blockIdx.y * (d / gs), cend = cbeg + d / gs;
+  const int ti = l >> 3, tj = l & 7;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  double cur[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = t + 256 * e;
+    cur[e] = g[grow(idx >> 6) * d + cbeg + (idx & 63)];
+  }
+  for (int c0 = cbeg; c0 < cend; c0 += JCW) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = t + 256 * e;
+      Tt[idx & 63][idx >> 6] = cur[e];
+    }
+    __syncthreads();
+    if (c0 + JCW < cend) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = t + 256 * e;
+        cur[e] = g[grow(idx >> 6) * d + c0 + JCW + (idx & 63)];
+      }
+    }
+    for (int k = w; k < JCW; k += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = Tt[k][4 * ti + e]; b[e] = Tt[k][4 * tj + e]; }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) Mp[w][4 * ti + x][4 * tj + y] = acc[x][y];
+  __syncthreads();
+  double* out = mpart + ((int64_t)blockIdx.x * gs + blockIdx.y) * (JR * JR);
+  for (int e = t; e < JR * JR; e += 256) {
+    const int r = e / JR, c = e - r * JR;
+    out[e] = Mp[0][r][c] + Mp[1][r][c] + Mp[2][r][c] + Mp[3][r][c];
+  }
+}
+__global__ __launch_bounds__(256) void bj_sweep_kernel(const double* __restrict__ mpart, int gs,
+                                                       double tol, double* __restrict__ jg,
+                                                       int* __restrict__ rot,
+                                                       int* __restrict__ flags) {
+  if (flags[0]) return;
+  __shared__ double M[JR][JR + 1];
+  __shared__ double J[JR][JR + 1];
+  __shared__ double s_c[JB], s_s[JB];
+  __shared__ int s_p[JB], s_q[JB], s_rot;
+  const int t = threadIdx.x;
+  if (t == 0) s_rot = 0;
+  const double* mp = mpart + (int64_t)blockIdx.x * gs * (JR * JR);
+  for (int e = t; e < JR * JR; e += 256) {
+    const int r = e / JR, c = e - r * JR;
+    double sum = mp[e];
+    for (int k = 1; k < gs; ++k) sum += mp[(int64_t)k * (JR * JR) + e];
+    M[r][c] = sum;
+    J[r][c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int ir = 0; ir < JR - 1; ++ir) {
+    if (t < JB) {
+      const int mm = JR - 1;
+      int p, q;
+      if (t == 0) { p = JR - 1; q = ir % mm; }
+      else { p = (ir + t) % mm; q = (ir - t + mm) % mm; }
+      if (p > q) { const int x = p; p = q; q = x; }
+      const double al = M[p][p], be = M[q][q], ga = M[p][q];
+      double cs = 1.0, sn = 0.0;
+      const double thr = JACOBI_NULL_ROW * __longlong_as_double(
+          (long long)*reinterpret_cast<const unsigned long long*>(flags + 2));
+      if (fabs(ga) > tol * sqrt(al * be) && fabs(ga) > 1e-300 && al > thr && be > thr) {
+        const double zeta = (be - al) / (2.0 * ga);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        cs = 1.0 / sqrt(1.0 + tt * tt);
+        sn = cs * tt;
+        atomicAdd(&s_rot, 1);
+      }
+      s_c[t] = cs; s_s[t] = sn; s_p[t] = p; s_q[t] = q;
+    }
+    __syncthreads();
+    {
+      const int pi = t >> 4, p = s_p[pi], q = s_q[pi];
+      const double cs = s_c[pi], sn = s_s[pi];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = (t & 15) + 16 * h;
+        const double mpv = M[p][c], mq = M[q][c];
+        M[p][c] = cs * mpv - sn * mq;
+        M[q][c] = sn * mpv + cs * mq;
+        const double jp = J[p][c], jq = J[q][c];
+        J[p][c] = cs * jp - sn * jq;
+        J[q][c] = sn * jp + cs * jq;
+      }
+    }
+    __syncthreads();
+    {
+      const int pi = t >> 4, p = s_p[pi], q = s_q[pi];
+      const double cs = s_c[pi], sn = s_s[pi];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = (t & 15) + 16 * h;
+        const double mpv = M[r][p], mq = M[r][q];
+        M[r][p] = cs * mpv - sn * mq;
+        M[r][q] = sn * mpv + cs * mq;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    rot[blockIdx.x] = s_rot;
+    if (s_rot) atomicAdd(&flags[1], s_rot);
+  }
+  if (s_rot == 0) return;
+  double* out = jg + (int64_t)blockIdx.x * (JR * JR);
+  for (int e = t; e < JR * JR; e += 256) out[e] = J[e / JR][e % JR];
+}
+__global__ __launch_bounds__(256) void bj_apply_kernel(double* __restrict__ g,
+                                                       double* __restrict__ v, int d, int nb,
+                                                       int round, int as,
+                                                       const double* __restrict__ jg,
+                                                       const int* __restrict__ rot,
+                                                       const int* __restrict__ flags) {
+  if (flags[0] || rot[blockIdx.x] == 0) return;
+  __shared__ double Tt[JCW][JR + 2];
+  __shared__ double J[JR][JR + 1];
+  const int t = threadIdx.x;
+  int P, Q;
+  bj_pair(blockIdx.x, nb, round, &P, &Q);
+  auto grow = [&](int r) -> int64_t { return (int64_t)(r < JB ? P * JB + r : Q * JB + r - JB); };
+  for (int e = t; e < JR * JR; e += 256) J[e / JR][e % JR] = jg[(int64_t)blockIdx.x * (JR * JR) + e];
+  const int ti = t >> 5, tj = t & 31;
+  const int per = 2 * (d / JCW) / as;            // chunks of this workgroup (G chunks, then V chunks)
+  const int cbeg = blockIdx.y * per, cendc = cbeg + per;
+  auto chunk_ptr = [&](int ci) -> double* { return (ci < d / JCW ? g : v); };
+  auto chunk_col = [&](int ci) -> int { return (ci < d / JCW ? ci : ci - d / JCW) * JCW; };
+  double cur[8];
+  {
+    const double* __restrict__ x0 = chunk_ptr(cbeg);
+    const int c0 = chunk_col(cbeg);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = t + 256 * e;
+      cur[e] = x0[grow(idx >> 6) * d + c0 + (idx & 63)];
+    }
+  }
+  for (int ci = cbeg; ci < cendc; ++ci) {
+    double* __restrict__ x = chunk_ptr(ci);
+    const int c0 = chunk_col(ci);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = t + 256 * e;
+      Tt[idx & 63][idx >> 6] = cur[e];
+    }
+    __syncthreads();               // (also publishes J on the first pass)
+    if (ci + 1 < cendc) {
+      const double* __restrict__ xn = chunk_ptr(ci + 1);
+      const int cn = chunk_col(ci + 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = t + 256 * e;
+        cur[e] = xn[grow(idx >> 6) * d + cn + (idx & 63)];
+      }
+    }
+    double acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a][0] = acc[a][1] = 0.0;
+#pragma unroll 8
+    for (int sI = 0; sI < JR; ++sI) {
+      const double b0 = Tt[2 * tj][sI], b1 = Tt[2 * tj + 1][sI];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double ja = J[4 * ti + a][sI];
+        acc[a][0] += ja * b0;
+        acc[a][1] += ja * b1;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double* o = x + grow(4 * ti + a) * d + c0 + 2 * tj;
+      o[0] = acc[a][0];
+      o[1] = acc[a][1];
+    }
+  }
+}
 __global__ void jacobi_sweep_end_kernel(int* flags) {
   if (flags[0]) return;
   if (flags[1] == 0) flags[0] = 1;
@@ -645,7 +868,13 @@ extern "C" int cg_rowscale_f64(const double* a, const double* scale, double* out
   return CG_OK;
 }
 
-extern "C" size_t cg_syevj_workspace_bytes(int d) { return d > 0 ? 256 : 0; }
+// flags (256 B) + for the split block rounds: partial Gram matrices [nb/2][4][32 x 32], rotation
+// products [nb/2][32 x 32], rotation counts [nb/2]
+extern "C" size_t cg_syevj_workspace_bytes(int d) {
+  if (d <= 0) return 0;
+  const size_t pairs = (size_t)(d / JB + 1) / 2 + 1;
+  return 256 + pairs * 5 * JR * JR * sizeof(double) + align_up(pairs * sizeof(int), 256);
+}
 
 extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol,
                             void* ws, size_t ws_bytes, cgStream stream) {
@@ -665,11 +894,75 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
   }();
   if (block_min > 0 && d >= block_min && d % JCW == 0) {   // whole 64-column chunks, nb even
     const int nb = d / JB;   // even
-    for (int s = 0; s < max_sweeps; ++s) {
-      for (int r = 0; r < nb - 1; ++r)
-        bjacobi_round_kernel<<<nb / 2, 256, 0, st>>>(a, v, d, nb, r, tol, flags);
-      jacobi_sweep_end_kernel<<<1, 1, 0, st>>>(flags);
+    static const int split_env = []() {
+      const char* e = getenv("CGAMD_JACOBI_SPLIT");   // 0: the fused round kernel (A/B)
+      return e ? atoi(e) : 1;
+    }();
+    const int chunks = d / JCW;
+    const int gs = (chunks % 4 == 0) ? 4 : ((chunks % 2 == 0) ? 2 : 1);
+    const int as = (2 * chunks) % 8 == 0 ? 8 : ((2 * chunks) % 4 == 0 ? 4 : 2);
+    double* mpart = reinterpret_cast<double*>((char*)ws + 256);
+    double* jg = mpart + (size_t)(nb / 2) * 4 * JR * JR;
+    int* rot = reinterpret_cast<int*>(jg + (size_t)(nb / 2) * JR * JR);
+    auto launch_sweep = [&](hipStream_t q) {
+      for (int r = 0; r < nb - 1; ++r) {
+        if (split_env) {
+          bj_gram_kernel<<<dim3(nb / 2, gs), 256, 0, q>>>(a, d, nb, r, gs, mpart, flags);
+          bj_sweep_kernel<<<nb / 2, 256, 0, q>>>(mpart, gs, tol, jg, rot, flags);
+          bj_apply_kernel<<<dim3(nb / 2, as), 256, 0, q>>>(a, v, d, nb, r, as, jg, rot, flags);
+        } else {
+          bjacobi_round_kernel<<<nb / 2, 256, 0, q>>>(a, v, d, nb, r, tol, flags);
+        }
+      }
+      jacobi_sweep_end_kernel<<<1, 1, 0, q>>>(flags);
+    };
+    // A sweep is 3 (nb - 1) + 1 dependent launches of ~10 us kernels: replayed as ONE hipGraph per
+    // sweep (captured on a private stream: the caller's may be the legacy default stream, which
+    // cannot be captured), and the host looks at the convergence flag every other sweep from the
+    // sixth on instead of queueing all max_sweeps sweeps of no-op launches behind the last useful one.
+    static const int graph_env = []() {
+      const char* e = getenv("CGAMD_JACOBI_GRAPH");
+      return e ? atoi(e) : 1;
+    }();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(st, &cap);
+    bool done = false;
+    if (graph_env && cap == hipStreamCaptureStatusNone) {
+      static hipStream_t js = nullptr;
+      static hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (!js) {
+        hipStreamCreateWithFlags(&js, hipStreamNonBlocking);
+        hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+      }
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipEventRecord(e0, st);
+      hipStreamWaitEvent(js, e0, 0);
+      if (hipStreamBeginCapture(js, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        launch_sweep(js);
+        if (hipStreamEndCapture(js, &graph) == hipSuccess && graph &&
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          int hflags[2] = {0, 0};
+          for (int s = 0; s < max_sweeps; ++s) {
+            hipGraphLaunch(exec, js);
+            if ((s >= 5 && (s & 1)) || s + 1 == max_sweeps) {
+              hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, js);
+              hipStreamSynchronize(js);
+              if (hflags[0]) break;
+            }
+          }
+          done = true;
+        }
+      }
+      (void)hipGetLastError();
+      if (exec) hipGraphExecDestroy(exec);
+      if (graph) hipGraphDestroy(graph);
+      hipEventRecord(e1, js);
+      hipStreamWaitEvent(st, e1, 0);
     }
+    if (!done)
+      for (int s = 0; s < max_sweeps; ++s) launch_sweep(st);
     CG_CHECK_LAUNCH("cg_syevj_f64(block sweeps)");
   } else if (d > 1) {
     for (int s = 0; s < max_sweeps; ++s) {

@@ -112,19 +112,24 @@ def conv_shapes(spec=None, cin=3):
   return out, c_final
 
 
-def make_weights(seed=2015):
-  """Seeded He-normal conv kernels (HWIO fp32), small biases, and the logits layer."""
-  g = torch.Generator().manual_seed(seed)
+def make_weights(seed=2015, device="cpu"):
+  """Seeded He-normal conv kernels (HWIO fp32), small biases, and the logits layer.  device: where
+  the draws are made (the stand-in extractor of an offline evaluation draws its 24 M values on the
+  GPU: 1.2 s of host sampling + 190 host-to-device copies otherwise, bench.py `extractor_setup_s`);
+  the host and device generators give DIFFERENT values for one seed -- tests that compare with the
+  oracle pass the same dictionary to both."""
+  device = torch.device(device)
+  g = torch.Generator(device=device).manual_seed(seed)
   w = {}
   shapes, c_final = conv_shapes()
   assert c_final == POOL3_DIM
   for name, (kh, kw, ci, co) in shapes:
     std = math.sqrt(2.0 / (kh * kw * ci))
-    w[name + "/kernel"] = torch.randn((kh, kw, ci, co), generator=g, dtype=F32) * std
-    w[name + "/bias"] = torch.randn((co,), generator=g, dtype=F32) * 0.05
-  w["logits/kernel"] = torch.randn((POOL3_DIM, NUM_LOGITS), generator=g, dtype=F32) * (
-      1.0 / math.sqrt(POOL3_DIM))
-  w["logits/bias"] = torch.zeros((NUM_LOGITS,), dtype=F32)
+    w[name + "/kernel"] = torch.randn((kh, kw, ci, co), generator=g, dtype=F32, device=device) * std
+    w[name + "/bias"] = torch.randn((co,), generator=g, dtype=F32, device=device) * 0.05
+  w["logits/kernel"] = torch.randn((POOL3_DIM, NUM_LOGITS), generator=g, dtype=F32,
+                                   device=device) * (1.0 / math.sqrt(POOL3_DIM))
+  w["logits/bias"] = torch.zeros((NUM_LOGITS,), dtype=F32, device=device)
   return w
 
 
@@ -133,7 +138,7 @@ class InceptionV3(object):
 
   def __init__(self, device, weights=None, seed=2015):
     self.device = torch.device(device)
-    self.load_weights(weights if weights is not None else make_weights(seed))
+    self.load_weights(weights if weights is not None else make_weights(seed, self.device))
 
   # (producer, consumer) pairs whose intermediate channel count is not a multiple of 32 (48 / 80):
   # the MFMA-tiled kernels slice K in 64-channel blocks and need Ci % 32 == 0 (cg_gconv falls back
