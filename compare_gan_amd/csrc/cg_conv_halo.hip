@@ -797,6 +797,312 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// Zero-insertion ("unpool", resnet_ops.py:35-56) + 3x3 convolution with ALL FOUR output phases in
+// one workgroup.  hconv_kernel runs the phases as separate workgroups (blockIdx.y): phase (0,0) has
+// ONE tap, (0,1) / (1,0) two, (1,1) four, so a phase workgroup of a 128-channel layer loops over 2-8
+// K-slices and spends most of its life in set-up, first-load latency and epilogue (293-580 TFLOP/s on
+// the generator's up-convolutions, profiles/r03_dstep_launches.txt).  Here a workgroup owns an 8 x 16
+// LOW-RESOLUTION tile x 64 output channels and all four phases of it (16 x 32 output pixels): the
+// input window (9 x 17 pixels, shared by every phase) is staged once per 64-channel block, the nine
+// taps' weight slabs stream through a three-deep ring, and tap (r, s) accumulates into the phase
+// (r != 1, s != 1) it belongs to, reading the window at shift (r == 2, s == 2).
+//  * 4 waves, each 32 low-resolution pixels x 64 channels x 4 phases = 128 accumulator registers; two
+//    workgroups per CU;
+//  * window double-buffered (the next channel block lands during the nine taps of the current one),
+//    weight ring waits are counted (vmcnt 2 / 8), one barrier per tap;
+//  * a wave owns ALL 64 channels of its pixels, so every output pixel is written as full 128-byte
+//    rows (a channel-split wave would write 64-byte halves of lines that are 2 pixels apart);
+//  * FUSE == 1: batch-norm (+ReLU) prologue on the staged window and per-channel statistics of the
+//    stored output, one statistics row per workgroup tile (all phases together).
+// -------------------------------------------------------------------------------------------
+constexpr int HU_TW = 16, HU_TH = 8, HU_PITCH = HU_TW + 2;
+constexpr int HU_ROWS = (HU_TH + 1) * HU_PITCH;        // 162 window rows (pixels)
+constexpr int HU_SLOTS = 6;                            // window pieces per wave: 4 x 6 = 24 pieces
+constexpr int HU_HB = 4 * HU_SLOTS * 1024;             // one window buffer (the last 3 pieces are dummies)
+constexpr int HU_RING = 3;
+constexpr int HU_SLAB = 64 * 128;                      // 64 out-channels x 64 k, bf16
+
+template <bool RELU, int FUSE>
+__global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
+  constexpr int LDS_BYTES = 2 * HU_HB + HU_RING * HU_SLAB;
+  constexpr int TAB_OFF = LDS_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES + 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, half = lane >> 5;
+
+  const int wg = hc_xcd_remap(blockIdx.x, gridDim.x);
+  const int st = (int)fdiv((uint32_t)wg, a.dNt);
+  const int nt = wg - st * a.ntiles;
+  const int t1 = (int)fdiv((uint32_t)st, a.dTx);
+  const int tx = st - t1 * a.tiles_x;
+  const int n = (int)fdiv((uint32_t)t1, a.dTy);
+  const int ty = t1 - n * a.tiles_y;
+  const int n0 = nt * 64;
+  const int nk = 9 * a.cblocks;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bt =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.bt, 0, a.bt_bytes, 0x00020000);
+
+  // ---- staging descriptors ----
+  uint32_t hvoff[HU_SLOTS];
+  int hc8[HU_SLOTS];
+  const int iy0 = ty * HU_TH, ix0 = tx * HU_TW;
+  const bool ragged_ci = (a.Ci & 63) != 0;
+#pragma unroll
+  for (int j = 0; j < HU_SLOTS; ++j) {
+    const int row = (wave + 4 * j) * 8 + (lane >> 3);
+    const int hy = row / HU_PITCH, hx = row - hy * HU_PITCH;
+    const int c = (lane & 7) ^ ((hx >> 1) & 7);
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = row < HU_ROWS && hx <= HU_TW && iy < a.Hin && ix < a.Win;
+    hvoff[j] = ok ? (uint32_t)((((n * a.Hin + iy) * a.Win + ix) * a.Ci + c * 8) * 2) : HC_OOB;
+    hc8[j] = c * 8;
+  }
+  uint32_t bvoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    bvoff[j] = (n0 + row) < a.Co ? (uint32_t)(((n0 + row) * a.Kp + c * 8) * 2) : HC_OOB;
+  }
+  auto issue_halo = [&](int cb) {
+    const int crem = a.Ci - cb * 64;
+    unsigned char* hbuf = smem + (cb & 1) * HU_HB;
+#pragma unroll
+    for (int j = 0; j < HU_SLOTS; ++j) {
+      const uint32_t vo = (ragged_ci && hc8[j] >= crem) ? HC_OOB : hvoff[j];
+      hc_dma16(rs_in, vo, (uint32_t)(cb * 128), hbuf + (wave + 4 * j) * 1024);
+    }
+  };
+  auto issue_b = [&](int s) {   // slab of K-slice s = (channel block s / 9, tap s % 9)
+    const int cb = s / 9, tap = s - cb * 9;
+    unsigned char* bs = smem + 2 * HU_HB + (s % HU_RING) * HU_SLAB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      hc_dma16(rs_bt, bvoff[j], (uint32_t)((tap * a.Ci + cb * 64) * 2), bs + (wave * 2 + j) * 1024);
+  };
+  const bool bnp = FUSE == 1 && a.bn_mean != nullptr;
+  auto load_bn_table = [&](int cb) {
+    if (bnp && tid < 64) {
+      float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
+      const int ch = min(cb * 64 + tid, a.Ci - 1);
+      const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
+      const int64_t sidx = a.bn_stat_group > 0 ? (int64_t)(n / a.bn_stat_group) * a.Ci + ch : ch;
+      tab[tid] = a.bn_mean[sidx];
+      tab[64 + tid] = rsqrtf(a.bn_var[sidx] + a.bn_eps);
+      tab[128 + tid] = a.bn_gamma ? a.bn_gamma[pidx] : 1.f;
+      tab[192 + tid] = a.bn_beta ? a.bn_beta[pidx] : 0.f;
+    }
+  };
+  auto bn_transform = [&](int cb) {   // as hconv_kernel: in place, padding pixels stay zero
+    const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
+    const int crem = a.Ci - cb * 64;
+    unsigned char* hbuf = smem + (cb & 1) * HU_HB;
+    for (int i = tid; i < HU_ROWS * 8; i += 256) {
+      const int row = i >> 3;
+      const int hy = row / HU_PITCH, hx = row - hy * HU_PITCH;
+      if (!(hx <= HU_TW && iy0 + hy < a.Hin && ix0 + hx < a.Win)) continue;
+      const int c8 = ((i & 7) ^ ((hx >> 1) & 7)) * 8;
+      if (c8 >= crem) continue;
+      uint4* p = reinterpret_cast<uint4*>(hbuf + i * 16);
+      float v[8];
+      unpack8_bf16(*p, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (v[e] - tab[c8 + e]) * tab[64 + c8 + e];
+        t = t * tab[128 + c8 + e] + tab[192 + c8 + e];
+        v[e] = fmaxf(t, 0.f);
+      }
+      *p = pack8_bf16(v);
+    }
+  };
+
+  issue_halo(0);
+  issue_b(0);
+  if (nk > 1) issue_b(1);
+  load_bn_table(0);
+
+  // ---- fragment addressing: pixel p = wave * 32 + frow -> (y, x) of the 8 x 16 tile ----
+  const int py = (wave * 32 + frow) >> 4, px = frow & 15;
+  int aoff[2][2];   // [dy][dx] byte offset of the pixel's window row; chunk swizzle per dx
+  int aswz[2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) aoff[dy][dx] = ((py + dy) * HU_PITCH + px + dx) * 128;
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) aswz[dx] = ((px + dx) >> 1) & 7;
+  int bko[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) bko[kk] = frow * 128 + (((kk * 2 + half) ^ ((frow >> 1) & 7)) << 4);
+
+  f32x16_t acc[4][2];   // [phase][32-channel tile]
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ph][j][v] = 0.f;
+
+  int slot = 0;
+  for (int cb = 0; cb < a.cblocks; ++cb) {
+    const unsigned char* Hb = smem + (cb & 1) * HU_HB;
+    const bool next_cb = cb + 1 < a.cblocks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s = cb * 9 + tap;
+      // own pieces of slab s (and, on tap 0, of this block's window) have landed: what may still be
+      // in flight are the later slab (2 instructions) and, on tap 1, the next window (6) issued
+      // after tap 0's barrier
+      if (tap == 1 && next_cb) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (bnp && tap == 0) {
+        __syncthreads();
+        bn_transform(cb);
+        __syncthreads();
+      } else {
+        asm volatile("s_barrier" ::: "memory");
+      }
+      if (tap == 0 && next_cb) {   // the other window buffer was last read a whole block ago
+        // (the table is read by bn_transform(cb + 1), nine barriers from here; its loads go first:
+        // the compiler waits for them before the LDS stores, and vmcnt retires in order)
+        load_bn_table(cb + 1);
+        issue_halo(cb + 1);
+      }
+      if (s + 2 < nk) issue_b(s + 2);   // into the slot every wave finished before this barrier
+
+      const int tr = tap / 3, ts = tap % 3;
+      const int ph = (tr != 1 ? 2 : 0) + (ts != 1 ? 1 : 0);
+      const int dy = tr == 2 ? 1 : 0, dx = ts == 2 ? 1 : 0;
+      const unsigned char* Bs = smem + 2 * HU_HB + slot * HU_SLAB;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Hb + aoff[dy][dx] +
+                                                         (((kk * 2 + half) ^ aswz[dx]) << 4));
+        if (RELU) af = hc_relu(af);
+        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk]);
+        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk] + 32 * 128);
+        acc[ph][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, af, acc[ph][0], 0, 0, 0);
+        acc[ph][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, af, acc[ph][1], 0, 0, 0);
+      }
+      slot = slot + 1 == HU_RING ? 0 : slot + 1;
+    }
+  }
+
+  // ---- epilogue: per-wave staging (32 pixels x 64 channels fp32), 8 lanes finish one pixel's 64
+  // channels: 128-byte rows ----
+  constexpr int SP = 64 * 4 + 16;
+  static_assert(4 * 32 * SP <= LDS_BYTES, "epilogue staging does not fit");
+  unsigned char* Sw = smem + wave * (32 * SP);
+  const int g8 = lane & 7, rl = lane >> 3;
+  const int co = n0 + g8 * 8;
+  const bool co_ok = co < a.Co;
+  float bv[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = s1[e] = s2[e] = 0.f;
+  if (a.bias && co_ok) {
+    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+    bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+  }
+  __syncthreads();   // window / ring images are dead
+  const float osc = a.out_scale;
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q * 8 + 4 * half) * 4) =
+            make_float4(acc[ph][j][q * 4 + 0], acc[ph][j][q * 4 + 1], acc[ph][j][q * 4 + 2],
+                        acc[ph][j][q * 4 + 3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = rl + 8 * k;
+      const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
+      const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
+      if (!co_ok) continue;
+      const int p = wave * 32 + row;
+      const int oy = (ty * HU_TH + (p >> 4)) * 2 + (ph >> 1), ox = (tx * HU_TW + (p & 15)) * 2 + (ph & 1);
+      const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
+      float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
+                    hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
+      if (a.self_gate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+      }
+      if (a.gate_out) {
+        float gv[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!(gv[e] > 0.f)) v[e] *= a.slope_out;
+      }
+      if (a.residual) {
+        float rv[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (a.out_f32) {
+        float* op = reinterpret_cast<float*>(a.out) + o;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        const uint4 pk = pack8_bf16(v);
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pk;
+        if (FUSE == 1 && a.stats) unpack8_bf16(pk, v);   // statistics of the STORED values
+      }
+      if (FUSE == 1 && a.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += v[e];
+          s2[e] += v[e] * v[e];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (FUSE == 1 && a.stats) {   // wave-uniform
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], m, 64);
+        s2[e] += __shfl_xor(s2[e], m, 64);
+      }
+    }
+    __syncthreads();   // every wave is done with its staging rows
+    float* sreg = reinterpret_cast<float*>(smem);   // [4 waves][2][64]
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sreg[(wave * 2 + 0) * 64 + g8 * 8 + e] = s1[e];
+        sreg[(wave * 2 + 1) * 64 + g8 * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < a.Co) {
+      float t1s = 0.f, t2s = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        t1s += sreg[(w4 * 2 + 0) * 64 + tid];
+        t2s += sreg[(w4 * 2 + 1) * 64 + tid];
+      }
+      a.stats[(int64_t)st * 2 * a.Co + n0 + tid] = t1s;
+      a.stats[(int64_t)st * 2 * a.Co + a.Co + n0 + tid] = t2s;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // Weight gradient of the same convolutions (3x3, unit stride, 'SAME'): dw[tap][ci][co] =
 // sum_pixels x[pixel + tap][ci] * dy[pixel][co]  (tf.gradients of arch_ops.conv2d w.r.t. the kernel,
 // arch_ops.py:559-573).  A workgroup owns a 64-channel x 64-out-channel block of ALL 9 taps and a
@@ -1454,6 +1760,18 @@ static int hc_pick_bn(const cgConvGeom* g) {
   return wgs128 <= bn64_max ? 64 : 128;
 }
 
+// all-phase zero-insertion kernel (hup_kernel): 3x3 on a x2 zero-inserted input, 8 x 16 tiles
+// Up to CGAMD_HUP_MAX_CO (128) output channels: every 64-channel tile re-stages (and, fused,
+// re-normalises) the window, which costs more than the per-phase kernel's set-up from 4 tiles on
+// (measured, batch 64: 64^2 -> 128^2 x 64: 121 / 145 -> 71 / 86 us plain / fused; 32^2 -> 64^2 x 128:
+// 55 / 77 -> 51 / 68; 16^2 -> 32^2 x 256: 40 / 45 -> 40 / 62)
+static bool hup_geom_ok(const cgConvGeom* g) {
+  static const int enabled = hc_env("CGAMD_HUP", 1);
+  static const int max_co = hc_env("CGAMD_HUP_MAX_CO", 128);
+  return enabled && (enabled > 1 || g->Co <= max_co) && g->U == 2 && g->S == 1 && g->kh == 3 && g->kw == 3 && g->pt == 1 && g->pl == 1 &&
+         g->Ho == 2 * g->Hin && g->Wo == 2 * g->Win && (g->Hin % HU_TH) == 0 &&
+         (g->Win % HU_TW) == 0 && (g->Ci % 32) == 0 && (g->Co % 8) == 0 && g->Co >= 64;
+}
 static bool hconv_rw_geom_ok(const cgConvGeom* g);
 static void hconv_rw_launch_ex(const cgConvGeom* g, const void* in, const void* bt, void* out,
                                int out_is_f32, const float* bias, const void* gate_in,
@@ -1485,6 +1803,7 @@ bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in
 }
 
 int cg_hconv_stats_rows(const cgConvGeom* g) {
+  if (hup_geom_ok(g)) return g->N * (g->Hin / HU_TH) * (g->Win / HU_TW);   // one row per tile
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   return g->U * g->U * g->N * (Hp * Wp / 256);
 }
@@ -1513,6 +1832,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
                        fu->out_scale != 0.f ? fu->out_scale : 1.f, st);
     return;
   }
+  const bool hup = hup_geom_ok(g) && !(fu && (fu->pool_out || fu->in_up));
   HConvArgs a;
   a.bn_mean = fu ? fu->bn_mean : nullptr;
   a.bn_var = fu ? fu->bn_var : nullptr;
@@ -1555,6 +1875,24 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.tdbg = g_hconv_tdbg;
 #endif
   const bool relu = gate_in != nullptr && a.bn_mean == nullptr;   // the BN prologue includes the ReLU
+  if (hup) {
+    a.tiles_x = g->Win / HU_TW;
+    a.tiles_y = g->Hin / HU_TH;
+    a.ntiles = cdiv(g->Co, 64);
+    a.dNt = make_fastdiv(a.ntiles);
+    a.dTx = make_fastdiv(a.tiles_x);
+    a.dTy = make_fastdiv(a.tiles_y);
+    dim3 ugrid(g->N * a.tiles_y * a.tiles_x * a.ntiles);
+    CgProfScope prof(CG_PROF_HCONV_64, g, st);
+    if (a.bn_mean || a.stats) {
+      if (relu) hup_kernel<true, 1><<<ugrid, 256, 0, st>>>(a);
+      else hup_kernel<false, 1><<<ugrid, 256, 0, st>>>(a);
+    } else {
+      if (relu) hup_kernel<true, 0><<<ugrid, 256, 0, st>>>(a);
+      else hup_kernel<false, 0><<<ugrid, 256, 0, st>>>(a);
+    }
+    return;
+  }
   dim3 grid(g->N * a.tiles_y * a.tiles_x * a.ntiles, g->U * g->U);
   CgProfScope prof(bn == 128 ? CG_PROF_HCONV_128 : CG_PROF_HCONV_64, g, st);
 #define HC_LAUNCH2(BN_, TWL_, FUSE_)                                                     \

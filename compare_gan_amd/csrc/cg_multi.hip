@@ -57,8 +57,21 @@ __global__ __launch_bounds__(256) void sn_matvec_kernel(SNChunk c, int second) {
     const int k0 = z * kps, k1 = min(K, k0 + kps);
     const int co = cblk * 64 + l;
     float s = 0.f;
-    if (co < Co)
-      for (int k = k0 + wv; k < k1; k += 4) s += vec[k] * w[(int64_t)k * Co + co];
+    if (co < Co) {
+      // four independent loads in flight per lane (the loop is a chain of dependent adds otherwise)
+      int k = k0 + wv;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (; k + 12 < k1; k += 16) {
+        const float w0 = w[(int64_t)k * Co + co], w1 = w[(int64_t)(k + 4) * Co + co];
+        const float w2 = w[(int64_t)(k + 8) * Co + co], w3 = w[(int64_t)(k + 12) * Co + co];
+        s += vec[k] * w0;
+        s1 += vec[k + 4] * w1;
+        s2 += vec[k + 8] * w2;
+        s3 += vec[k + 12] * w3;
+      }
+      for (; k < k1; k += 4) s += vec[k] * w[(int64_t)k * Co + co];
+      s = (s + s1) + (s2 + s3);
+    }
     sm[wv][l] = s;
     __syncthreads();
     if (wv == 0 && co < Co) part[(int64_t)z * Co + co] = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
@@ -66,7 +79,28 @@ __global__ __launch_bounds__(256) void sn_matvec_kernel(SNChunk c, int second) {
     const int k = b * 4 + wv;
     if (k >= K) return;
     float s = 0.f;
-    for (int co = l; co < Co; co += 64) s += w[(int64_t)k * Co + co] * vec[co];
+    const float* __restrict__ wr = w + (int64_t)k * Co;
+    if ((Co & 3) == 0 && (((uintptr_t)wr | (uintptr_t)vec) & 15) == 0) {
+      // 16-byte loads, two in flight
+      float s1 = 0.f;
+      int co = l * 4;
+      for (; co + 256 < Co; co += 512) {
+        const float4 a0 = *reinterpret_cast<const float4*>(wr + co);
+        const float4 a1 = *reinterpret_cast<const float4*>(wr + co + 256);
+        const float4 v0 = *reinterpret_cast<const float4*>(vec + co);
+        const float4 v1 = *reinterpret_cast<const float4*>(vec + co + 256);
+        s += (a0.x * v0.x + a0.y * v0.y) + (a0.z * v0.z + a0.w * v0.w);
+        s1 += (a1.x * v1.x + a1.y * v1.y) + (a1.z * v1.z + a1.w * v1.w);
+      }
+      for (; co < Co; co += 256) {
+        const float4 a0 = *reinterpret_cast<const float4*>(wr + co);
+        const float4 v0 = *reinterpret_cast<const float4*>(vec + co);
+        s += (a0.x * v0.x + a0.y * v0.y) + (a0.z * v0.z + a0.w * v0.w);
+      }
+      s += s1;
+    } else {
+      for (int co = l; co < Co; co += 64) s += wr[co] * vec[co];
+    }
     s = wave_sum(s);
     if (l == 0) part[(int64_t)c.splits[it] * Co + k] = s;   // row-dot area follows the partials
   }

@@ -96,6 +96,10 @@ CONV_CASES = [
     # 64 -> 64 channels with register-resident weights (hconv_rw_kernel; "hconv_all" variant)
     ("hc_rw", 3, 32, 64, 64, 64, 3, 1, 1),
     ("hc_c160_up", 1, 16, 16, 160, 96, 3, 1, 2),
+    # all-phase zero-insertion kernel (hup_kernel, "hconv_all" variant; "no_hup" keeps the per-phase
+    # form covered): non-square map, 3 channel blocks with a ragged last one, partial channel tile
+    ("hup_rect", 2, 8, 32, 96, 72, 3, 1, 2),
+    ("hup_3blocks", 1, 16, 16, 160, 128, 3, 1, 2),
     # window-staged RGB-input kernels (cg_conv_halo.hip: wstem_*): 8x32 and 16x16 tiles, 64 / 96 /
     # 128 output channels
     ("wstem_32", 3, 32, 32, 3, 64, 3, 1, 1),
@@ -454,6 +458,7 @@ def test_gconv_gates_residual(K, dev, slope, size):
     ("cbn_up", 2, 16, 16, 128, 64, 3, 2, True, False),
     ("cbn_1x1", 2, 32, 32, 64, 128, 1, 1, True, True),
     ("cbn_c96", 2, 16, 16, 96, 64, 3, 1, True, False),
+    ("bn_up_c160_res", 1, 16, 32, 160, 96, 3, 2, False, True),
 ], ids=lambda c: c[0])
 def test_gconv_fused_batch_norm(K, dev, case):
     """cg_gconv_fused: relu(batch_norm(x)) applied in LDS in front of the convolution
@@ -1068,7 +1073,10 @@ CONV_VARIANT_ENVS = [
     ("halo_forward", {"CGAMD_HALO": "1"}),             # experimental halo-staged forward kernel
     ("one_tap_wgrad", {"CGAMD_NO_HALO_WGRAD": "1"}),   # one-tap-per-workgroup weight gradient
     # halo-staged forward / weight-gradient kernels wherever they apply
-    ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1", "CGAMD_HCONV_RW_MIN": "1"}),
+    ("hconv_all", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1", "CGAMD_HCONV_RW_MIN": "1",
+                   "CGAMD_HUP": "2"}),
+    ("no_hup", {"CGAMD_HCONV_MIN": "1", "CGAMD_HWGRAD_MIN": "1", "CGAMD_HCONV_RW_MIN": "1",
+                "CGAMD_HUP": "0"}),
     ("no_hconv", {"CGAMD_HCONV": "0", "CGAMD_HWGRAD": "0", "CGAMD_WSTEM": "0", "CGAMD_HCONV_RW": "0"}),
     # small-map kernels (cg_conv_small.hip) wherever their geometry fits / nowhere
     ("small_all", {"CGAMD_SCONV": "2", "CGAMD_SWGRAD": "2"}),
