@@ -1404,13 +1404,13 @@ __device__ __forceinline__ void ws_load_window(const WStemArgs& a, int n, int ty
 }
 
 // forward: 4 waves, each 64 pixels x all CT*32 output channels of a 256-pixel tile
-template <int CT, int TWL>
+template <int CT, int TWL, bool POOL>
 __global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
   constexpr int TW = 1 << TWL, TH = 256 >> TWL;
   constexpr int CO = CT * 32;
   constexpr int SP = CO * 4 + 16;   // epilogue staging row pitch (bytes)
   constexpr int G8 = CO / 8;        // 8-channel groups per pixel
-  __shared__ __attribute__((aligned(16))) bf16_t win[WS_WIN_MAX + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t win2[2][WS_WIN_MAX + 8];
   __shared__ __attribute__((aligned(16))) unsigned char stg[4 * 32 * SP];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1439,16 +1439,50 @@ __global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[g8 * 8 + e] : 0.f;
 
+  // The window of the NEXT tile is loaded into registers right after the barrier that publishes
+  // the current one -- before this tile's output stores are issued.  vmcnt retires in order, so a
+  // window load issued behind the stores (round 2: load, barrier, compute, store, loop) made every
+  // tile wait for the previous tile's 32 KiB of stores to reach memory: 15 us per tile and
+  // workgroup, 2.1 TB/s of a 6.9 TB/s write path.  Two window buffers: one barrier per tile.
+  constexpr int WE = (TH + 2) * WC, WL = (WE + 255) / 256;
+  const int rowlen = a.W * WS_CI;
+  bf16_t wreg[WL];
+  uint32_t wok = 0;   // bit k: element k of this thread lies inside the image
+  auto window_load = [&](int t) {
+    const int q = (int)fdiv((uint32_t)t, a.dTx);
+    const int tx = t - q * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)q, a.dTy);
+    const int ty = q - n * a.tiles_y;
+    wok = 0;
+    // unconditional loads from clamped addresses (a guarded load becomes a branch with a wait on
+    // the value right behind it: four serial round trips, each draining the previous tile's stores)
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const int e = tid + 256 * k;
+      const int wy = e / WC, wc = e - wy * WC;
+      const int iy = ty * TH - 1 + wy, ic = (tx * TW - 1) * WS_CI + wc;
+      const bool ok = e < WE && (unsigned)iy < (unsigned)a.H && (unsigned)ic < (unsigned)rowlen;
+      wok |= ok ? (1u << k) : 0u;
+      wreg[k] = a.in[ok ? ((int64_t)n * a.H + iy) * rowlen + ic : 0];
+    }
+  };
   const int t0 = blockIdx.x * a.tiles_per_wg;
   const int t1e = min(a.ntiles, t0 + a.tiles_per_wg);
+  if (t0 < t1e) window_load(t0);
   for (int t = t0; t < t1e; ++t) {
     const int q = (int)fdiv((uint32_t)t, a.dTx);
     const int tx = t - q * a.tiles_x;
     const int n = (int)fdiv((uint32_t)q, a.dTy);
     const int ty = q - n * a.tiles_y;
-    __syncthreads();   // the previous tile's window reads are done
-    ws_load_window<TWL>(a, n, ty, tx, win, tid, 256);
-    __syncthreads();
+    bf16_t* win = win2[(t - t0) & 1];
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      bf16_t v = (wok >> k) & 1u ? wreg[k] : (bf16_t)0;
+      if (a.relu_in && (v & 0x8000)) v = 0;
+      if (tid + 256 * k < WE) win[tid + 256 * k] = v;
+    }
+    __syncthreads();   // window published; every wave is past its reads of the OTHER buffer's last use
+    if (t + 1 < t1e) window_load(t + 1);
 
     f32x16_t acc[2][CT];
 #pragma unroll
@@ -1474,77 +1508,65 @@ __global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
     }
     // epilogue: per-wave staging (see hconv_kernel), 32 pixels per pass
     unsigned char* Sw = stg + wave * (32 * SP);
-    if constexpr (64 % G8 == 0) {
-      if (a.pool) {
-        // pooled form (see hconv_kernel): x pairs in lanes G8 apart, y pairs in the other pass (8x32
-        // tiles) or NK/2 sweeps on (16x16 tiles); lanes with an even row finish the pixels
-        constexpr int RPI = 64 / G8, NK = 32 / RPI;
-        const int rl = lane / G8;
-        float keep[NK][8];
+    if constexpr (POOL) {
+      // pooled form (as hconv_kernel's): the wave's 64 pixels are two tile rows (8x32 tiles: rows
+      // wave*2 + i -> vertical neighbours are acc[0] / acc[1] of the SAME lane, summed in registers,
+      // one staging pass) or four half rows (16x16 tiles: staged rows r and r + 16 of a pass are
+      // vertical neighbours); every lane then finishes pooled pixels from 2 (4) staged rows
+      constexpr int NPASS = TWL == 5 ? 1 : 2;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NPASS; ++i) {
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-              *reinterpret_cast<float4*>(Sw + frow * SP + (ct * 32 + qq * 8 + 4 * half) * 4) =
-                  make_float4(acc[i][ct][qq * 4 + 0], acc[i][ct][qq * 4 + 1],
-                              acc[i][ct][qq * 4 + 2], acc[i][ct][qq * 4 + 3]);
-          __builtin_amdgcn_wave_barrier();
-          float vv[NK][8];
-#pragma unroll
-          for (int k = 0; k < NK; ++k) {
-            const int row = rl + RPI * k;
-            const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
-            const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
-            const float t8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float tq = t8[e] + bv[e];
-              vv[k][e] = tq + __shfl_xor(tq, G8, 64);
+          for (int qq = 0; qq < 4; ++qq) {
+            float4 t4 = make_float4(acc[i][ct][qq * 4 + 0], acc[i][ct][qq * 4 + 1],
+                                    acc[i][ct][qq * 4 + 2], acc[i][ct][qq * 4 + 3]);
+            if (TWL == 5) {
+              t4.x += acc[1][ct][qq * 4 + 0]; t4.y += acc[1][ct][qq * 4 + 1];
+              t4.z += acc[1][ct][qq * 4 + 2]; t4.w += acc[1][ct][qq * 4 + 3];
             }
+            *reinterpret_cast<float4*>(Sw + frow * SP + (ct * 32 + qq * 8 + 4 * half) * 4) = t4;
           }
-          __builtin_amdgcn_wave_barrier();
-          constexpr int NST = TWL == 4 ? NK / 2 : NK;
+        __builtin_amdgcn_wave_barrier();
+        constexpr int NPX = TWL == 5 ? 16 : 8;   // pooled pixels per pass
+#pragma unroll
+        for (int it = lane; it < NPX * G8; it += 64) {
+          const int x2 = it / G8, gg = it - x2 * G8;
+          const unsigned char* r0 = Sw + (2 * x2) * SP + gg * 32;
+          float v[8];
+          {
+            const float4 a0 = *reinterpret_cast<const float4*>(r0);
+            const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16);
+            const float4 b0 = *reinterpret_cast<const float4*>(r0 + SP);
+            const float4 b1 = *reinterpret_cast<const float4*>(r0 + SP + 16);
+            v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
+            v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
+          }
           if (TWL == 4) {
-#pragma unroll
-            for (int k = 0; k < NK / 2; ++k)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) vv[k][e] += vv[k + NK / 2][e];
-          } else if (i == 0) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) keep[k][e] = vv[k][e];
-            continue;
-          } else {
-#pragma unroll
-            for (int k = 0; k < NK; ++k)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) vv[k][e] += keep[k][e];
+            const float4 a0 = *reinterpret_cast<const float4*>(r0 + 16 * SP);
+            const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16 * SP + 16);
+            const float4 b0 = *reinterpret_cast<const float4*>(r0 + 17 * SP);
+            const float4 b1 = *reinterpret_cast<const float4*>(r0 + 17 * SP + 16);
+            v[0] += a0.x + b0.x; v[1] += a0.y + b0.y; v[2] += a0.z + b0.z; v[3] += a0.w + b0.w;
+            v[4] += a1.x + b1.x; v[5] += a1.y + b1.y; v[6] += a1.z + b1.z; v[7] += a1.w + b1.w;
           }
-          if (rl & 1) continue;
+          const int y2 = TWL == 4 ? wave * 2 + i : wave;
+          const int64_t o = (((int64_t)n * (a.H >> 1) + ((ty * TH) >> 1) + y2) * (a.W >> 1) +
+                             ((tx * TW) >> 1) + x2) * a.Co + gg * 8;
 #pragma unroll
-          for (int k = 0; k < NST; ++k) {
-            const int row = rl + RPI * k;
-            const int y2 = TWL == 4 ? wave * 2 + i : wave;
-            const int x2 = (TWL == 4 ? (row & 15) : row) >> 1;
-            const int64_t o = (((int64_t)n * (a.H >> 1) + ((ty * TH) >> 1) + y2) * (a.W >> 1) +
-                               ((tx * TW) >> 1) + x2) * a.Co + g8 * 8;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.25f * vv[k][e];
-            if (a.out_f32) {
-              float* op = reinterpret_cast<float*>(a.out) + o;
-              *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-              *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
-            }
+          for (int e = 0; e < 8; ++e) v[e] = 0.25f * v[e] + (a.bias ? a.bias[gg * 8 + e] : 0.f);
+          if (a.out_f32) {
+            float* op = reinterpret_cast<float*>(a.out) + o;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
           }
         }
-        continue;   // next tile
+        __builtin_amdgcn_wave_barrier();
       }
+      continue;   // next tile
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -2069,14 +2091,21 @@ void cg_wstem_conv_launch_pool(const cgConvGeom* g, const void* in, const void* 
   a.in = (const bf16_t*)in; a.bt = (const bf16_t*)bt; a.dy = nullptr; a.out = out; a.bias = bias;
   a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.self_gate = gate_out != nullptr;
   a.want_bias = 0; a.slope_out = slope_out;
-  a.tiles_per_wg = a.ntiles >= 8192 ? 4 : (a.ntiles >= 2048 ? 2 : 1);
+  // persistent workgroups (4 per CU) once there are enough tiles: the window prefetch needs a loop
+  static const int wg_target = hc_env("CGAMD_WSTEM_WGS", 1024);
+  a.tiles_per_wg = a.ntiles >= 2 * wg_target ? cdiv(a.ntiles, wg_target) : (a.ntiles >= 2048 ? 2 : 1);
   const int grid = cdiv(a.ntiles, a.tiles_per_wg);
   const int twl = hc_tile_log(g->Ho, g->Wo);
   CgProfScope prof(CG_PROF_STEM_FWD, g, st);
 #define WS_FWD(CT_)                                                             \
   do {                                                                          \
-    if (twl == 5) wstem_fwd_kernel<CT_, 5><<<grid, 256, 0, st>>>(a);            \
-    else wstem_fwd_kernel<CT_, 4><<<grid, 256, 0, st>>>(a);                     \
+    if (a.pool) {                                                               \
+      if (twl == 5) wstem_fwd_kernel<CT_, 5, true><<<grid, 256, 0, st>>>(a);    \
+      else wstem_fwd_kernel<CT_, 4, true><<<grid, 256, 0, st>>>(a);             \
+    } else {                                                                    \
+      if (twl == 5) wstem_fwd_kernel<CT_, 5, false><<<grid, 256, 0, st>>>(a);   \
+      else wstem_fwd_kernel<CT_, 4, false><<<grid, 256, 0, st>>>(a);            \
+    }                                                                           \
   } while (0)
   if (g->Co == 64) WS_FWD(2);
   else if (g->Co == 96) WS_FWD(3);
