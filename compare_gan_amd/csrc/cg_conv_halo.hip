@@ -1403,6 +1403,38 @@ __device__ __forceinline__ void ws_load_window(const WStemArgs& a, int n, int ty
   }
 }
 
+// the same window through registers: issue() starts branch-free loads from clamped addresses (a
+// guarded load compiles to a branch with a wait on the value right behind it -- serial round trips
+// that also drain whatever DMA or stores the wave has in flight), commit() writes them to LDS later
+template <int TWL>
+struct WsWindowRegs {
+  static constexpr int TW = 1 << TWL, TH = 256 >> TWL;
+  static constexpr int WC = (TW + 2) * WS_CI, WE = (TH + 2) * WC, WL = (WE + 255) / 256;
+  bf16_t v[WL];
+  uint32_t ok;
+  __device__ __forceinline__ void issue(const WStemArgs& a, int n, int ty, int tx, int tid) {
+    const int rowlen = a.W * WS_CI;
+    ok = 0;
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const int e = tid + 256 * k;
+      const int wy = e / WC, wc = e - wy * WC;
+      const int iy = ty * TH - 1 + wy, ic = (tx * TW - 1) * WS_CI + wc;
+      const bool in = e < WE && (unsigned)iy < (unsigned)a.H && (unsigned)ic < (unsigned)rowlen;
+      ok |= in ? (1u << k) : 0u;
+      v[k] = a.in[in ? ((int64_t)n * a.H + iy) * rowlen + ic : 0];
+    }
+  }
+  __device__ __forceinline__ void commit(const WStemArgs& a, bf16_t* win, int tid) const {
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      bf16_t x = (ok >> k) & 1u ? v[k] : (bf16_t)0;
+      if (a.relu_in && (x & 0x8000)) x = 0;
+      if (tid + 256 * k < WE) win[tid + 256 * k] = x;
+    }
+  }
+};
+
 // forward: 4 waves, each 64 pixels x all CT*32 output channels of a 256-pixel tile
 template <int CT, int TWL, bool POOL>
 __global__ __launch_bounds__(256) void wstem_fwd_kernel(WStemArgs a) {
@@ -1661,7 +1693,17 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
       for (int j = 0; j < 8; ++j)
         hc_dma16(ry, yrel[j], 0, ysm + buf * Y_BYTES + (wave * 8 + j) * 1024);
     }
-    ws_load_window<TWL>(a, n, ty, tx, win[buf], tid, 256);
+  };
+  // the window goes through registers: its loads leave BEFORE the dy DMA of the same tile and are
+  // written to LDS after the current tile's MFMA work (loading it straight to LDS behind the DMA made
+  // every tile wait for its successor's 32 KiB of dy before multiplying: no overlap at all)
+  WsWindowRegs<TWL> wreg;
+  auto window_issue = [&](int t) {
+    const int q = (int)fdiv((uint32_t)t, a.dTx);
+    const int tx = t - q * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)q, a.dTy);
+    const int ty = q - n * a.tiles_y;
+    wreg.issue(a, n, ty, tx, tid);
   };
 
   // A^T fragment of k-step ks: lane -> im2col element k = lane & 31, pixels ks*16 + half*8 + e
@@ -1689,13 +1731,20 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
 
   const int t0 = blockIdx.y * a.tiles_per_wg;
   const int t1e = min(a.ntiles, t0 + a.tiles_per_wg);
-  if (t0 < t1e) stage(0, t0);
+  if (t0 < t1e) {
+    window_issue(t0);
+    stage(0, t0);
+    wreg.commit(a, win[0], tid);
+  }
   hc_lds_ptr ylds = (hc_lds_ptr)ysm;
   for (int t = t0; t < t1e; ++t) {
     const int buf = (t - t0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < t1e) stage(buf ^ 1, t + 1);
+    if (t + 1 < t1e) {
+      window_issue(t + 1);
+      stage(buf ^ 1, t + 1);
+    }
     const bf16_t* wb = win[buf] + abase;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -1711,6 +1760,7 @@ __global__ __launch_bounds__(256) void wstem_wgrad_kernel(WStemArgs a) {
         if (a.want_bias) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yf, accb[j], 0, 0, 0);
       }
     }
+    if (t + 1 < t1e) wreg.commit(a, win[buf ^ 1], tid);   // last read a whole tile ago
   }
   // ---- cross-wave sum through LDS, then one partial per (split): dw[k][co] rows k < K, dbias
   __syncthreads();

@@ -294,7 +294,7 @@ __device__ __forceinline__ float vconv_in(const GConvArgs& a, int64_t off) {
   return bf2f(v);
 }
 
-constexpr int THIN_PIX = 8;
+constexpr int THIN_PIX = 4;
 // block = gpb channel groups x ppb pixels (gpb * ppb <= 256): thread -> (pixel slot t / gpb, group
 // blockIdx.y * gpb + t % gpb); iteration i covers the ppb consecutive pixels blockIdx.x * THIN_PIX *
 // ppb + i * ppb ..: the stores of a block iteration are one contiguous span of pixel rows
