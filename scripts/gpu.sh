@@ -1,0 +1,104 @@
+#!/bin/bash
+# ONE launcher for every GPU visit:   gpurun --timeout T -- 'bash scripts/gpu.sh <task> [args]'
+# Everything is written under gpurun_out/ (scratch, merged back by gpurun); copy what is worth
+# keeping to profiles/.  TAG prefixes the output files (default: the task name).
+#
+#   full [TAG]                      complete `-m gpu` suite (log kept) + __graft_entry__.smoke()
+#   tests [TAG] -- PYTEST_ARGS...   pytest tests/ -m gpu with the given arguments (e.g. -k attention)
+#   bench [TAG] -- BENCH_ARGS...    python bench.py ... -> gpurun_out/TAG_bench.json (one JSON line)
+#   launches LEG [TAG]              per-launch geometry log of a leg's convolutions (CGAMD_PROF_LOG):
+#                                   LEG = resnet128_dstep | resnet128_dstep_gp | biggan128 | biggan128_bs256
+#   stats WORKLOAD [TAG]            rocprofv3 --kernel-trace --stats summary (csv):
+#                                   WORKLOAD = cifar | fid | resnet128_dstep | resnet128_dstep_gp | biggan128
+#   traffic WORKLOAD                the two --pmc passes (FETCH_SIZE, WRITE_SIZE; own runs, no other
+#                                   trace domain) + scripts/pmc_traffic.py -> gpurun_out/r03_pmc_traffic.json
+#                                   WORKLOAD = cifar | resnet128_dstep
+#   ab VAR V1,V2,... LEG [TAG]      the same build under VAR=V1, VAR=V2, ... on one box (boxes of the
+#                                   pool differ by +-15 % in clocks): bench.py --legs LEG, prints the
+#                                   headline step, the leg's step and its per-family kernel times
+#   dp [TAG]                        CGAMD_FORCE_DP=1: the data-parallel path on a one-rank RCCL group
+#                                   (bucket, all-reduce captured in the hipGraph, bucketed overlap on / off)
+#   final [TAG]                     full + bench (all legs) + stats cifar / resnet128_dstep / fid + dp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$R" || exit 1
+mkdir -p gpurun_out
+task=$1; shift
+split_args() {   # TAG [--] rest...
+  TAG=$1
+  if [ "$TAG" = "--" ] || [ -z "$TAG" ]; then TAG=$task; else shift; fi
+  [ "$1" = "--" ] && shift
+  REST=("$@")
+}
+run_full() {
+  timeout 2400 python -m pytest tests/ -q -m gpu -x --durations=15 > gpurun_out/$1_tests.txt 2>&1
+  tail -25 gpurun_out/$1_tests.txt
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3
+}
+leg_summary() {   # file.json LEG
+  python - "$1" "$2" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+out = "cifar %.3f ms/step" % d["ms_per_step"]
+leg = d.get(sys.argv[2]) if len(sys.argv) > 2 else None
+if leg and "ms" in leg:
+    out += " | %s %.3f ms | %s" % (sys.argv[2], leg["ms"], {k: round(v["ms_per_step"], 3)
+                                                          for k, v in leg.get("kernels", {}).items()})
+if d.get("fid10k"):
+    out += " | fid10k %s" % {k: d["fid10k"].get(k) for k in ("wall_s", "split_s")}
+print(out)
+PY
+}
+stats_cmd() {   # WORKLOAD -> command line profiled
+  case $1 in
+    cifar) echo "python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-fid --no-legs" ;;
+    fid) echo "python $R/bench.py --steps 2 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-roofline --no-legs" ;;
+    *) echo "python $R/scripts/run_leg_eager.py $1 3" ;;
+  esac
+}
+run_stats() {   # WORKLOAD TAG
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p_$1 &&
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$1 -o prof -- $(stats_cmd $1) \
+      > "$R/gpurun_out/$2_$1.log" 2>&1 )
+  cp "$(find /tmp/p_$1 -name '*kernel_stats.csv' | head -1)" gpurun_out/$2_$1_kernel_stats.csv
+  head -12 gpurun_out/$2_$1_kernel_stats.csv | cut -c1-150
+}
+run_dp() {
+  for ov in 0 1; do
+    CGAMD_FORCE_DP=1 CGAMD_DP_OVERLAP=$ov CGAMD_DP_BUCKET_MIN_MB=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=2956$ov \
+      RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline \
+      --no-fid --no-legs --no-roofline > gpurun_out/$1_dp_ov$ov.json 2> gpurun_out/$1_dp_ov$ov.err
+    echo "forced DP, overlap $ov: $(leg_summary gpurun_out/$1_dp_ov$ov.json)"
+  done
+}
+case $task in
+  full) split_args "$@"; run_full $TAG ;;
+  tests) split_args "$@"; timeout 2400 python -m pytest tests/ -q -m gpu "${REST[@]}" 2>&1 | tee gpurun_out/${TAG}_tests.txt | tail -15 ;;
+  bench) split_args "$@"
+    timeout 1500 python bench.py "${REST[@]}" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+    tail -c 1500 gpurun_out/${TAG}_bench.json ;;
+  launches) LEG=$1; TAG=${2:-launches}; rm -f gpurun_out/${TAG}_$LEG.txt
+    CGAMD_PROF_LOG=$R/gpurun_out/${TAG}_$LEG.txt timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline \
+      --no-fid --no-roofline --legs $LEG > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+    leg_summary gpurun_out/${TAG}_bench.json $LEG; wc -l gpurun_out/${TAG}_$LEG.txt ;;
+  stats) run_stats $1 ${2:-stats} ;;
+  traffic) W=$1
+    case $W in cifar) CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fid --no-legs --preheat-s 0" ;;
+               *) CMD="python $R/scripts/run_leg_eager.py $W 2" ;; esac
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$W /tmp/pw_$W &&
+      timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$W -o p -- $CMD > "$R/gpurun_out/traffic_pf_$W.log" 2>&1 &&
+      timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$W -o p -- $CMD > "$R/gpurun_out/traffic_pw_$W.log" 2>&1 )
+    python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r03_pmc_traffic.json $W | head -14 ;;
+  ab) VAR=$1; VALS=$2; LEG=$3; TAG=${4:-ab}
+    for v in ${VALS//,/ }; do
+      env $VAR=$v timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fid --no-roofline --legs $LEG \
+        > gpurun_out/${TAG}_${VAR}_$v.json 2> gpurun_out/${TAG}_${VAR}_$v.err
+      echo "$VAR=$v: $(leg_summary gpurun_out/${TAG}_${VAR}_$v.json $LEG)"
+    done ;;
+  dp) run_dp ${1:-dp} ;;
+  final) TAG=${1:-final}; run_full $TAG
+    timeout 1500 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+    leg_summary gpurun_out/${TAG}_bench.json resnet128_dstep
+    for w in cifar resnet128_dstep fid; do run_stats $w $TAG > /dev/null; done
+    run_dp $TAG ;;
+  *) echo "unknown task '$task' (see the header of scripts/gpu.sh)"; exit 2 ;;
+esac
