@@ -419,7 +419,7 @@ def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f3
         want_stats=_EMIT_BN_STATS[0] and not out_f32)
     if partials is not None:
       out._cg_bn_partials = (partials, spec_geom.N * spec_geom.Ho * spec_geom.Wo,   # pylint: disable=protected-access
-                             spec_geom.U * spec_geom.U)
+                             K.gconv_fused_phases(spec_geom))
     return out
   if pending_bn is not None:
     x = pending_bn.materialize()

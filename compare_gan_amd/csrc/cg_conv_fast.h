@@ -46,6 +46,7 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
                            const void* gate_out, float slope_out, const void* residual,
                            const cgConvFusion* fu, hipStream_t st);
 int cg_hconv_stats_rows(const cgConvGeom* g);
+int cg_hconv_stats_phases(const cgConvGeom* g);   // phase blocks of the statistics rows (1 or U*U)
 bool cg_hconv_geom_ok(const cgConvGeom* g);   // cg_hconv_supported without the grid-size policy
 
 bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,

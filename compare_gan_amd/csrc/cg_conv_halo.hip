@@ -1874,6 +1874,8 @@ bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in
   return wgs >= min_wgs;
 }
 
+int cg_hconv_stats_phases(const cgConvGeom* g) { return hup_geom_ok(g) ? 1 : g->U * g->U; }
+
 int cg_hconv_stats_rows(const cgConvGeom* g) {
   if (hup_geom_ok(g)) return g->N * (g->Hin / HU_TH) * (g->Win / HU_TW);   // one row per tile
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;

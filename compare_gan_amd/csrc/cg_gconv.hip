@@ -831,6 +831,11 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   return CG_OK;
 }
 
+extern "C" int cg_gconv_fused_phases(const cgConvGeom* g) {
+  if (!g || check_geom(g, "cg_gconv_fused_phases") || !cg_hconv_geom_ok(g)) return 0;
+  return cg_hconv_stats_phases(g);
+}
+
 extern "C" int cg_gconv_fused_rows(const cgConvGeom* g) {
   if (!g || check_geom(g, "cg_gconv_fused_rows")) return 0;
   // the fused kernel is the halo-staged one; small grids are covered too (min work-groups = 1 here:

@@ -135,6 +135,11 @@ def gconv_pool_supported(geom):
     return bool(lib().cg_gconv_pool_supported(ctypes.byref(geom)))
 
 
+def gconv_fused_phases(geom):
+    """Phase blocks of the statistics rows cg_gconv_fused emits for `geom` (bn_finalize's `phases`)."""
+    return int(lib().cg_gconv_fused_phases(ctypes.byref(geom)))
+
+
 def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, want_stats=False,
                 gate_in=None, gate_out=None, slope_out=0.0, pool=False, in_up=False,
                 out_scale=1.0):

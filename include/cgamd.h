@@ -145,6 +145,10 @@ typedef struct {
   int32_t bn_stat_group;
 } cgConvFusion;
 int cg_gconv_fused_rows(const cgConvGeom* geom);
+/* Layout of those rows for cg_bn_finalize: [phases][rows / phases]; U*U when the output phases of a
+ * zero-inserted input run as separate workgroups, 1 when one workgroup covers all of them (0 when
+ * the geometry is not covered). */
+int cg_gconv_fused_phases(const cgConvGeom* geom);
 int cg_gconv_fused(const cgConvGeom* geom, const void* in, const void* bt, void* out,
                    int out_is_f32, const float* bias, const void* gate_in, float slope_in,
                    const void* gate_out, float slope_out, const void* residual,

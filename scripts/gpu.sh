@@ -30,7 +30,7 @@ split_args() {   # TAG [--] rest...
   REST=("$@")
 }
 run_full() {
-  timeout 2400 python -m pytest tests/ -q -m gpu -x --durations=15 > gpurun_out/$1_tests.txt 2>&1
+  timeout 2400 python -m pytest tests/ -q -m gpu --durations=15 > gpurun_out/$1_tests.txt 2>&1
   tail -25 gpurun_out/$1_tests.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3
 }

@@ -569,7 +569,7 @@ def test_gconv_fused_statistics_groups(K, dev, case):
     out, part = K.gconv_fused(geom, xb, bt_f, bias=bias,
                               bn=(mean, var, gamma, beta, 1e-5, per_sample), want_stats=True)
     cnt = N * geom.Ho * geom.Wo
-    m_g, v_g = K.bn_finalize(part, cnt, groups=groups, phases=up * up)
+    m_g, v_g = K.bn_finalize(part, cnt, groups=groups, phases=K.gconv_fused_phases(geom))
     for i in range(groups):
         sl = slice(i * per, (i + 1) * per)
         gm = gamma[sl].contiguous() if per_sample else gamma
