@@ -2304,8 +2304,14 @@ void cg_fast_wgrad_plan(const cgConvGeom* g, int* splits, int* rows_per_split) {
   // reduce): only split as far as filling the chip needs, and never below 8 row slices per split
   int s = cdiv(384, tiles);
   const int max_by_rows = Mp / 512 > 0 ? Mp / 512 : 1;
+  // ... unless the weight is tiny (1x1 projections of the attention block, 96 x 32: 12 KiB per
+  // partial): the launch is a pure reduction over half a million pixels then, and 2 tiles x 64
+  // splits left half the chip idle at 0.9 TB/s -- up to 256 splits while the partials stay < 8 MiB
+  const int64_t kc = (int64_t)g->kh * g->kw * g->Ci * g->Co;
+  const int cap = kc * 4 * 256 <= (8ll << 20) ? 256 : 64;
+  if (cap > 64) s = cdiv(512, tiles);
   if (s > max_by_rows) s = max_by_rows;
-  if (s > 64) s = 64;
+  if (s > cap) s = cap;
   if (s < 1) s = 1;
   int rps = cdiv(Mp, s);
   rps = (rps + 63) / 64 * 64;

@@ -15,6 +15,8 @@ FAMILIES = [
     (r"halo_conv_kernel", "halo_conv_kernel<*>"),
     (r"hconv_kernel<128", "hconv_kernel<128, *>"),
     (r"hconv(_rw)?_kernel", "hconv_kernel<64, *>"),
+    (r"hup_kernel", "hconv_kernel<64, *>"),            # bracketed under the 64-channel-tile family
+    (r"(thin_conv|small_linear)_kernel", "gconv_kernel<...>"),
     (r"hwgrad_kernel", "hwgrad_kernel<*>"),
     (r"sconv_kernel", "sconv_kernel<*>"),
     (r"swgrad_kernel", "swgrad_kernel<*>"),

@@ -342,6 +342,10 @@ def test_conv_pool_fused_full_size(K, dev, case):
     rb = torch.randn((N, H // 2, W // 2, Co), generator=g, device=dev).to(BF16)
     dyb = torch.randn((N, H // 2, W // 2, Co), generator=g, device=dev).to(BF16)
     geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+    import os
+    if not K.gconv_pool_supported(geom) and "0" in (os.environ.get("CGAMD_HCONV"),
+                                                    os.environ.get("CGAMD_WSTEM")):
+        pytest.skip("the kernels that carry the fused pooling are switched off in this variant")
     assert K.gconv_pool_supported(geom)
     # reference
     xr = xb.double().requires_grad_(True)
