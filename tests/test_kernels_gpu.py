@@ -612,6 +612,10 @@ def test_conv_pool_fused(K, dev, case):
     bias = torch.randn(Co, generator=g, dtype=torch.float32)
     r64, rb = rand_bf16((N, H // 2, W // 2, Co), g)
     geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+    import os
+    if not K.gconv_pool_supported(geom) and "0" in (os.environ.get("CGAMD_HCONV"),
+                                                    os.environ.get("CGAMD_WSTEM")):
+        pytest.skip("the kernels that carry the fused pooling are switched off in this variant")
     assert K.gconv_pool_supported(geom)
     xr = x64.clone().requires_grad_(True)
     wr = w64.clone().requires_grad_(True)
