@@ -320,6 +320,31 @@ __global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = kind == 0 ? -3.4e38f : 0.f;
     int cnt = 0;
+    if (k == 3) {
+      // the 3x3 windows of the Inception stages: nine unconditional loads from clamped positions,
+      // selected afterwards (guarded loads in the tap loop are nine serial round trips)
+      uint4 raw[9];
+      bool ok[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int ih = oh * s - p + r, iw = ow * s - p + t;
+          ok[r * 3 + t] = ih >= 0 && ih < H && iw >= 0 && iw < W;
+          const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+          raw[r * 3 + t] = *reinterpret_cast<const uint4*>(
+              x + ((((int64_t)n * H + ihc) * W + iwc) * C8 + c8) * 8);
+        }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        float v[8];
+        unpack8_bf16(raw[j], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          acc[e] = kind == 0 ? (ok[j] ? fmaxf(acc[e], v[e]) : acc[e]) : acc[e] + (ok[j] ? v[e] : 0.f);
+        cnt += ok[j] ? 1 : 0;
+      }
+    } else
     for (int r = 0; r < k; ++r) {
       const int ih = oh * s - p + r;
       if (ih < 0 || ih >= H) continue;

@@ -255,20 +255,29 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
 // registers; small linear: of one row, lanes of a wave share the channel group (weight loads are
 // wave-uniform) and differ in the row.
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void vconv_store8(const GConvArgs& a, int64_t m, int co, float* val) {
-  const int64_t o = m * a.Co + co;
+__device__ __forceinline__ void vconv_bias8(const GConvArgs& a, int co, float* bv) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    if (co + e >= a.Co) continue;
-    if (a.bias) val[e] += a.bias[co + e];
-    if (a.self_gate) {
-      if (!(val[e] > 0.f)) val[e] *= a.slope_out;
-    } else if (a.gate_out) {
-      if (!(bf2f(a.gate_out[o + e]) > 0.f)) val[e] *= a.slope_out;
-    }
-    if (a.residual) val[e] += bf2f(a.residual[o + e]);
+    const float b = a.bias ? a.bias[min(co + e, a.Co - 1)] : 0.f;   // clamped, not guarded
+    bv[e] = co + e < a.Co ? b : 0.f;
   }
+}
+__device__ __forceinline__ void vconv_store8(const GConvArgs& a, int64_t m, int co, float* val,
+                                             const float* bv) {
+  const int64_t o = m * a.Co + co;
   if (co + 8 <= a.Co && (a.Co & 7) == 0) {
+    // whole group: gate / residual as one 16-byte load each, no per-element branches
+    float gv[8], rv[8];
+    if (a.gate_out) unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
+    if (a.residual) unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = val[e] + bv[e];
+      if (a.self_gate) v = v > 0.f ? v : v * a.slope_out;
+      else if (a.gate_out) v = gv[e] > 0.f ? v : v * a.slope_out;
+      if (a.residual) v += rv[e];
+      val[e] = v;
+    }
     if (a.out_f32) {
       float* op = reinterpret_cast<float*>(a.out) + o;
       *reinterpret_cast<float4*>(op) = make_float4(val[0], val[1], val[2], val[3]);
@@ -276,20 +285,29 @@ __device__ __forceinline__ void vconv_store8(const GConvArgs& a, int64_t m, int 
     } else {
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(val);
     }
-  } else {
+    return;
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (co + e >= a.Co) continue;
-      if (a.out_f32) reinterpret_cast<float*>(a.out)[o + e] = val[e];
-      else reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val[e]);
+  for (int e = 0; e < 8; ++e) {
+    if (co + e >= a.Co) continue;
+    val[e] += bv[e];
+    if (a.self_gate) {
+      if (!(val[e] > 0.f)) val[e] *= a.slope_out;
+    } else if (a.gate_out) {
+      if (!(bf2f(a.gate_out[o + e]) > 0.f)) val[e] *= a.slope_out;
     }
+    if (a.residual) val[e] += bf2f(a.residual[o + e]);
+    if (a.out_f32) reinterpret_cast<float*>(a.out)[o + e] = val[e];
+    else reinterpret_cast<bf16_t*>(a.out)[o + e] = f2bf(val[e]);
   }
 }
+// input element `off` (always a valid offset: callers clamp and select afterwards -- a guarded load
+// compiles to a branch with a wait on the value behind it, i.e. one serial round trip per element)
 __device__ __forceinline__ float vconv_in(const GConvArgs& a, int64_t off) {
   bf16_t v = a.in[off];
-  if (a.gate_in) {
+  if (a.gate_in) {   // kernel-uniform
     const float g = bf2f(a.gate_in[off]);
-    if (!(g > 0.f)) v = f2bf(bf2f(v) * a.slope_in);   // rounded like the staged operand
+    v = g > 0.f ? v : f2bf(bf2f(v) * a.slope_in);   // rounded like the staged operand
   }
   return bf2f(v);
 }
@@ -304,25 +322,26 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups,
   if (g >= groups || ps >= ppb) return;
   const int co = g * 8;
   const int64_t m0 = (int64_t)blockIdx.x * THIN_PIX * ppb + ps;
-  float w[8][8];
+  float w[8][8], bv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    if (co + e < a.Co) {
-      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp), w[e]);
-    } else {
+  for (int e = 0; e < 8; ++e) {   // clamped row, zeroed afterwards
+    unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)min(co + e, a.Co - 1) * a.Kp), w[e]);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[e][k] = 0.f;
-    }
+    for (int k = 0; k < 8; ++k) w[e][k] = co + e < a.Co ? w[e][k] : 0.f;
   }
-  // all inputs of the thread's pixels first (independent loads), then the arithmetic
+  vconv_bias8(a, co, bv);
+  // all inputs of the thread's pixels first: unconditional loads from clamped offsets, selected
+  // afterwards (the weights of the padding k are zero anyway)
   float x[THIN_PIX][8];
 #pragma unroll
-  for (int i = 0; i < THIN_PIX; ++i)
+  for (int i = 0; i < THIN_PIX; ++i) {
+    const int64_t m = min(m0 + (int64_t)i * ppb, (int64_t)a.M - 1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int64_t m = m0 + (int64_t)i * ppb;
-      x[i][k] = (k < a.Ci && m < a.M) ? vconv_in(a, m * a.Ci + k) : 0.f;
+      const float v = vconv_in(a, m * a.Ci + min(k, a.Ci - 1));
+      x[i][k] = k < a.Ci ? v : 0.f;
     }
+  }
 #pragma unroll
   for (int i = 0; i < THIN_PIX; ++i) {
     const int64_t m = m0 + (int64_t)i * ppb;
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups,
 #pragma unroll
       for (int k = 0; k < 8; ++k) val[e] += x[i][k] * w[e][k];   // Kp == 8, padding is zero
     }
-    vconv_store8(a, m, co, val);
+    vconv_store8(a, m, co, val, bv);
   }
 }
 
@@ -356,12 +375,14 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a) {
   for (int k0 = wave * 8; k0 < a.Ci; k0 += 32) {
     float x[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = (mok && k0 + k < a.Ci) ? vconv_in(a, xrow + k0 + k) : 0.f;
+    for (int k = 0; k < 8; ++k) {   // clamped offsets, selected afterwards (see vconv_in)
+      const float v = vconv_in(a, xrow + min(k0 + k, a.Ci - 1));
+      x[k] = (mok && k0 + k < a.Ci) ? v : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (co + e >= a.Co) continue;   // block-uniform
       float w[8];
-      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)(co + e) * a.Kp + k0), w);
+      unpack8_bf16(*reinterpret_cast<const uint4*>(a.bt + (int64_t)min(co + e, a.Co - 1) * a.Kp + k0), w);
 #pragma unroll
       for (int k = 0; k < 8; ++k) val[e] += x[k] * w[k];   // bt rows are zero-padded to Kp
     }
@@ -370,10 +391,12 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a) {
   for (int e = 0; e < 8; ++e) part[wave][lane][e] = val[e];
   __syncthreads();
   if (wave == 0 && mok) {
+    float bv[8];
+    vconv_bias8(a, co, bv);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       val[e] = (part[0][lane][e] + part[1][lane][e]) + (part[2][lane][e] + part[3][lane][e]);
-    vconv_store8(a, m, co, val);
+    vconv_store8(a, m, co, val, bv);
   }
 }
 
