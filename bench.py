@@ -267,6 +267,7 @@ def extra_leg(config, bindings, batch, mode, steps, warmup, dev, survey_tflop=No
 
 
 def main():
+    teardown_hung = False
     args = parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.config, args.batch_per_gpu, args.cpu_budget_s,
@@ -497,7 +498,18 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        dist.destroy_process_group()
+        # the communicator goes down on a helper thread with a deadline: a teardown that hangs (never
+        # seen on one rank; N > 1 has not met hardware yet) must not cost the measured line
+        import threading
+        torn_down = threading.Event()
+
+        def _destroy():
+            try:
+                dist.destroy_process_group()
+            finally:
+                torn_down.set()
+        threading.Thread(target=_destroy, daemon=True).start()
+        teardown_hung = not torn_down.wait(30.0)
     # RCCL prints its version banner through C stdio; flush it so that the JSON line is the LAST
     # line on stdout
     import ctypes
@@ -509,8 +521,10 @@ def main():
         sys.stdout.write(json.dumps(result) + "\n")
     sys.stdout.flush()
     sys.stderr.flush()
-    if (world > 1 or force_dp) and os.environ.get("CGAMD_BENCH_HARD_EXIT", "0") == "1":
-        # operator override only: skips the interpreter's teardown of HIP / RCCL objects
+    if (world > 1 or force_dp) and (os.environ.get("CGAMD_BENCH_HARD_EXIT", "0") == "1" or
+                                    teardown_hung):
+        # operator override, or a communicator teardown past its 30 s deadline: skip the
+        # interpreter's teardown of HIP / RCCL objects
         os._exit(0)
 
 
