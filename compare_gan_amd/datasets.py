@@ -14,7 +14,9 @@ Reference: compare_gan/datasets.py:66-648.  The reference reads TFDS TFRecords; 
   "none" + TF1 bilinear resize; "distorted" draws its box from a seeded numpy stream instead of
   tf.image.sample_distorted_bounding_box), then repeat -> shuffle buffer -> batch with
   drop_remainder (datasets.py:256-281) and the unshuffled eval split (datasets.py:283-307).
-  Record decoding (TFRecord framing, JPEG) stays outside: it is the storage format, not the path.
+  When `<path>` is a TFDS data dir instead (the reference's --tfds_data_dir: record shards under
+  <path>/<tfds name>/...), compare_gan_amd/tfrecord.py decodes the TFRecord framing, the
+  tf.train.Example messages and the PNG / JPEG images (Pillow) and feeds the same pipeline.
 """
 import os
 
@@ -146,6 +148,10 @@ class ImageDatasetV2(object):
   def _load_arrays(self, split):
     path = os.path.join(self._data_dir, self._name, split + ".npz")
     if not os.path.exists(path):
+      # a TFDS data dir (the reference's --tfds_data_dir): decode the records themselves
+      from compare_gan_amd import tfrecord
+      if tfrecord.has_split(self._data_dir, self._name, split == "train"):
+        return tfrecord.load_split(self._data_dir, self._name, split == "train")
       raise ValueError("Dataset %s: no %s (expected arrays `image` uint8 [N,h,w,c] and `label`)" % (
           self._name, path))
     with np.load(path, allow_pickle=False) as f:
