@@ -227,6 +227,39 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   auto bn_transform = [&](int cb) {
     const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
     const int crem = a.Ci - cb * 64;
+    if constexpr (BN == 64) {
+      // a thread keeps ONE 8-channel group (tid & 7) for all its rows, so the 32 coefficients come
+      // out of the LDS table once per block instead of once per chunk (32 of the ~36 LDS operations
+      // a chunk cost); the chunk of that group in row r sits at slot group ^ ((hx >> 1) & 7).
+      // Only where the registers are free: the 128-channel form (126 VGPRs) would spill.
+      const int c8 = (tid & 7) * 8;
+      if (c8 >= crem) return;   // zero-filled half of a ragged last channel block
+      float cm[8], cr[8], cg[8], cbt[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        cm[e] = tab[c8 + e];
+        cr[e] = tab[64 + c8 + e];
+        cg[e] = tab[128 + c8 + e];
+        cbt[e] = tab[192 + c8 + e];
+      }
+      for (int row = tid >> 3; row < npieces * 8; row += 64) {
+        const int hy = row / PITCH, hx = row - hy * PITCH;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (!(hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win))
+          continue;
+        uint4* p = reinterpret_cast<uint4*>(smem + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16);
+        float v[8];
+        unpack8_bf16(*p, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = (v[e] - cm[e]) * cr[e];
+          t = t * cg[e] + cbt[e];
+          v[e] = fmaxf(t, 0.f);
+        }
+        *p = pack8_bf16(v);
+      }
+      return;
+    }
     for (int i = tid; i < npieces * 64; i += 512) {
       const int row = i >> 3;
       const int hy = row / PITCH, hx = row - hy * PITCH;
@@ -901,19 +934,26 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
     const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
     const int crem = a.Ci - cb * 64;
     unsigned char* hbuf = smem + (cb & 1) * HU_HB;
-    for (int i = tid; i < HU_ROWS * 8; i += 256) {
-      const int row = i >> 3;
+    const int c8 = (tid & 7) * 8;   // one channel group per thread: coefficients in registers
+    if (c8 >= crem) return;
+    float cm[8], cr[8], cg[8], cbt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      cm[e] = tab[c8 + e];
+      cr[e] = tab[64 + c8 + e];
+      cg[e] = tab[128 + c8 + e];
+      cbt[e] = tab[192 + c8 + e];
+    }
+    for (int row = tid >> 3; row < HU_ROWS; row += 32) {
       const int hy = row / HU_PITCH, hx = row - hy * HU_PITCH;
       if (!(hx <= HU_TW && iy0 + hy < a.Hin && ix0 + hx < a.Win)) continue;
-      const int c8 = ((i & 7) ^ ((hx >> 1) & 7)) * 8;
-      if (c8 >= crem) continue;
-      uint4* p = reinterpret_cast<uint4*>(hbuf + i * 16);
+      uint4* p = reinterpret_cast<uint4*>(hbuf + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16);
       float v[8];
       unpack8_bf16(*p, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float t = (v[e] - tab[c8 + e]) * tab[64 + c8 + e];
-        t = t * tab[128 + c8 + e] + tab[192 + c8 + e];
+        float t = (v[e] - cm[e]) * cr[e];
+        t = t * cg[e] + cbt[e];
         v[e] = fmaxf(t, 0.f);
       }
       *p = pack8_bf16(v);
