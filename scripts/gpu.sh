@@ -72,7 +72,7 @@ run_dp() {
 }
 case $task in
   full) split_args "$@"; run_full $TAG ;;
-  tests) split_args "$@"; timeout 2400 python -m pytest tests/ -q -m gpu "${REST[@]}" 2>&1 | tee gpurun_out/${TAG}_tests.txt | tail -15 ;;
+  tests) split_args "$@"; timeout 2400 python -m pytest -q -m gpu "${REST[@]}" 2>&1 | tee gpurun_out/${TAG}_tests.txt | tail -15 ;;
   bench) split_args "$@"
     timeout 1500 python bench.py "${REST[@]}" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
     tail -c 1500 gpurun_out/${TAG}_bench.json ;;
