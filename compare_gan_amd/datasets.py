@@ -14,6 +14,8 @@ Reference: compare_gan/datasets.py:66-648.  The reference reads TFDS TFRecords; 
   "none" + TF1 bilinear resize; "distorted" draws its box from a seeded numpy stream instead of
   tf.image.sample_distorted_bounding_box), then repeat -> shuffle buffer -> batch with
   drop_remainder (datasets.py:256-281) and the unshuffled eval split (datasets.py:283-307).
+  The eval arrays are always `<path>/<dataset name>/test.npz` -- for ImageNet that file holds the
+  VALIDATION records (datasets.py:514), for LSUN the 1 % tail of the training shards (:413-418).
   When `<path>` is a TFDS data dir instead (the reference's --tfds_data_dir: record shards under
   <path>/<tfds name>/...), compare_gan_amd/tfrecord.py decodes the TFRecord framing, the
   tf.train.Example messages and the PNG / JPEG images (Pillow) and feeds the same pipeline.
