@@ -75,3 +75,79 @@ def test_tf_adam_restatements_agree():
         np.testing.assert_allclose(p.detach().numpy(), ref, rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(opt.m[0].numpy(), m_ref, rtol=1e-12, atol=1e-300)
         np.testing.assert_allclose(opt.v[0].numpy(), v_ref, rtol=1e-12, atol=1e-300)
+
+
+# ---- round 3: pooling / un-pooling, spectral norm, batch norm, attention, losses, EMA ------------
+def test_unpool_and_poolings_agree():
+    rng = np.random.RandomState(11)
+    for shape in ((2, 3, 5, 4), (1, 4, 4, 3), (3, 7, 2, 2)):
+        x = rng.randn(*shape)
+        xt = torch.from_numpy(x)
+        np.testing.assert_array_equal(direct.unpool(x), oops.unpool(xt).numpy())
+        np.testing.assert_allclose(direct.avg_pool2_same(x), oops.avg_pool2(xt).numpy(), rtol=0, atol=1e-15)
+        if shape[1] >= 2 and shape[2] >= 2:
+            np.testing.assert_array_equal(direct.max_pool2_valid(x), oops.max_pool2(xt).numpy())
+
+
+@pytest.mark.parametrize("shape,mode", [((3, 3, 8, 16), "left"), ((1, 1, 20, 6), "right"),
+                                         ((12, 40), "auto"), ((64, 5), "auto")])
+def test_spectral_norm_agrees(shape, mode):
+    rng = np.random.RandomState(sum(shape))
+    w = rng.randn(*shape)
+    vs = oops.VarStore(dtype=torch.float64)
+    wt = torch.from_numpy(w.copy()).requires_grad_(True)
+    # the oracle creates u from its own stream; read it back and hand the SAME vector to the loops
+    wbar_o = oops.spectral_norm(vs, wt, "layer/kernel", singular_value=mode, update=False)
+    u0 = vs.vars["layer/kernel/u_var"].detach().numpy().copy()
+    wbar_d, u_new, sigma = direct.spectral_norm(w, u0, mode)
+    np.testing.assert_allclose(wbar_o.detach().numpy(), wbar_d, rtol=1e-12, atol=1e-14)
+    # with update=True the persisted vector is the new one
+    oops.spectral_norm(vs, wt, "layer/kernel", singular_value=mode, update=True)
+    np.testing.assert_allclose(vs.vars["layer/kernel/u_var"].numpy(), u_new, rtol=1e-12, atol=1e-14)
+    # sigma is the top singular value's estimate from below, never above it
+    assert 0.0 < sigma <= np.linalg.svd(w.reshape(-1, shape[-1]), compute_uv=False)[0] * (1 + 1e-12)
+
+
+def test_batch_norm_training_mode_agrees():
+    rng = np.random.RandomState(5)
+    x = rng.randn(4, 3, 5, 6) * 2.0 + 0.7
+    vs = oops.VarStore(dtype=torch.float64)
+    cfg = oops.BNConfig()
+    out_o = oops.standardize_batch(vs, torch.from_numpy(x), True, "bn/", cfg)
+    out_d, mean, var = direct.batch_norm_train(x, eps=cfg.epsilon)
+    np.testing.assert_allclose(out_o.numpy(), out_d, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(mean, x.reshape(-1, 6).mean(0), rtol=1e-13)
+    np.testing.assert_allclose(var, x.reshape(-1, 6).var(0), rtol=1e-10)      # biased
+    gamma, beta = rng.rand(4, 6) + 0.5, rng.randn(4, 6)                       # conditional: per sample
+    got, _, _ = direct.batch_norm_train(x, gamma, beta, eps=cfg.epsilon)
+    want = out_o.numpy() * gamma[:, None, None, :] + beta[:, None, None, :]
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12)
+
+
+def test_attention_agrees():
+    rng = np.random.RandomState(9)
+    theta, phi, g = rng.randn(2, 7, 3), rng.randn(2, 5, 3), rng.randn(2, 5, 4)
+    want = torch.softmax(torch.from_numpy(theta) @ torch.from_numpy(phi).transpose(1, 2), dim=-1) @ torch.from_numpy(g)
+    np.testing.assert_allclose(direct.attention(theta, phi, g), want.numpy(), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("kind", ["non_saturating", "wasserstein", "least_squares", "hinge"])
+def test_gan_losses_agree(kind):
+    from oracle import gan as ogan
+    rng = np.random.RandomState(2)
+    r, f = rng.randn(9, 1) * 3.0, rng.randn(9, 1) * 3.0       # |logit| up to ~9: the stable form matters
+    rt, ft = torch.from_numpy(r), torch.from_numpy(f)
+    want = getattr(ogan, kind)(d_real=torch.sigmoid(rt), d_fake=torch.sigmoid(ft), d_real_logits=rt,
+                               d_fake_logits=ft)
+    got = direct.gan_losses(kind, r, f)
+    for a, b in zip(got, want):
+        assert abs(float(a) - float(b)) <= 1e-12 * max(1.0, abs(float(b))), (kind, a, b)
+
+
+def test_ema_agrees():
+    from oracle import gan as ogan
+    rng = np.random.RandomState(4)
+    s, p = rng.randn(5, 3), rng.randn(5, 3)
+    st = [torch.from_numpy(s.copy())]
+    ogan.ema_update(st, [torch.from_numpy(p)], 0.999)
+    np.testing.assert_allclose(st[0].numpy(), direct.ema(s, p, 0.999), rtol=1e-15)
