@@ -225,3 +225,39 @@ def gan_losses(kind, d_real_logits, d_fake_logits):
 def ema(shadow, value, decay):
     """tf.train.ExponentialMovingAverage.apply: shadow -= (1 - decay) * (shadow - value)."""
     return shadow - (1.0 - decay) * (shadow - value)
+
+
+def gradient_penalty_quadratic(x_hat, a, b):
+    """The WGAN-GP / DRAGAN penalty (penalty_lib.py:59-82, 33-56) for the closed-form discriminator
+    D(x) = (a . x)^2 + b . x per sample (its input gradient is 2 (a . x) a + b, no autograd needed):
+    mean over the batch of (sqrt(1e-4 + |grad|^2) - 1)^2, and d penalty / d a, d penalty / d b --
+    what the double backward of the product has to deliver -- by the chain rule written out."""
+    x_hat = np.asarray(x_hat, dtype=np.float64)
+    n = x_hat.shape[0]
+    xf = x_hat.reshape(n, -1)
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    pen, da, db = 0.0, np.zeros_like(a), np.zeros_like(b)
+    for i in range(n):
+        s = float(a.dot(xf[i]))
+        g = 2.0 * s * a + b
+        slope = math.sqrt(1e-4 + float(g.dot(g)))
+        pen += (slope - 1.0) ** 2 / n
+        dg = (2.0 * (slope - 1.0) / slope) * g / n          # d pen / d g
+        da += 2.0 * s * dg + 2.0 * float(dg.dot(a)) * xf[i]  # g = 2 (a.x) a + b
+        db += dg
+    return pen, da, db
+
+
+def interpolate(x, x_fake, alpha):
+    """penalty_lib.py:74: x + alpha (x_fake - x), alpha [B,1,1,1]."""
+    return np.asarray(x, np.float64) + np.asarray(alpha, np.float64) * (
+        np.asarray(x_fake, np.float64) - np.asarray(x, np.float64))
+
+
+def dragan_perturb(x, noise):
+    """penalty_lib.py:46-49: x + std(x) * (noise - 0.5) with the population standard deviation over
+    ALL elements of the batch (tf.nn.moments over every axis), clipped to [0, 1]; noise ~ U[0, 1)."""
+    x = np.asarray(x, dtype=np.float64)
+    std = math.sqrt(float(((x - x.mean()) ** 2).mean()))
+    return np.clip(x + std * (np.asarray(noise, np.float64) - 0.5), 0.0, 1.0)

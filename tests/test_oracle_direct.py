@@ -151,3 +151,60 @@ def test_ema_agrees():
     st = [torch.from_numpy(s.copy())]
     ogan.ema_update(st, [torch.from_numpy(p)], 0.999)
     np.testing.assert_allclose(st[0].numpy(), direct.ema(s, p, 0.999), rtol=1e-15)
+
+
+class _QuadraticD(object):
+    """D(x) = (a . x)^2 + b . x per sample, through torch autograd (the shape of a discriminator
+    call: (probabilities, logits, features))."""
+
+    def __init__(self, a, b):
+        self.a = torch.from_numpy(a.copy()).requires_grad_(True)
+        self.b = torch.from_numpy(b.copy()).requires_grad_(True)
+
+    def __call__(self, x, y, is_training):
+        xf = x.reshape(x.shape[0], -1)
+        logits = (xf @ self.a) ** 2 + xf @ self.b
+        return torch.sigmoid(logits), logits.reshape(-1, 1), None
+
+
+def test_gradient_penalties_against_the_closed_form():
+    """The oracle's WGAN-GP and DRAGAN penalties -- value AND the gradients that reach the
+    discriminator's parameters through the double backward -- against the chain rule written out by
+    hand for a discriminator whose input gradient has a closed form."""
+    rng = np.random.RandomState(8)
+    x, xf = rng.rand(5, 2, 3, 2), rng.rand(5, 2, 3, 2)
+    a, b = rng.randn(12) * 0.6, rng.randn(12) * 0.4
+    alpha = rng.rand(5, 1, 1, 1)
+    d = _QuadraticD(a, b)
+    pen = ogan.wgangp_penalty(d, torch.from_numpy(x), torch.from_numpy(xf), None, True,
+                              torch.from_numpy(alpha))
+    ga, gb = torch.autograd.grad(pen, [d.a, d.b])
+    want, da, db = direct.gradient_penalty_quadratic(direct.interpolate(x, xf, alpha), a, b)
+    assert abs(float(pen.detach()) - want) <= 1e-12 * max(1.0, want)
+    np.testing.assert_allclose(ga.numpy(), da, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gb.numpy(), db, rtol=1e-10, atol=1e-12)
+    noise = rng.rand(*x.shape)
+    d2 = _QuadraticD(a, b)
+    pen2 = ogan.dragan_penalty(d2, torch.from_numpy(x), None, True, torch.from_numpy(noise))
+    ga2, gb2 = torch.autograd.grad(pen2, [d2.a, d2.b])
+    want2, da2, db2 = direct.gradient_penalty_quadratic(direct.dragan_perturb(x, noise), a, b)
+    assert abs(float(pen2.detach()) - want2) <= 1e-12 * max(1.0, want2)
+    np.testing.assert_allclose(ga2.numpy(), da2, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gb2.numpy(), db2, rtol=1e-10, atol=1e-12)
+    # and the closed form itself against central differences in a
+    eps = 1e-6
+    for k in (0, 5, 11):
+        ap, am = a.copy(), a.copy()
+        ap[k] += eps
+        am[k] -= eps
+        xh = direct.interpolate(x, xf, alpha)
+        fd = (direct.gradient_penalty_quadratic(xh, ap, b)[0] - direct.gradient_penalty_quadratic(xh, am, b)[0]) / (2 * eps)
+        assert abs(fd - da[k]) <= 1e-6 * max(1.0, abs(da[k]))
+
+
+def test_l2_penalty_agrees():
+    rng = np.random.RandomState(1)
+    ws = [rng.randn(3, 3, 4, 5), rng.randn(7, 2), rng.randn(1, 1, 6, 6)]
+    want = float(np.mean([0.5 * (w ** 2).sum() for w in ws]))     # penalty_lib.py:85-102: mean of tf.nn.l2_loss
+    got = float(ogan.l2_penalty([torch.from_numpy(w) for w in ws]))
+    assert abs(got - want) <= 1e-13 * want
