@@ -261,3 +261,20 @@ def dragan_perturb(x, noise):
     x = np.asarray(x, dtype=np.float64)
     std = math.sqrt(float(((x - x.mean()) ** 2).mean()))
     return np.clip(x + std * (np.asarray(noise, np.float64) - 0.5), 0.0, 1.0)
+
+
+def inception_score(logits):
+    """tfgan.eval.classifier_score_from_logits (metrics/inception_score.py:39-48): with p(y|x_i) =
+    softmax(logits_i) and p(y) = mean_i p(y|x_i), exp(mean_i sum_y p(y|x_i) (log p(y|x_i) - log p(y)))
+    -- sample by sample with scalar-free Python loops over the rows."""
+    logits = np.asarray(logits, dtype=np.float64)
+    probs = []
+    for row in logits:
+        e = np.exp(row - row.max())
+        probs.append(e / e.sum())
+    marginal = sum(probs) / len(probs)
+    total = 0.0
+    for p in probs:
+        nz = p > 0.0                      # 0 * log 0 = 0
+        total += float((p[nz] * (np.log(p[nz]) - np.log(marginal[nz]))).sum())
+    return math.exp(total / len(probs))

@@ -208,3 +208,16 @@ def test_l2_penalty_agrees():
     want = float(np.mean([0.5 * (w ** 2).sum() for w in ws]))     # penalty_lib.py:85-102: mean of tf.nn.l2_loss
     got = float(ogan.l2_penalty([torch.from_numpy(w) for w in ws]))
     assert abs(got - want) <= 1e-13 * want
+
+
+def test_inception_score_agrees():
+    from oracle import fid as ofid
+    rng = np.random.RandomState(6)
+    logits = rng.randn(40, 17) * 4.0
+    assert abs(direct.inception_score(logits) - ofid.classifier_score_from_logits(logits)) <= 1e-12 * 17
+    # closed forms: identical rows -> 1; one-hot rows spread evenly over K classes -> K
+    assert abs(direct.inception_score(np.tile(logits[:1], (8, 1))) - 1.0) <= 1e-12
+    onehot = np.full((12, 4), -1e3)
+    onehot[np.arange(12), np.arange(12) % 4] = 1e3
+    assert abs(ofid.classifier_score_from_logits(onehot) - 4.0) <= 1e-9
+    assert abs(direct.inception_score(onehot) - 4.0) <= 1e-9
