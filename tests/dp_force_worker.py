@@ -18,13 +18,16 @@ sys.path.insert(0, ROOT)
 from tests import gan_util as U  # noqa: E402
 
 
-def run(dev, bindings, steps=2, bs=8, capture=True):
+def run(dev, bindings, steps=2, bs=8, capture=True, not_unrolled=False):
     gan, options, dataset = U.build_product("resnet_cifar10.gin", bs, dev, seed=3,
                                             bindings=bindings)
     init = {k: v.detach().clone() for k, v in gan.store.vars.items()}
-    nsub = options["disc_iters"] + 1
+    nsub = 1 if not_unrolled else options["disc_iters"] + 1
     it = dataset.train_batches(bs * nsub, seed=11)
-    step = gan.capture_train_step() if capture else gan.train_step
+    if not_unrolled:
+        step = gan.train_step_not_unrolled
+    else:
+        step = gan.capture_train_step() if capture else gan.train_step
     for _ in range(steps):
         images, labels = next(it)
         step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
@@ -48,7 +51,12 @@ def main():
     # autograd-thread collectives (cross-replica batch norm backward) AFTER an earlier capture in
     # the same process made the group's watchdog thread query a captured event
     # (hipErrorCapturedEvent, torch 2.10 / RCCL 2.26); launchers capture once, group up first
-    init, base, gan = run(dev, local_bn, capture=(mode in ("local", "buckets")))
+    if mode == "buckets_nu":
+        # the NOT unrolled step (one sub-batch per call, host-side cadence of the G update: the reader
+        # of the D step counter ADVICE r02 flagged) for 7 calls = one G update among them
+        init, base, gan = run(dev, local_bn, steps=7, capture=False, not_unrolled=True)
+    else:
+        init, base, gan = run(dev, local_bn, capture=(mode in ("local", "buckets")))
     stage("single replica done")
     assert gan.d_opt.flat is None          # no bucket without data parallelism
     del gan
@@ -85,6 +93,16 @@ def main():
         bad = [k for k in base if not torch.equal(base[k], eager[k])]
         assert not bad, "bucketed data parallel (eager) differs: %s" % bad[:5]
         del gan, gan2
+    if mode == "buckets_nu":
+        from compare_gan_amd.gans import modular_gan as mg
+        mg._DP_OVERLAP, mg._DP_BUCKETS, mg._DP_BUCKET_MIN_BYTES = "1", 3, 1 << 16
+        _, forced, gan = run(dev, local_bn, steps=7, capture=False, not_unrolled=True)
+        stage("one-rank data parallel, forced overlap, not-unrolled steps done")
+        assert int(gan.global_step.item()) == 1 and int(gan.global_step_disc.item()) == 7
+        assert sorted(gan.d_opt.last_bucket_order) == [0, 1, 2]
+        bad = [k for k in base if not torch.equal(base[k], forced[k])]
+        assert not bad, "not-unrolled step under forced overlap differs: %s" % bad[:5]
+        del gan
     if mode == "sync":
         # default bindings: cross-replica batch norm through SyncMoments on the one-rank group
         _, synced, gan = run(dev, ())
