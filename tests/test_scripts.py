@@ -64,3 +64,21 @@ def test_bench_reads_the_committed_traffic_summary():
         assert bench.pmc_traffic(family, "resnet128_dstep") == \
             summary["resnet128_dstep"]["families"][family]["hbm_bytes_per_launch"] > 0
     assert bench.pmc_traffic("no_such_kernel") is None
+
+
+def test_gpu_launcher_is_valid_shell_and_documents_its_tasks():
+    """scripts/gpu.sh is the one launcher of every GPU visit: it must at least parse, reject unknown
+    tasks, and every task of its case statement must be described in scripts/README.md."""
+    import re
+    import subprocess
+    sh = os.path.join(ROOT, "scripts", "gpu.sh")
+    assert subprocess.run(["bash", "-n", sh]).returncode == 0
+    r = subprocess.run(["bash", sh, "no_such_task"], capture_output=True, text=True,
+                       env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+    assert r.returncode == 2 and "unknown task" in r.stdout
+    body = open(sh).read()
+    tasks = re.findall(r"^  ([a-z]+)\) ", body, flags=re.M)
+    assert {"full", "tests", "bench", "launches", "stats", "traffic", "ab", "dp", "final"} <= set(tasks)
+    readme = open(os.path.join(ROOT, "scripts", "README.md")).read()
+    for t in tasks:
+        assert "`%s" % t in readme, t
