@@ -1917,6 +1917,7 @@ bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in
 int cg_hconv_stats_phases(const cgConvGeom* g) { return hup_geom_ok(g) ? 1 : g->U * g->U; }
 
 int cg_hconv_stats_rows(const cgConvGeom* g) {
+  if (cg_pconv_use(g)) return cg_pconv_stats_rows(g);   // one row per 16x32 tile
   if (hup_geom_ok(g)) return g->N * (g->Hin / HU_TH) * (g->Win / HU_TW);   // one row per tile
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   return g->U * g->U * g->N * (Hp * Wp / 256);
@@ -1944,6 +1945,11 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
     hconv_rw_launch_ex(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
                        fu->pool_out ? 1 : 0, fu->in_up ? 1 : 0,
                        fu->out_scale != 0.f ? fu->out_scale : 1.f, st);
+    return;
+  }
+  // persistent deep-pipelined form (cg_conv_pers.hip) wherever its 16x32 tiles fill the chip
+  if (cg_pconv_use(g) && !(fu && fu->pool_out && fu->in_up)) {
+    cg_pconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fu, st);
     return;
   }
   const bool hup = hup_geom_ok(g) && !(fu && (fu->pool_out || fu->in_up));

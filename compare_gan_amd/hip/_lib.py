@@ -78,6 +78,7 @@ SIGNATURES = {
     "cg_prof_reset": (c_int, []),
     "cg_prof_collect": (c_int, [c_int, vp, vp, vp, vp]),
     "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
+    "cg_weight_prep_elems": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
     "cg_gconv_fused_rows": (c_int, [GP]),
     "cg_gconv_fused_phases": (c_int, [GP]),

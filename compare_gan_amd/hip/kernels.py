@@ -67,18 +67,27 @@ def geom_adjoint(g):
 # ------------------------------------------------------------------------------------------------
 # convolution family
 # ------------------------------------------------------------------------------------------------
+def _prep_elems(kh, kw, Ci, Co, which):
+    """bf16 elements of a weight operand buffer (which: 0 forward, 1 backward image)."""
+    return int(lib().cg_weight_prep_elems(int(kh), int(kw), int(Ci), int(Co), int(which)))
+
+
 def weight_prep(w, scale=None, want_fwd=True, want_bwd=False):
     """w fp32 [kh,kw,Ci,Co] -> (bt_fwd [Co, Kp] bf16, bt_bwd [Ci, Kbp] bf16)."""
     _req(w, F32, "w")
     _req(scale, F32, "scale", True)
     kh, kw, Ci, Co = w.shape
     bt_f = bt_b = None
+    # the allocations may be larger than the row-major image: the fragment-ordered copy of the
+    # same weights follows it (cg_weight_prep_elems, cgamd.h); the returned view keeps it alive
     if want_fwd:
         Kp = (kh * kw * Ci + 7) // 8 * 8
-        bt_f = torch.empty((Co, Kp), dtype=BF16, device=w.device)
+        buf = torch.empty(_prep_elems(kh, kw, Ci, Co, 0), dtype=BF16, device=w.device)
+        bt_f = buf[:Co * Kp].view(Co, Kp)
     if want_bwd:
         Kbp = (kh * kw * Co + 7) // 8 * 8
-        bt_b = torch.empty((Ci, Kbp), dtype=BF16, device=w.device)
+        buf = torch.empty(_prep_elems(kh, kw, Ci, Co, 1), dtype=BF16, device=w.device)
+        bt_b = buf[:Ci * Kbp].view(Ci, Kbp)
     check(lib().cg_weight_prep(_p(w), kh, kw, Ci, Co, _p(scale), _p(bt_f), _p(bt_b), _stream()),
           "cg_weight_prep")
     return bt_f, bt_b
@@ -417,9 +426,10 @@ def weight_prep_multi(weights4d, want_fwd=True, want_bwd=False):
     for w in weights4d:
         _req(w, F32, "w")
         kh, kw, Ci, Co = w.shape
-        f_sizes.append(Co * ((kh * kw * Ci + 7) // 8 * 8) if want_fwd else 0)
-        b_sizes.append(Ci * ((kh * kw * Co + 7) // 8 * 8) if want_bwd else 0)
-    # every image starts 16-byte aligned (sizes are multiples of 8 bf16 elements)
+        f_sizes.append(_prep_elems(kh, kw, Ci, Co, 0) if want_fwd else 0)
+        b_sizes.append(_prep_elems(kh, kw, Ci, Co, 1) if want_bwd else 0)
+    # every image starts 16-byte aligned (sizes are multiples of 8 bf16 elements); an image may be
+    # followed by its fragment-ordered copy (cg_weight_prep_elems)
     fbuf = _carve(torch.empty(sum(f_sizes), dtype=BF16, device=dev), f_sizes)
     bbuf = _carve(torch.empty(sum(b_sizes), dtype=BF16, device=dev), b_sizes)
     items = (_lib.PrepItem * n)()
@@ -429,8 +439,8 @@ def weight_prep_multi(weights4d, want_fwd=True, want_bwd=False):
         it = items[i]
         it.w = w.data_ptr()
         it.T, it.Ci, it.Co = kh * kw, Ci, Co
-        f = fbuf[i].view(Co, -1) if want_fwd else None
-        b = bbuf[i].view(Ci, -1) if want_bwd else None
+        f = fbuf[i][:Co * ((kh * kw * Ci + 7) // 8 * 8)].view(Co, -1) if want_fwd else None
+        b = bbuf[i][:Ci * ((kh * kw * Co + 7) // 8 * 8)].view(Ci, -1) if want_bwd else None
         it.bt_fwd = f.data_ptr() if f is not None else None
         it.bt_bwd = b.data_ptr() if b is not None else None
         bt_f.append(f); bt_b.append(b)

@@ -90,7 +90,15 @@ typedef struct {
  *   bt_bwd   optional [Ci][kh*kw*Co] bf16  with taps flipped (r'=kh-1-r, s'=kw-1-s),
  *            k' = (r'*kw+s')*Co+co contiguous                                    -> data-gradient /
  *            conv2d_transpose form.
+ * Buffer sizes: cg_weight_prep_elems(kh, kw, Ci, Co, which) bf16 elements (which = 0: bt_fwd,
+ * 1: bt_bwd).  For 3x3 filters with channel counts that are multiples of 32 this is MORE than the
+ * row-major image: the same weights follow it in MFMA-fragment order ([rows/32][Cin/64][9 taps]
+ * [4 k-steps][64 lanes][8]: every wave load of the persistent convolution kernel is 1 KiB
+ * contiguous), and cg_gconv / cg_gconv_fused read that second image behind the `bt` they are
+ * given.  Both prep entry points write both images; a `bt` built any other way must have the
+ * size this function returns and carry the fragment image too.
  */
+size_t cg_weight_prep_elems(int kh, int kw, int Ci, int Co, int which);
 int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,
                    void* bt_fwd, void* bt_bwd, cgStream stream);
 
@@ -98,7 +106,7 @@ int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* 
  *   d(g) = g > 0 ? 1 : slope   (elementwise ReLU / leaky-ReLU derivative gates,
  *   arch_ops.py:595-597 lrelu; resnet_ops.py:165,175 tf.nn.relu); gate_in==in gives act(in).
  *   in        [N,Hin,Win,Ci] bf16
- *   bt        [Co][kh*kw*Ci] bf16 (from cg_weight_prep)
+ *   bt        [Co][kh*kw*Ci] bf16 (from cg_weight_prep: cg_weight_prep_elems elements)
  *   out       [N,Ho,Wo,Co] bf16, or fp32 when out_is_f32 != 0
  *   bias      [Co] fp32 or NULL;  gate_in like `in` (bf16) or NULL;  gate_out / residual like
  *             `out` (bf16) or NULL.  gate_out == out selects the value itself as the gate, i.e.
@@ -263,7 +271,7 @@ size_t cg_sn_backward_multi_workspace_floats(int K, int Co);
 int cg_sn_backward_multi(const cgSNBwdItem* items_host, int n, cgStream stream);
 typedef struct {
   const float* w;  /* [T, Ci, Co] fp32 (T = kh*kw) */
-  void* bt_fwd;    /* [Co][Kp] bf16 or NULL  (layouts of cg_weight_prep) */
+  void* bt_fwd;    /* [Co][Kp] bf16 or NULL  (layouts and sizes of cg_weight_prep) */
   void* bt_bwd;    /* [Ci][Kbp] bf16 or NULL */
   int32_t T, Ci, Co;
 } cgPrepItem;

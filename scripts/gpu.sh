@@ -16,6 +16,8 @@
 #   ab VAR V1,V2,... LEG [TAG]      the same build under VAR=V1, VAR=V2, ... on one box (boxes of the
 #                                   pool differ by +-15 % in clocks): bench.py --legs LEG, prints the
 #                                   headline step, the leg's step and its per-family kernel times
+#   pconv [TAG]                     persistent convolution kernel (cg_conv_pers.hip): parity under its forced
+#                                   variants + per-shape timings with the kernel off / on / in its 2x4 wave layout
 #   dp [TAG]                        CGAMD_FORCE_DP=1: the data-parallel path on a one-rank RCCL group
 #                                   (bucket, all-reduce captured in the hipGraph, bucketed overlap on / off)
 #   final [TAG]                     full + bench (all legs) + stats cifar / resnet128_dstep / fid + dp
@@ -93,6 +95,16 @@ case $task in
       env $VAR=$v timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fid --no-roofline --legs $LEG \
         > gpurun_out/${TAG}_${VAR}_$v.json 2> gpurun_out/${TAG}_${VAR}_$v.err
       echo "$VAR=$v: $(leg_summary gpurun_out/${TAG}_${VAR}_$v.json $LEG)"
+    done ;;
+  pconv) TAG=${1:-pconv}   # the persistent kernel: parity under its forced variants, then per-shape A/B
+    KSEL="(test_gconv_forward_adjoint_wgrad and (pc_ or fast_big or hc_)) or test_gconv_gates_residual or (test_conv_pool_fused and not full_size) or (test_gconv_fused_batch_norm and not full_size) or test_gconv_fused_statistics_groups"
+    CGAMD_PCONV_MIN=1 CGAMD_HCONV_MIN=1 CGAMD_HCONV_RW=0 timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "$KSEL" 2>&1 | tail -12 | tee gpurun_out/${TAG}_t_all.txt
+    CGAMD_PCONV_MIN=1 CGAMD_PCONV_GRID=3 CGAMD_HCONV_MIN=1 CGAMD_HCONV_RW=0 timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "$KSEL" 2>&1 | tail -12 | tee gpurun_out/${TAG}_t_walk.txt
+    CGAMD_PCONV_MIN=1 CGAMD_PCONV_GRID=5 CGAMD_PCONV_WM2=1 CGAMD_HCONV_MIN=1 timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "$KSEL" 2>&1 | tail -12 | tee gpurun_out/${TAG}_t_wm2.txt
+    timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "full_size" 2>&1 | tail -8 | tee gpurun_out/${TAG}_t_full.txt
+    for v in "CGAMD_PCONV=0" "CGAMD_PCONV=1" "CGAMD_PCONV_WM2=1"; do
+      echo "== $v" | tee -a gpurun_out/${TAG}_convs.txt
+      env $v BENCH_NO_WGRAD=1 timeout 600 python scripts/bench_convs.py hc 2>&1 | tee -a gpurun_out/${TAG}_convs.txt | tail -16
     done ;;
   dp) run_dp ${1:-dp} ;;
   final) TAG=${1:-final}; run_full $TAG

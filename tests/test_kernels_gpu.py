@@ -93,6 +93,11 @@ CONV_CASES = [
     ("hc_up32_c64", 1, 32, 32, 64, 64, 3, 1, 2),
     ("hc_1x1", 2, 32, 32, 128, 136, 1, 1, 1),
     ("hc_c96", 2, 32, 32, 96, 160, 3, 1, 1),
+    # persistent deep-pipelined kernel (cg_conv_pers.hip; selected for these small grids by the
+    # "pconv_*" variants below): several 16x32 tiles per image, three channel blocks, three
+    # out-channel tiles with a ragged last one
+    ("pc_64x64_c192", 1, 64, 64, 192, 128, 3, 1, 1),
+    ("pc_32x64_co320", 3, 32, 64, 64, 320, 3, 1, 1),
     # 64 -> 64 channels with register-resident weights (hconv_rw_kernel; "hconv_all" variant)
     ("hc_rw", 3, 32, 64, 64, 64, 3, 1, 1),
     ("hc_c160_up", 1, 16, 16, 160, 96, 3, 1, 2),
@@ -1089,6 +1094,15 @@ CONV_VARIANT_ENVS = [
     # small-map kernels (cg_conv_small.hip) wherever their geometry fits / nowhere
     ("small_all", {"CGAMD_SCONV": "2", "CGAMD_SWGRAD": "2"}),
     ("no_small", {"CGAMD_SCONV": "0", "CGAMD_SWGRAD": "0"}),
+    # persistent kernel wherever its 16x32 tiles fit: one item per workgroup; three workgroups that
+    # walk all the items (window / weight prefetch across items, epilogue between them); the
+    # 2 x 4 wave layout; and switched off (no fragment image behind the weights at all)
+    ("pconv_all", {"CGAMD_PCONV_MIN": "1", "CGAMD_HCONV_MIN": "1", "CGAMD_HCONV_RW": "0"}),
+    ("pconv_walk", {"CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GRID": "3", "CGAMD_HCONV_MIN": "1",
+                    "CGAMD_HCONV_RW": "0"}),
+    ("pconv_wm2", {"CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GRID": "5", "CGAMD_PCONV_WM2": "1",
+                   "CGAMD_HCONV_MIN": "1"}),
+    ("no_pconv", {"CGAMD_PCONV": "0"}),
 ]
 
 
@@ -1103,7 +1117,9 @@ def test_conv_kernel_variants(dev, variant):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
                         "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual or "
-                        "test_stem_relu_gate or (test_conv_pool_fused and not full_size)"],
+                        "test_stem_relu_gate or (test_conv_pool_fused and not full_size) or "
+                        "(test_gconv_fused_batch_norm and not full_size) or "
+                        "test_gconv_fused_statistics_groups"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
 
