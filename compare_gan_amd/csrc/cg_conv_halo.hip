@@ -1947,8 +1947,14 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
                        fu->out_scale != 0.f ? fu->out_scale : 1.f, st);
     return;
   }
-  // persistent deep-pipelined form (cg_conv_pers.hip) wherever its 16x32 tiles fill the chip
-  if (cg_pconv_use(g) && !(fu && fu->pool_out && fu->in_up)) {
+  // persistent deep-pipelined form (cg_conv_pers.hip) wherever its 16x32 tiles fill the chip.  Not
+  // with a gate tensor in the epilogue (data gradients): every persistent workgroup reaches its
+  // epilogue at the same time, and reading the gate on top of writing the output doubles a burst that
+  // is already bound by HBM (measured: 180 -> 190 us on 128 x 64^2 x 128 -> 128; CGAMD_PCONV_GATED=1)
+  static const int pc_gated = hc_env("CGAMD_PCONV_GATED", 0);
+  const bool gated = gate_out != nullptr && gate_out != out;
+  if (cg_pconv_use(g) && !(fu && fu->pool_out && fu->in_up) &&
+      (pc_gated || !gated || (fu && fu->stats_out))) {   // (statistics rows follow cg_pconv_use)
     cg_pconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fu, st);
     return;
   }

@@ -68,7 +68,30 @@ struct PConvArgs {
   int pool, in_up;
   float out_scale;
   FastDiv dNt, dTx, dTy;
+#ifdef CG_CONV_TIMING
+  unsigned long long* tdbg;   // 8 words per workgroup + 4 per wave (scripts/pconv_timeline.py)
+#endif
+  int prio;  // s_setprio level of the younger half of the waves (4..7), 0..3
+  int dbg;   // CGAMD_PCONV_DBG, measurement only (results are WRONG when set): ablation bits 1 no
+             // window DMA, 2 no weight wait, 4 no weight loads, 8 no output stores, 16 no window
+             // fragment reads, 32 no MFMA
+
 };
+#ifdef CG_CONV_TIMING
+#define PC_NOW() __builtin_amdgcn_s_memtime()
+#define PC_TDBG(slot, val)                                              \
+  do {                                                                  \
+    if (a.tdbg && tid == 0) a.tdbg[blockIdx.x * 8 + (slot)] = (val);    \
+  } while (0)
+#else
+#define PC_NOW() 0ull
+#define PC_TDBG(slot, val) do {} while (0)
+#endif
+#if defined(CG_CONV_TIMING) || defined(CG_CONV_ABLATE)
+#define PC_DBG(bit) (a.dbg & (bit))
+#else
+#define PC_DBG(bit) 0
+#endif
 
 __device__ __forceinline__ int pc_xcd_remap(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = b & 7;
@@ -136,7 +159,7 @@ struct PcBlock {
 
 // BN: out-channels per workgroup (128 / 64); WM: waves along the pixels (4: 128 x (BN/2) per wave,
 // 2: 256 x (BN/4)); FUSE: 0 plain, 1 batch-norm prologue / statistics epilogue, 2 pooled epilogue
-template <int BN, int WM, bool RELU, int FUSE>
+template <int BN, int WM, bool RELU, int FUSE, bool PIPE>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
   constexpr int WN = 8 / WM;
   constexpr int MI = PC_TH / WM;          // tile rows (= 32-pixel MFMA tiles) per wave
@@ -155,6 +178,10 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
   const int wgp = pc_xcd_remap(blockIdx.x, G);
   const uint32_t lds0 = cg_lds_addr(smem);
   const int us = a.in_up;   // 0 / 1: logical pixel (iy, ix) lives at (iy >> us, ix >> us)
+  PC_TDBG(0, PC_NOW());
+  PC_TDBG(5, __builtin_amdgcn_s_memrealtime());
+  unsigned long long t_blocks = 0, t_epi = 0, n_blocks = 0, t_wait = 0, t_bar = 0;
+  (void)t_blocks; (void)t_epi; (void)n_blocks; (void)t_wait; (void)t_bar;
 
   const cg_i32x4_t rs_b = cg_make_rsrc(a.btf, a.btf_bytes);
 
@@ -192,27 +219,67 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
     const bf16_t* o = a.in + (((int64_t)b.n * (a.H >> us) + py) * (a.W >> us) + px) * a.Ci;
     return cg_make_rsrc(o, 0x7fffffffu);
   };
-  auto halo_piece = [&](auto jc, const PcBlock& b, const cg_i32x4_t& rs, int buf) {
+  // Per piece ONE register, computed once: the byte offset of this lane's 16-byte chunk relative to
+  // the window origin (a multiple of 16, < 2^30), with the conditions that can make it padding in
+  // its spare bits -- bit 0 / 1: first / last window row, bit 2 / 3: first / last window column
+  // (outside the image when the tile touches that edge), bit 30: upper half of the 64 channels
+  // (zero-filled in a ragged last channel block) -- or PC_OOB for the rows past the window.
+  uint32_t prel[PC_SLOTS];
+#pragma unroll
+  for (int j = 0; j < PC_SLOTS; ++j) {
+    const int row = (wave + 8 * j) * 8 + (lane >> 3);
+    const int hy = row / PC_PITCH, hx = row - hy * PC_PITCH;
+    const int c8 = ((lane & 7) ^ ((hx >> 1) & 7)) * 8;
+    const uint32_t rel =
+        (uint32_t)(((((hy + us) >> us) * (a.W >> us) + ((hx + us) >> us)) * a.Ci + c8) * 2);
+    prel[j] = row < PC_HROWS ? (rel | (hy == 0 ? 1u : 0u) | (hy == PC_TH + 1 ? 2u : 0u) |
+                                (hx == 0 ? 4u : 0u) | (hx == PC_TW + 1 ? 8u : 0u) |
+                                (c8 >= 32 ? 0x40000000u : 0u))
+                             : PC_OOB;
+  }
+  // the bits of prel that mean "padding" for a block: its tile's image edges, a ragged channel block,
+  // everything when the block is past the end
+  auto pad_mask = [&](const PcBlock& b) {
+    uint32_t m = 0x80000000u | (b.ty == 0 ? 1u : 0u) | (b.ty == a.tiles_y - 1 ? 2u : 0u) | (b.tx == 0 ? 4u : 0u) |
+                 (b.tx == a.tiles_x - 1 ? 8u : 0u) | (a.Ci - b.cb * 64 < 64 ? 0x40000000u : 0u);
+    return b.valid ? m : 0xffffffffu;
+  };
+  auto halo_piece = [&](auto jc, uint32_t pmask, int cb, const cg_i32x4_t& rs, int buf) {
     constexpr int j = decltype(jc)::value;
     const int piece = wave + 8 * j;
     if (piece < PC_PIECES) {   // wave-uniform (false only for j = 9 on waves 5..7)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));   // opaque: keeps hipcc from hoisting 10 pieces' worth of per-lane
-                                     // geometry out of the item loop (it spilled them to scratch)
-      const int row = piece * 8 + (ln >> 3);
-      const int hy = row / PC_PITCH, hx = row - hy * PC_PITCH;
-      const int c8 = ((ln & 7) ^ ((hx >> 1) & 7)) * 8;
-      const int iy = b.ty * PC_TH - 1 + hy, ix = b.tx * PC_TW - 1 + hx;
-      const bool ok = b.valid && row < PC_HROWS && (unsigned)iy < (unsigned)a.H &&
-                      (unsigned)ix < (unsigned)a.W && c8 < a.Ci - b.cb * 64;
-      const uint32_t rel =
-          (uint32_t)(((((hy + us) >> us) * (a.W >> us) + ((hx + us) >> us)) * a.Ci + c8) * 2);
-      pc_dma16(rs, ok ? rel : PC_OOB, (uint32_t)(b.cb * 128), lds0 + buf * PC_HB + piece * 1024);
+      const uint32_t pr = prel[j];
+      const uint32_t vo = ((pr & pmask) != 0u || pmask == 0xffffffffu) ? PC_OOB : (pr & 0x3ffffff0u);
+      if (!PC_DBG(1)) pc_dma16(rs, vo, (uint32_t)(cb * 128), lds0 + buf * PC_HB + piece * 1024);
+    }
+  };
+  // ReLU of the input (arch_ops.py:595-597 / resnet_ops.py:165 in front of the convolution): applied
+  // ONCE to the staged window, in LDS, by the wave that staged the piece, right after its own counted
+  // wait has seen the piece land -- not on each of the 9 x 2 fragment reads that consume a chunk
+  // (that was 2 VALU instructions per MFMA in a loop whose ceiling is instruction issue).  bf16 ReLU
+  // = signed 16-bit max with 0; padding zeros stay zeros.
+  auto relu_piece = [&](auto jc, int buf) {
+    constexpr int j = decltype(jc)::value;
+    const int piece = wave + 8 * j;
+    if (piece < PC_PIECES) {
+      bf16x8_t* p = reinterpret_cast<bf16x8_t*>(smem + buf * PC_HB + piece * 1024 + lane * 16);
+      *p = pc_relu(*p);
     }
   };
 
   // ---- weight fragments of half-slice (slice s = cb * 9 + tap, k-steps 2 hh, 2 hh + 1) ----
   const uint32_t lane16 = (uint32_t)lane * 16u;
+  // load `idx` (= j * 2 + k2) of a half-slice on its own: the main loop spreads the LB loads of a
+  // half-slice over its row pairs (a burst of 4 queues up in front of the address unit)
+  auto b_issue_one = [&](pc_frag_t (&dst)[NJ][2], const PcBlock& b, int tap, auto hhc, auto idxc) {
+    constexpr int hh = decltype(hhc)::value, idx = decltype(idxc)::value;
+    constexpr int j = idx >> 1, k2 = idx & 1;
+    const int ct = b.nt * (BN / 32) + wn * NJ + j;
+    const bool ok = b.valid && ct < a.cotiles;
+    const uint32_t soff = (uint32_t)(((ok ? ct : 0) * a.nslices + b.cb * 9 + tap) * 4096);
+    const uint32_t vo = ok ? lane16 : PC_OOB;
+    if (!PC_DBG(4)) pc_bload<hh * 2048 + k2 * 1024>(dst[j][k2], vo, rs_b, soff);
+  };
   auto b_issue = [&](pc_frag_t (&dst)[NJ][2], const PcBlock& b, int tap, auto hhc) {
     constexpr int hh = decltype(hhc)::value;
 #pragma unroll
@@ -221,8 +288,10 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
       const bool ok = b.valid && ct < a.cotiles;
       const uint32_t soff = (uint32_t)(((ok ? ct : 0) * a.nslices + b.cb * 9 + tap) * 4096);
       const uint32_t vo = ok ? lane16 : PC_OOB;
-      pc_bload<hh * 2048>(dst[j][0], vo, rs_b, soff);
-      pc_bload<hh * 2048 + 1024>(dst[j][1], vo, rs_b, soff);
+      if (!PC_DBG(4)) {
+        pc_bload<hh * 2048>(dst[j][0], vo, rs_b, soff);
+        pc_bload<hh * 2048 + 1024>(dst[j][1], vo, rs_b, soff);
+      }
     }
   };
 
@@ -301,77 +370,162 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
   PcBlock nxt = next_block(cur);
   {
     const cg_i32x4_t rs0 = window_rsrc(cur);
-    pc_static_for<0, PC_SLOTS>([&](auto jc) { halo_piece(jc, cur, rs0, 0); });
+    const uint32_t pm0 = pad_mask(cur);
+    pc_static_for<0, PC_SLOTS>([&](auto jc) { halo_piece(jc, pm0, cur.cb, rs0, 0); });
     b_issue(Bq[0], cur, 0, std::integral_constant<int, 0>());
     b_issue(Bq[1], cur, 0, std::integral_constant<int, 1>());
     if (bnp) load_bn_table(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RELU) pc_static_for<0, PC_SLOTS>([&](auto jc) { relu_piece(jc, 0); });   // own pieces: landed
     __syncthreads();
     if (bnp) {
       bn_transform(cur, 0);
       __syncthreads();
     }
   }
+  PC_TDBG(1, PC_NOW());
+  // the second-dispatched half of the waves loses every issue arbitration to the older half on its
+  // SIMD (MI355X_MICROARCH.md, two waves per SIMD) and sets the pace of every block: a static
+  // priority for it
+  if (wave >= 4) {
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
+  }
   int buf = 0;
   bool fresh = true;   // the weights of half-slices 0 and 1 have landed (prologue / after an epilogue)
 
   while (cur.valid) {
     const cg_i32x4_t rs_n = window_rsrc(nxt);
+    const uint32_t pm_n = pad_mask(nxt);
+    const int cb_n = nxt.cb;
     const int rb = rowbase + buf * PC_HB;
 
     // ---- 9 taps x 2 half-slices: no barrier, no drain ----
+    const unsigned long long tb0 = PC_NOW();
+    // window fragments of k-step kk of half-slice h for tile rows i0, i0 + 1
+    auto a_read = [&](auto hc, auto k2c, auto i0c, bf16x8_t (&dst)[2]) {
+      constexpr int h = decltype(hc)::value, k2 = decltype(k2c)::value, i0 = decltype(i0c)::value;
+      constexpr int tap = h >> 1, hh = h & 1, r = tap / 3, s = tap % 3, kk = hh * 2 + k2;
+      const int ad = rb + (tsw[s] ^ (kk << 5));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (PC_DBG(16)) continue;
+        dst[e] = *reinterpret_cast<const bf16x8_t*>(smem + ad + s * 128 + (i0 + e + r) * PC_ROWSTEP);
+      }
+    };
+    bf16x8_t afp[2][2];   // PIPE: two fragment pairs in flight (read one pair ahead of the MFMAs)
+    if constexpr (PIPE)
+      a_read(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(),
+             std::integral_constant<int, 0>(), afp[0]);
     pc_static_for<0, 18>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
       constexpr int tap = h >> 1, hh = h & 1, r = tap / 3, s = tap % 3;
       constexpr int h2 = h + 2;
-      // 1. weights two half-slices ahead (of this block, or of the next one)
-      if constexpr (h2 < 18)
-        b_issue(Bq[h2 % 3], cur, h2 >> 1, std::integral_constant<int, h2 & 1>());
-      else
-        b_issue(Bq[h2 % 3], nxt, (h2 - 18) >> 1, std::integral_constant<int, h2 & 1>());
-      // 2. this half-slice's weights have landed: everything younger may stay in flight -- the two
-      // half-slices just issued and the window pieces issued behind them (one per half-slice 0..8;
-      // piece 9 is not issued by every wave and is not counted: a stricter wait for the others)
-      constexpr int allow = 2 * LB + ((h - 2 >= 0 && h - 2 <= 8) ? 1 : 0) + ((h - 1 >= 0 && h - 1 <= 8) ? 1 : 0);
-      if (!(fresh && h < 2)) {
+      // 1. weights two half-slices ahead (of this block, or of the next one): all at once here, or
+      // (PIPE) one load per row pair below
+      auto b_ahead = [&](auto idxc) {
+        if constexpr (h2 < 18)
+          b_issue_one(Bq[h2 % 3], cur, h2 >> 1, std::integral_constant<int, h2 & 1>(), idxc);
+        else
+          b_issue_one(Bq[h2 % 3], nxt, (h2 - 18) >> 1, std::integral_constant<int, h2 & 1>(), idxc);
+      };
+      if constexpr (!PIPE) pc_static_for<0, LB>(b_ahead);
+      // 2. this half-slice's weights have landed: everything younger may stay in flight.  !PIPE: the
+      // two half-slices just issued and the window pieces issued behind them (one per half-slice
+      // 0..8; piece 9 is not issued by every wave and is not counted: a stricter wait for the
+      // others).  PIPE: the last load of this half-slice left in the last row pair of half-slice
+      // h - 2; behind it came the piece and the loads of half-slice h - 1
+      constexpr int allow = PIPE ? LB + ((h - 1 >= 0 && h - 1 <= 8) ? 1 : 0)
+                                 : 2 * LB + ((h - 2 >= 0 && h - 2 <= 8) ? 1 : 0) +
+                                       ((h - 1 >= 0 && h - 1 <= 8) ? 1 : 0);
+#ifdef CG_CONV_TIMING
+      const unsigned long long tw0 = PC_NOW();
+#endif
+      if (!(fresh && h < 2) && !PC_DBG(2 | 4)) {
         if constexpr (NJ == 2)
           pc_wait<allow>(Bq[h % 3][0][0], Bq[h % 3][0][1], Bq[h % 3][1][0], Bq[h % 3][1][1]);
         else
           pc_wait<allow>(Bq[h % 3][0][0], Bq[h % 3][0][1]);
       }
+#ifdef CG_CONV_TIMING
+      t_wait += PC_NOW() - tw0;
+#endif
       // 3. one piece of the next block's window
-      if constexpr (h < PC_SLOTS) halo_piece(hc, nxt, rs_n, buf ^ 1);
+      if constexpr (h < PC_SLOTS) halo_piece(hc, pm_n, cb_n, rs_n, buf ^ 1);
+      // 3b. ReLU of the next window: every piece of this wave is older than the weights the wait
+      // above covered (issued at half-slices >= 10), so they have landed; two pieces per half-slice
+      if constexpr (RELU && h >= 12 && h < 12 + PC_SLOTS / 2) {
+        asm volatile("" ::: "memory");   // the LDS reads below stay behind the wait
+        relu_piece(std::integral_constant<int, 2 * (h - 12)>(), buf ^ 1);
+        relu_piece(std::integral_constant<int, 2 * (h - 12) + 1>(), buf ^ 1);
+      }
       // 4. two k-steps
+      if constexpr (PIPE) {
+        // pairs of tile rows: (k-step, row pair) = MI pairs per half-slice; the fragments of pair
+        // g + 1 are read before the MFMAs of pair g are issued (MI is even: pair 0 of every
+        // half-slice uses set 0)
+        constexpr int NP = MI;   // 2 k-steps x MI / 2 row pairs
+        pc_static_for<0, NP>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int k2 = g / (MI / 2), i0 = (g % (MI / 2)) * 2;
+          constexpr int gn = g + 1;
+          if constexpr (g % (NP / LB) == 0) b_ahead(std::integral_constant<int, g / (NP / LB)>());
+          if constexpr (gn < NP)
+            a_read(hc, std::integral_constant<int, gn / (MI / 2)>(),
+                   std::integral_constant<int, (gn % (MI / 2)) * 2>(), afp[gn & 1]);
+          else if constexpr (h + 1 < 18)
+            a_read(std::integral_constant<int, h + 1>(), std::integral_constant<int, 0>(),
+                   std::integral_constant<int, 0>(), afp[0]);
+          if (!PC_DBG(32)) {
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int kk = hh * 2 + k2;
-        const int ad = rb + (tsw[s] ^ (kk << 5));
-        bf16x8_t af[MI];
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          af[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad + s * 128 + (i + r) * PC_ROWSTEP);
-          if (RELU) af[i] = pc_relu(af[i]);
+              for (int j = 0; j < NJ; ++j)
+                acc[i0 + e][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8_t, Bq[h % 3][j][k2]), afp[g & 1][e], acc[i0 + e][j], 0, 0, 0);
+          }
+        });
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int kk = hh * 2 + k2;
+          const int ad = rb + (tsw[s] ^ (kk << 5));
+          bf16x8_t af[MI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8_t*>(smem + ad + s * 128 + (i + r) * PC_ROWSTEP);
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8_t, Bq[h % 3][j][k2]), af[i], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8_t, Bq[h % 3][j][k2]), af[i], acc[i][j], 0, 0, 0);
       }
     });
+#ifdef CG_CONV_TIMING
+    const unsigned long long tb1 = PC_NOW();
+    t_blocks += tb1 - tb0;
+    ++n_blocks;
+#endif
     fresh = false;
 
     // every wave is done with window `buf`, and its pieces of the next window have landed (they are
     // older than the weights it waited for in half-slices 12..17): after the barrier so have
     // everybody's
-    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (the ReLU pass's ds_writes)
+#ifdef CG_CONV_TIMING
+    t_bar += PC_NOW() - tb1;
+#endif
 
     if (cur.cb == a.cblocks - 1) {
       // ================= epilogue of the item, in the dead window buffer =================
       // the next block's first weights land before the stores below queue up behind them
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       fresh = true;
+      const unsigned long long te0 = PC_NOW();
       constexpr int WCO = BN / WN;           // channels per wave
       constexpr int SP = WCO * 4 + 16;       // staging row pitch in bytes (+16: conflict-free b128 writes)
       constexpr int G8 = WCO / 8;            // 8-channel groups per row
@@ -491,6 +645,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
+            if (PC_DBG(8)) continue;
             if (a.out_f32) {
               float* op = reinterpret_cast<float*>(a.out) + o;
               *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
@@ -550,6 +705,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
       zero_acc();
       // the staging rows are dead before any wave stages a piece of the window after next into them
       __syncthreads();
+#ifdef CG_CONV_TIMING
+      t_epi += PC_NOW() - te0;
+#endif
     }
 
     cur = nxt;
@@ -564,6 +722,17 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
   }
   // nothing of this wave may still be in flight towards LDS when the workgroup's LDS is released
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PC_TDBG(2, t_blocks);
+  PC_TDBG(3, t_epi);
+  PC_TDBG(7, n_blocks);
+  PC_TDBG(4, PC_NOW());
+  PC_TDBG(6, __builtin_amdgcn_s_memrealtime());
+#ifdef CG_CONV_TIMING
+  if (a.tdbg && lane == 0) {
+    unsigned long long* w = a.tdbg + 512 * 8 + ((size_t)blockIdx.x * 8 + wave) * 4;
+    w[0] = t_blocks; w[1] = t_wait; w[2] = t_bar; w[3] = t_epi;
+  }
+#endif
 }
 
 int pc_env(const char* name, int dflt) {
@@ -607,6 +776,10 @@ __global__ __launch_bounds__(256) void frag_prep_kernel(FragChunk c) {
 }  // namespace
 
 // ---- host side ----
+#ifdef CG_CONV_TIMING
+static unsigned long long* g_pconv_tdbg = nullptr;
+extern "C" void cg_debug_set_pconv_timing_buffer(void* p) { g_pconv_tdbg = (unsigned long long*)p; }
+#endif
 size_t cg_weight_frag_elems(int T, int Cin, int R) {
   static const int enabled = pc_env("CGAMD_PCONV", 1);
   if (!enabled || T != 9 || (Cin % 32) != 0 || (R % 8) != 0 || R < 64) return 0;
@@ -639,7 +812,7 @@ bool cg_pconv_geom_ok(const cgConvGeom* g) {
   if ((g->Hin % PC_TH) != 0 || (g->Win % PC_TW) != 0) return false;
   if ((g->Ci % 32) != 0 || (g->Co % 8) != 0 || g->Co < 64) return false;
   if (cg_weight_frag_elems(9, g->Ci, g->Co) == 0) return false;
-  if ((int64_t)(PC_TH + 2) * g->Win * g->Ci * 2 >= (1ll << 31)) return false;
+  if ((int64_t)(PC_TH + 2) * g->Win * g->Ci * 2 >= (1ll << 30)) return false;
   return true;
 }
 
@@ -696,13 +869,26 @@ void cg_pconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
   a.dTy = make_fastdiv(a.tiles_y);
   static const int grid_max = pc_env("CGAMD_PCONV_GRID", 256);
   static const int wm2 = pc_env("CGAMD_PCONV_WM2", 0);
+  static const int pipe = pc_env("CGAMD_PCONV_PIPE", 1);
+#ifdef CG_CONV_TIMING
+  a.tdbg = g_pconv_tdbg;
+#endif
+  static const int prio = pc_env("CGAMD_PCONV_PRIO", 1);
+  a.prio = prio;
+  static const int dbg = pc_env("CGAMD_PCONV_DBG", 0);
+  a.dbg = dbg;
   const int grid = a.nitems < grid_max ? a.nitems : grid_max;
   const bool relu = gate_in != nullptr && a.bn_mean == nullptr;   // the BN prologue includes the ReLU
   CgProfScope prof(bn == 128 ? CG_PROF_PCONV_128 : CG_PROF_PCONV_64, g, st);
+#define PC_LAUNCH3(BN_, WM_, FUSE_, PIPE_)                                          \
+  do {                                                                              \
+    if (relu) pconv_kernel<BN_, WM_, true, FUSE_, PIPE_><<<grid, 512, 0, st>>>(a);  \
+    else pconv_kernel<BN_, WM_, false, FUSE_, PIPE_><<<grid, 512, 0, st>>>(a);      \
+  } while (0)
 #define PC_LAUNCH2(BN_, WM_, FUSE_)                                              \
   do {                                                                           \
-    if (relu) pconv_kernel<BN_, WM_, true, FUSE_><<<grid, 512, 0, st>>>(a);      \
-    else pconv_kernel<BN_, WM_, false, FUSE_><<<grid, 512, 0, st>>>(a);          \
+    if (pipe) PC_LAUNCH3(BN_, WM_, FUSE_, true);                                 \
+    else PC_LAUNCH3(BN_, WM_, FUSE_, false);                                     \
   } while (0)
 #define PC_LAUNCH(BN_, WM_)                                                      \
   do {                                                                           \
@@ -718,4 +904,5 @@ void cg_pconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* 
   }
 #undef PC_LAUNCH
 #undef PC_LAUNCH2
+#undef PC_LAUNCH3
 }

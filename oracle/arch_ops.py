@@ -187,6 +187,8 @@ def conv2d_same_gemm(x, w, stride):
 def conv2d_transpose_same(x, w, out_hw, stride):
   """tf.nn.conv2d_transpose(x, w, output_shape, strides, 'SAME') (arch_ops.py:588-589): the exact
   adjoint of conv2d_same(y, w, stride) for y of spatial size out_hw; w is [kh, kw, Cout, Cin]."""
+  if x.is_cuda:
+    return conv2d_transpose_same_gemm(x, w, out_hw, stride)
   kh, kw = w.shape[0], w.shape[1]
   Hy, Wy = out_hw
   _, pt, _ = same_pads(Hy, kh, stride)
@@ -197,6 +199,26 @@ def conv2d_transpose_same(x, w, out_hw, stride):
   if need_h > fh or need_w > fw:
     full = F.pad(full, (0, max(need_w - fw, 0), 0, max(need_h - fh, 0)))
   return full[:, :, pt:pt + Hy, pl:pl + Wy].permute(0, 2, 3, 1)
+
+
+def conv2d_transpose_same_gemm(x, w, out_hw, stride):
+  """The same transposed convolution as one matrix product per filter tap, scattered into the
+  padded output (the adjoint of conv2d_same_gemm tap by tap): plain tensor ops, fp64 on any
+  device.  tests/test_oracle_direct.py pins it to conv2d_transpose_same."""
+  kh, kw, cout, cin = w.shape
+  n, h, wd, _ = x.shape
+  Hy, Wy = out_hw
+  ho, pt, pb = same_pads(Hy, kh, stride)
+  wo, pl, pr = same_pads(Wy, kw, stride)
+  assert (ho, wo) == (h, wd), "input is not the strided size of the requested output"
+  full = x.new_zeros((n, Hy + pt + pb, Wy + pl + pr, cout))
+  x2 = x.reshape(-1, cin)
+  for r in range(kh):
+    for s in range(kw):
+      t = (x2 @ w[r, s].t()).reshape(n, h, wd, cout)
+      v = full[:, r:r + (h - 1) * stride + 1:stride, s:s + (wd - 1) * stride + 1:stride, :]
+      v += t
+  return full[:, pt:pt + Hy, pl:pl + Wy, :]
 
 
 def unpool(x):

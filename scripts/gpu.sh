@@ -106,6 +106,25 @@ case $task in
       echo "== $v" | tee -a gpurun_out/${TAG}_convs.txt
       env $v BENCH_NO_WGRAD=1 timeout 600 python scripts/bench_convs.py hc 2>&1 | tee -a gpurun_out/${TAG}_convs.txt | tail -16
     done ;;
+  pconv_ab) TAG=${1:-pconv_ab}   # per-shape timings under each setting of the persistent kernel's switches
+    shift; for v in "$@"; do
+      echo "== $v" | tee -a gpurun_out/${TAG}.txt
+      env $v BENCH_NO_WGRAD=1 timeout 600 python scripts/bench_convs.py hc 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}.txt | tail -13
+    done ;;
+  pconv_timeline) TAG=${1:-pconv_timeline}; shift   # s_memtime phases (timing build), shapes N,H,W,Ci,Co,relu
+    for sh in "$@"; do
+      CGAMD_LIB_PATH=$R/compare_gan_amd/lib/libcgamd_timing.so timeout 300 python scripts/pconv_timeline.py $sh 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}.txt
+    done ;;
+  sq) TAG=$1; SHAPE=$2; KINDS=${3:-fwd}; shift 3   # SQ counter passes over one conv shape; extra args: VAR=V settings
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sq_$TAG && i=0 &&
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" \
+                 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+                 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH"; do
+        i=$((i+1))
+        env "$@" timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/sq_$TAG/p$i -o p -- python $R/scripts/pmc_one.py run $SHAPE $KINDS > "$R/gpurun_out/${TAG}_sq_p$i.log" 2>&1
+      done )
+    echo "# shape $SHAPE kinds $KINDS settings $*" > gpurun_out/${TAG}_sq.txt
+    python scripts/pmc_one.py agg /tmp/sq_$TAG >> gpurun_out/${TAG}_sq.txt; cat gpurun_out/${TAG}_sq.txt ;;
   dp) run_dp ${1:-dp} ;;
   final) TAG=${1:-final}; run_full $TAG
     timeout 1500 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err

@@ -48,6 +48,14 @@ def test_conv_transpose_restatements_agree(case):
     ref = direct.conv2d_transpose_same(x, wt, (h, w), stride)
     got = oops.conv2d_transpose_same(torch.from_numpy(x), torch.from_numpy(wt), (h, w), stride).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    # the per-tap GEMM form the oracle takes when it runs on a device (parity tests at the BASELINE
+    # batch sizes of dcgan_celeba64.gin / sndcgan_celebahq128.gin), and its gradient
+    xt = torch.from_numpy(x).requires_grad_(True)
+    gemm = oops.conv2d_transpose_same_gemm(xt, torch.from_numpy(wt), (h, w), stride)
+    np.testing.assert_allclose(gemm.detach().numpy(), ref, rtol=1e-12, atol=1e-12)
+    dy = rng.standard_normal(ref.shape)
+    (gx,) = torch.autograd.grad((gemm * torch.from_numpy(dy)).sum(), xt)
+    np.testing.assert_allclose(gx.numpy(), direct.conv2d_same(dy, wt, stride), rtol=1e-12, atol=1e-11)
 
 
 def test_conv_transpose_is_the_adjoint_of_conv():
