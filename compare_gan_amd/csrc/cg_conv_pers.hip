@@ -781,7 +781,11 @@ static unsigned long long* g_pconv_tdbg = nullptr;
 extern "C" void cg_debug_set_pconv_timing_buffer(void* p) { g_pconv_tdbg = (unsigned long long*)p; }
 #endif
 size_t cg_weight_frag_elems(int T, int Cin, int R) {
-  static const int enabled = pc_env("CGAMD_PCONV", 1);
+  // OFF by default (round 4): per shape the kernel is 6-12 % faster than hconv_kernel on forward
+  // launches and slower on gated data gradients, and inside the train steps the gain is eaten by the
+  // second weight image (one more prep launch per network call): resnet128 D sub-step 5.12 -> 5.26 ms,
+  // cifar step 7.05 -> 7.21 ms (profiles/r04_pconv_*.txt).  CGAMD_PCONV=1 switches it on.
+  static const int enabled = pc_env("CGAMD_PCONV", 0);
   if (!enabled || T != 9 || (Cin % 32) != 0 || (R % 8) != 0 || R < 64) return 0;
   return (size_t)cdiv(R, 32) * cdiv(Cin, 64) * 9 * 2048;
 }
@@ -819,7 +823,7 @@ bool cg_pconv_geom_ok(const cgConvGeom* g) {
 static int pc_bn(const cgConvGeom* g) { return g->Co <= 64 ? 64 : 128; }
 
 bool cg_pconv_use(const cgConvGeom* g) {
-  static const int enabled = pc_env("CGAMD_PCONV", 1);
+  static const int enabled = pc_env("CGAMD_PCONV", 0);
   static const int min_items = pc_env("CGAMD_PCONV_MIN", 224);
   if (!enabled || !cg_pconv_geom_ok(g)) return false;
   const int64_t items = (int64_t)g->N * (g->Hin / PC_TH) * (g->Win / PC_TW) * cdiv(g->Co, pc_bn(g));

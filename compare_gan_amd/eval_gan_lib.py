@@ -119,12 +119,19 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
 
   t0 = tick()
   chunk = eval_shard.row_chunk(num_test_examples, world, batch_size)
-  lo, hi = (rank * chunk, min((rank + 1) * chunk, num_test_examples)) if world > 1 else \
-           (0, num_test_examples)
-  real_dset = eval_utils.EvalDataSample(
-      eval_utils.get_real_images(dataset=dataset, num_examples=num_test_examples, device=device,
-                                 rows=(lo, hi)))
-  local_act, _ = eval_utils.inception_transform_np(real_dset.images, batch_size)
+  lo, hi = eval_shard.row_range(num_test_examples, rank, world, chunk)
+  if hi > lo:
+    real_dset = eval_utils.EvalDataSample(
+        eval_utils.get_real_images(dataset=dataset, num_examples=num_test_examples, device=device,
+                                   rows=(lo, hi)))
+    local_act, _ = eval_utils.inception_transform_np(real_dset.images, batch_size)
+  else:
+    # the chunks are whole Inception batches, so a small real set leaves the last ranks without rows
+    # (N = 257, 4 ranks: chunk 128, rank 3 empty): they contribute an empty block to the gather
+    # instead of running the extractor on nothing while the others wait in the collective
+    real_dset = eval_utils.EvalDataSample(None)
+    ref = fake_dsets[0].activations
+    local_act = ref.new_zeros((0,) + tuple(ref.shape[1:]))
   if world > 1:
     real_dset.discard_images()    # only this rank's rows: nothing downstream may mistake them for the set
   real_dset.activations = eval_shard.gather_rows(local_act, num_test_examples, rank, world, chunk)

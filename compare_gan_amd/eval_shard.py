@@ -70,6 +70,14 @@ def gather_rows(local_rows, total_rows, rank, world, chunk, group=None):
   return torch.cat(parts, dim=0)[:total_rows]
 
 
+def row_range(total_rows, rank, world, chunk):
+  """[lo, hi) of the rows rank `rank` holds; lo == hi when the chunks run out before the ranks do."""
+  if world == 1:
+    return 0, total_rows
+  lo = min(rank * chunk, total_rows)
+  return lo, min(lo + chunk, total_rows)
+
+
 def row_chunk(total_rows, world, multiple):
   """Rows per rank: ceil(total / world) rounded up to a multiple of the Inception batch."""
   per = int(math.ceil(total_rows / world))

@@ -67,8 +67,9 @@ def _evaluate(rank, world, num_batches, accu_batches, nan_at=None):
     g = torch.Generator().manual_seed(7)
     real = torch.rand((total, H, H, 3), generator=g) * 255.0
     chunk = eval_shard.row_chunk(total, world, B)
-    lo, hi = (rank * chunk, min((rank + 1) * chunk, total)) if world > 1 else (0, total)
-    real_act = eval_shard.gather_rows(_transform(real[lo:hi])[0], total, rank, world, chunk)
+    lo, hi = eval_shard.row_range(total, rank, world, chunk)
+    local = _transform(real[lo:hi])[0] if hi > lo else act.new_zeros((0, F))   # (evaluate_gan's rule)
+    real_act = eval_shard.gather_rows(local, total, rank, world, chunk)
     return accus, images, act, logits, nan_found, real_act
 
 
@@ -111,6 +112,24 @@ def test_two_rank_sharded_evaluation_equals_single_rank(tmp_path, num_batches):
         n = num_batches * B - 3
         assert abs(_fid(act[:n], real_act) - _fid(want[2][:n], want[5])) <= 1e-9
     assert act.shape == (num_batches * B, F) and real_act.shape == (num_batches * B - 3, F)
+
+
+def test_real_set_smaller_than_the_rank_chunks(tmp_path):
+    """the real set is split into whole Inception batches per rank, so a small set leaves
+    the LAST ranks without rows (17 rows, batch 8, 4 ranks: chunk 8 -> ranks hold 8 / 8 / 1 / 0 rows).
+    The empty rank contributes an empty block to the all-gather instead of hanging the others."""
+    world = 4
+    assert eval_shard.row_range(17, 3, 4, eval_shard.row_chunk(17, 4, 8)) == (17, 17)
+    assert eval_shard.row_range(17, 2, 4, 8) == (16, 17)
+    assert eval_shard.row_range(257, 3, 4, eval_shard.row_chunk(257, 4, 64)) == (257, 257)
+    # 5 batches on 4 ranks: 37 real rows, chunk 16 -> ranks hold 16 / 16 / 5 / 0 rows
+    assert eval_shard.row_range(37, 3, 4, eval_shard.row_chunk(37, 4, B)) == (37, 37)
+    mp.spawn(_worker, args=(world, _free_port(), 5, 2, None, str(tmp_path)), nprocs=world, join=True)
+    want = _evaluate(0, 1, 5, 2)
+    for r in range(world):
+        accus, images, act, logits, nan_found, real_act = torch.load(str(tmp_path / ("rank%d.pt" % r)))
+        assert torch.equal(act, want[2]) and torch.equal(real_act, want[5])
+        assert real_act.shape == (5 * B - 3, F)
 
 
 def test_nan_on_one_rank_stops_all_ranks(tmp_path):

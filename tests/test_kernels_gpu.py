@@ -1094,15 +1094,17 @@ CONV_VARIANT_ENVS = [
     # small-map kernels (cg_conv_small.hip) wherever their geometry fits / nowhere
     ("small_all", {"CGAMD_SCONV": "2", "CGAMD_SWGRAD": "2"}),
     ("no_small", {"CGAMD_SCONV": "0", "CGAMD_SWGRAD": "0"}),
-    # persistent kernel wherever its 16x32 tiles fit: one item per workgroup; three workgroups that
-    # walk all the items (window / weight prefetch across items, epilogue between them); the
-    # 2 x 4 wave layout; and switched off (no fragment image behind the weights at all)
-    ("pconv_all", {"CGAMD_PCONV_MIN": "1", "CGAMD_HCONV_MIN": "1", "CGAMD_HCONV_RW": "0"}),
-    ("pconv_walk", {"CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GRID": "3", "CGAMD_HCONV_MIN": "1",
-                    "CGAMD_HCONV_RW": "0"}),
-    ("pconv_wm2", {"CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GRID": "5", "CGAMD_PCONV_WM2": "1",
+    # persistent kernel (off by default, CGAMD_PCONV=1) wherever its 16x32 tiles fit: one item per
+    # workgroup; three workgroups that walk all the items (window / weight prefetch across items,
+    # epilogue between them); the 2 x 4 wave layout without the fragment read-ahead
+    ("pconv_all", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
+                   "CGAMD_HCONV_MIN": "1", "CGAMD_HCONV_RW": "0"}),
+    ("pconv_walk", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
+                    "CGAMD_PCONV_GRID": "3", "CGAMD_HCONV_MIN": "1", "CGAMD_HCONV_RW": "0"}),
+    ("pconv_wm2", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
+                   "CGAMD_PCONV_GRID": "5", "CGAMD_PCONV_WM2": "1", "CGAMD_PCONV_PIPE": "0",
                    "CGAMD_HCONV_MIN": "1"}),
-    ("no_pconv", {"CGAMD_PCONV": "0"}),
+    # default policy, kernel on: the full-size shapes go through it in their own test below
 ]
 
 
@@ -1122,6 +1124,23 @@ def test_conv_kernel_variants(dev, variant):
                         "test_gconv_fused_statistics_groups"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
+
+
+@pytest.mark.gpu
+def test_persistent_conv_at_the_benchmark_shapes(dev):
+    """cg_conv_pers.hip under its own grid policy (CGAMD_PCONV=1: 256 persistent workgroups that walk
+    1-4 items each) on the geometries of the benchmark: the full-size forward / data-gradient /
+    fused batch-norm / pooled cases of this file in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update({"CGAMD_PCONV": "1", "CGAMD_PCONV_GATED": "1"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
+                        "-x", "-k", "full_size"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, "%s\n%s" % (r.stdout[-3000:], r.stderr[-1000:])
 
 
 @pytest.mark.gpu
