@@ -357,6 +357,49 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups,
   }
 }
 
+// Linear layers with very few outputs and a long K (the final `linear(h, 1)` of the DCGAN / SNDCGAN
+// discriminators on a flattened 16 x 16 x 512 map: dcgan.py:125-128, sndcgan.py:123-126 -- K =
+// 131,072, Co = 1): one 1024-thread block per (row, output) walks K with 16-byte loads and reduces
+// in a fixed order (deterministic).  The MFMA tiles spend a 32-wide tile on one useful column and a
+// single workgroup's K loop of 2,048 slices: 4.6 ms per call at batch 64; this is one pass over
+// x (16.8 MB) -- HBM / latency bound, a few microseconds.
+__global__ __launch_bounds__(1024) void rowdot_linear_kernel(GConvArgs a) {
+  __shared__ float part[16];
+  const int m = blockIdx.x, co = blockIdx.y;
+  const bf16_t* __restrict__ x = a.in + (int64_t)m * a.Ci;
+  const bf16_t* __restrict__ gx = a.gate_in ? a.gate_in + (int64_t)m * a.Ci : nullptr;
+  const bf16_t* __restrict__ w = a.bt + (int64_t)co * a.Kp;
+  float acc = 0.f;
+  for (int k0 = threadIdx.x * 8; k0 < a.Ci; k0 += 1024 * 8) {   // Ci % 8 == 0
+    float xv[8], wv[8];
+    unpack8_bf16(*reinterpret_cast<const uint4*>(x + k0), xv);
+    unpack8_bf16(*reinterpret_cast<const uint4*>(w + k0), wv);
+    if (gx) {   // kernel-uniform; the gated operand is rounded to bf16 like the staged one (vconv_in)
+      float gv[8];
+      unpack8_bf16(*reinterpret_cast<const uint4*>(gx + k0), gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = gv[e] > 0.f ? xv[e] : bf2f(f2bf(xv[e] * a.slope_in));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += xv[e] * wv[e];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += part[i];
+    if (a.bias) v += a.bias[co];
+    const int64_t o = (int64_t)m * a.Co + co;
+    if (a.self_gate) v = v > 0.f ? v : v * a.slope_out;
+    else if (a.gate_out) v = bf2f(a.gate_out[o]) > 0.f ? v : v * a.slope_out;
+    if (a.residual) v += bf2f(a.residual[o]);
+    if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = v;
+    else reinterpret_cast<bf16_t*>(a.out)[o] = f2bf(v);
+  }
+}
+
 // block = 64 rows x ONE 8-channel group; wave w takes the 8-element K pieces w, w + 4, ... (the
 // weight loads of a wave are uniform), lane -> row; the four partial sums meet in LDS.  The 8 weight
 // rows of a group are read once per 64 rows (a wave per output re-read them per row: 100 MB of L2
@@ -794,6 +837,26 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   int rc = check_geom(g, "cg_gconv");
   if (rc) return rc;
   if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv: null tensor");
+  if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Hin == 1 && g->Win == 1 &&
+      g->Co <= 4 && (g->Ci % 8) == 0 && g->Ci >= 4096 && (int64_t)g->N * g->Co <= 4096 &&
+      (!gate_in || gate_in == in)) {
+    // few outputs, long K: one pass over x per output instead of an MFMA tile with one useful column
+    GConvArgs r;
+    memset(&r, 0, sizeof(r));
+    r.in = (const bf16_t*)in; r.bt = (const bf16_t*)bt; r.out = out; r.bias = bias;
+    r.gate_in = (const bf16_t*)gate_in;
+    r.self_gate = (gate_out != nullptr && gate_out == out);
+    r.gate_out = r.self_gate ? nullptr : (const bf16_t*)gate_out;
+    r.residual = (const bf16_t*)residual;
+    r.Ci = g->Ci; r.Co = g->Co; r.M = g->N; r.K = g->Ci; r.Kp = (g->Ci + 7) & ~7;
+    r.slope_in = slope_in; r.slope_out = slope_out; r.out_f32 = out_is_f32;
+    dim3 grid(g->N, g->Co);
+    hipStream_t fst = (hipStream_t)stream;
+    CgProfScope prof(CG_PROF_GCONV_GENERIC, g, fst);
+    rowdot_linear_kernel<<<grid, 1024, 0, fst>>>(r);
+    CG_CHECK_LAUNCH("cg_gconv(row dot)");
+    return CG_OK;
+  }
   if (cg_wstem_conv_supported(g, in, out, gate_in, slope_in, gate_out, residual)) {
     hipStream_t fst = (hipStream_t)stream;
     cg_wstem_conv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, fst);

@@ -2,6 +2,7 @@
 workspace allocation on the current torch HIP stream.  No arithmetic happens in Python/torch here;
 torch only owns the device memory and the stream."""
 import ctypes
+import os
 
 import torch
 
@@ -93,6 +94,13 @@ def weight_prep(w, scale=None, want_fwd=True, want_bwd=False):
     return bt_f, bt_b
 
 
+def _leaky_prepass(geom):
+    """Leaky self-gates are applied by an element-wise pass in front of the convolution wherever an
+    MFMA-tiled kernel can take the launch afterwards (channel counts in multiples of 32; image
+    inputs and linear layers keep the fused gate of the generic / VALU kernels)."""
+    return geom.Ci % 32 == 0 and geom.Hin * geom.Win > 1 and os.environ.get("CGAMD_LEAKY_PREPASS", "1") != "0"
+
+
 def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slope_out=0.0,
           residual=None, out_f32=False, act_out=None):
     """act_out: leaky-ReLU slope applied to (conv + bias) itself (0.0 = ReLU); exclusive with
@@ -121,6 +129,12 @@ def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slo
         # penalty_lib.py:74-82) is only understood by the generic kernel (~85 TFLOP/s): one
         # element-wise pass x * D(gate) and the MFMA-tiled kernels apply (exact for ReLU gates)
         x, gate_in = lrelu_bwd(gate_in, x, slope_in), None
+    elif gate_in is not None and float(slope_in) != 0.0 and _leaky_prepass(geom):
+        # y = conv(lrelu_slope(x)) (sndcgan.py:97-122, dcgan.py:108-124): the MFMA-tiled kernels gate
+        # their input with an integer max (ReLU only); the leaky form runs on the generic gather
+        # kernel at ~200 TFLOP/s.  One element-wise pass in front (x read + written once) and the
+        # tiled kernels apply: 347 -> ~90 us on 64 x 128^2 x 64 -> 64^2 x 128, 4x4 / stride 2
+        x, gate_in = lrelu_bwd(x, x, slope_in), None
     out = torch.empty(oshape, dtype=F32 if out_f32 else BF16, device=x.device)
     if act_out is not None:
         if gate_out is not None:
@@ -263,6 +277,8 @@ def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, 
     # separate gate tensors: see gconv
     if gate_in is not None and gate_in.data_ptr() != x.data_ptr():
         x, gate_in = lrelu_bwd(gate_in, x, slope_in), None
+    elif gate_in is not None and float(slope_in) != 0.0 and _leaky_prepass(geom):
+        x, gate_in = lrelu_bwd(x, x, slope_in), None   # see gconv
     if gate_dy is not None:
         dy, gate_dy = lrelu_bwd(gate_dy, dy, slope_dy), None
     dw = out if out is not None else torch.empty((geom.kh, geom.kw, geom.Ci, geom.Co), dtype=F32,

@@ -129,6 +129,9 @@ CONV_CASES = [
     ("lin_148", 64, 1, 1, 148, 192, 1, 1, 1),
     ("lin_1000", 70, 1, 1, 1000, 128, 1, 1, 1),
     ("lin_ragged", 5, 1, 1, 21, 20, 1, 1, 1),
+    # few outputs, long K (rowdot_linear_kernel): the final linear of the DCGAN / SNDCGAN discriminators
+    ("rowdot_k8192", 5, 1, 1, 8192, 1, 1, 1, 1),
+    ("rowdot_co3", 3, 1, 1, 4096, 3, 1, 1, 1),
 ]
 
 
