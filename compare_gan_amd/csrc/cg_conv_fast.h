@@ -36,6 +36,11 @@ void cg_weight_frag_launch(const cgFragJob* jobs, int n, hipStream_t st);
 bool cg_pconv_geom_ok(const cgConvGeom* g);
 bool cg_pconv_use(const cgConvGeom* g);   // geometry + grid-size policy
 int cg_pconv_stats_rows(const cgConvGeom* g);
+// the same K loop as two independent 4-wave workgroups per CU on 8x32 tiles (hconv_kernel's rows)
+bool cg_qconv_use(const cgConvGeom* g);
+void cg_qconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out, int out_is_f32,
+                     const float* bias, const void* gate_in, const void* gate_out, float slope_out,
+                     const void* residual, const cgConvFusion* fu, hipStream_t st);
 void cg_pconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out, int out_is_f32,
                      const float* bias, const void* gate_in, const void* gate_out, float slope_out,
                      const void* residual, const cgConvFusion* fu, hipStream_t st);

@@ -157,6 +157,196 @@ struct PcBlock {
   int st;             // spatial tile index (statistics row)
 };
 
+// ---- the epilogue of one (tile, out-channel tile) item, shared by the persistent and the
+// two-workgroups-per-CU kernel: every wave stages its own MI x 32 pixels x WCO channels accumulator
+// tile through a private LDS region (fp32, one tile row of 32 pixels per pass), then each lane
+// finishes 8 consecutive channels of one pixel (bias, activation, gate, residual, pooling: one
+// rounding to bf16) and writes 16 (bf16) / 32 (fp32) contiguous bytes; batch-norm statistics of the
+// STORED values per item in a fixed order (hconv_kernel's arithmetic).  NW waves = WM x WN; tile rows
+// wm * MI + i; TH = tile height.  Ends with the waves' LDS traffic complete but NO barrier.
+template <int BN, int WM, int WN, int MI, int NJ, int FUSE, int TH, int STAGE_BYTES>
+__device__ __forceinline__ void pc_epilogue(const PConvArgs& a, f32x16_t (&acc)[MI][NJ],
+                                            unsigned char* stage, int tid, int lane, int wave, int wm,
+                                            int wn, int frow, int half, int n, int ty, int tx, int nt,
+                                            int st) {
+  constexpr int NW = WM * WN;
+    constexpr int WCO = BN / WN;           // channels per wave
+    constexpr int SP = WCO * 4 + 16;       // staging row pitch in bytes (+16: conflict-free b128 writes)
+    constexpr int G8 = WCO / 8;            // 8-channel groups per row
+    constexpr int RPI = 64 / G8;           // rows per sweep of the 64 lanes
+    static_assert(NW * 32 * SP + NW * 2 * WCO * 4 <= STAGE_BYTES, "per-wave epilogue staging does not fit");
+    unsigned char* Sw = stage + wave * (32 * SP);
+    const int n0 = nt * BN;
+    const int g8 = lane & (G8 - 1), rl = lane / G8;
+    const int co = n0 + wn * WCO + g8 * 8;
+    const bool co_ok = co < a.Co;          // Co % 8 == 0
+    const float osc = a.out_scale;
+    if constexpr (FUSE == 2) {
+      // ---- pooled epilogue: tile rows wm*MI + 2p, + 2p + 1 are acc[2p] / acc[2p + 1] of the SAME
+      // lane (summed in registers); horizontal pairs are neighbouring staging rows
+#pragma unroll
+      for (int p = 0; p < MI / 2; ++p) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            float4 t = make_float4(acc[2 * p][j][q4 * 4 + 0] + acc[2 * p + 1][j][q4 * 4 + 0],
+                                   acc[2 * p][j][q4 * 4 + 1] + acc[2 * p + 1][j][q4 * 4 + 1],
+                                   acc[2 * p][j][q4 * 4 + 2] + acc[2 * p + 1][j][q4 * 4 + 2],
+                                   acc[2 * p][j][q4 * 4 + 3] + acc[2 * p + 1][j][q4 * 4 + 3]);
+            *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q4 * 8 + 4 * half) * 4) = t;
+          }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = lane; it < 16 * G8; it += 64) {
+          const int x2 = it / G8, gg = it - x2 * G8;
+          const unsigned char* r0 = Sw + (2 * x2) * SP + gg * 32;
+          float v[8];
+          {
+            const float4 a0 = *reinterpret_cast<const float4*>(r0);
+            const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16);
+            const float4 b0 = *reinterpret_cast<const float4*>(r0 + SP);
+            const float4 b1 = *reinterpret_cast<const float4*>(r0 + SP + 16);
+            v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
+            v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
+          }
+          const int cq = n0 + wn * WCO + gg * 8;
+          if (cq >= a.Co) continue;
+          const int oy = ty * (TH / 2) + wm * (MI / 2) + p, ox = tx * (PC_TW / 2) + x2;
+          const int64_t o = ((int64_t)(n * (a.H >> 1) + oy) * (a.W >> 1) + ox) * a.Co + cq;
+          if (a.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + cq);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + cq + 4);
+            v[0] = 0.25f * v[0] + b0.x; v[1] = 0.25f * v[1] + b0.y; v[2] = 0.25f * v[2] + b0.z;
+            v[3] = 0.25f * v[3] + b0.w; v[4] = 0.25f * v[4] + b1.x; v[5] = 0.25f * v[5] + b1.y;
+            v[6] = 0.25f * v[6] + b1.z; v[7] = 0.25f * v[7] + b1.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= 0.25f;
+          }
+          if (a.residual) {
+            float rv[8];
+            unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if (a.out_f32) {
+            float* op = reinterpret_cast<float*>(a.out) + o;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      float bv[8], s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = s1[e] = s2[e] = 0.f;
+      if (a.bias && co_ok) {
+        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q4 * 8 + 4 * half) * 4) =
+                make_float4(acc[i][j][q4 * 4 + 0], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2],
+                            acc[i][j][q4 * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 32 / RPI; ++k) {
+          const int row = rl + RPI * k;   // pixel column of tile row wm*MI + i
+          const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
+          const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
+          if (!co_ok) continue;
+          const int oy = ty * TH + wm * MI + i, ox = tx * PC_TW + row;
+          const int64_t o = ((int64_t)(n * a.H + oy) * a.W + ox) * a.Co + co;
+          float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
+                        hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
+          if (a.self_gate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (!(v[e] > 0.f)) v[e] *= a.slope_out;
+          }
+          if (a.gate_out) {
+            float gv[8];
+            unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (!(gv[e] > 0.f)) v[e] *= a.slope_out;
+          }
+          if (a.residual) {
+            float rv[8];
+            unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if (PC_DBG(8)) continue;
+          if (a.out_f32) {
+            float* op = reinterpret_cast<float*>(a.out) + o;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            const uint4 pk = pack8_bf16(v);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pk;
+            if (FUSE == 1 && a.stats) unpack8_bf16(pk, v);   // statistics of the STORED values
+          }
+          if (FUSE == 1 && a.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              s1[e] += v[e];
+              s2[e] += v[e] * v[e];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (FUSE == 1 && a.stats) {   // wave-uniform
+        // lanes with the same g8 hold partial sums of the same 8 channels: butterfly over the
+        // others, then the WM pixel-waves of a channel group are combined through LDS in a fixed
+        // order (deterministic)
+#pragma unroll
+        for (int m = G8; m < 64; m <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += __shfl_xor(s1[e], m, 64);
+            s2[e] += __shfl_xor(s2[e], m, 64);
+          }
+        }
+        float* sreg = reinterpret_cast<float*>(stage + NW * 32 * SP);   // [8 waves][2][WCO]
+        if (lane < G8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sreg[(wave * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
+            sreg[(wave * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
+          }
+        }
+        __syncthreads();
+        if (tid < BN) {
+          const int cw = tid / WCO, cc = tid - cw * WCO;
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int m4 = 0; m4 < WM; ++m4) {
+            t1 += sreg[((m4 * WN + cw) * 2 + 0) * WCO + cc];
+            t2 += sreg[((m4 * WN + cw) * 2 + 1) * WCO + cc];
+          }
+          const int cch = n0 + tid;
+          if (cch < a.Co) {
+            a.stats[(int64_t)st * 2 * a.Co + cch] = t1;
+            a.stats[(int64_t)st * 2 * a.Co + a.Co + cch] = t2;
+          }
+        }
+      }
+    }
+}
+
 // BN: out-channels per workgroup (128 / 64); WM: waves along the pixels (4: 128 x (BN/2) per wave,
 // 2: 256 x (BN/4)); FUSE: 0 plain, 1 batch-norm prologue / statistics epilogue, 2 pooled epilogue
 template <int BN, int WM, bool RELU, int FUSE, bool PIPE>
@@ -523,185 +713,17 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
     if (cur.cb == a.cblocks - 1) {
       // ================= epilogue of the item, in the dead window buffer =================
       // the next block's first weights land before the stores below queue up behind them
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (the ring registers are named so that none of them is handed to the epilogue while a load
+      // into it is still in flight: see qconv_kernel)
+#pragma unroll
+      for (int q3 = 0; q3 < 3; ++q3)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bq[q3][j][0]), "+v"(Bq[q3][j][1])::"memory");
       fresh = true;
       const unsigned long long te0 = PC_NOW();
-      constexpr int WCO = BN / WN;           // channels per wave
-      constexpr int SP = WCO * 4 + 16;       // staging row pitch in bytes (+16: conflict-free b128 writes)
-      constexpr int G8 = WCO / 8;            // 8-channel groups per row
-      constexpr int RPI = 64 / G8;           // rows per sweep of the 64 lanes
-      static_assert(8 * 32 * SP + 8 * 2 * WCO * 4 <= PC_HB, "per-wave epilogue staging does not fit");
-      unsigned char* Sw = smem + buf * PC_HB + wave * (32 * SP);
-      const int n0 = cur.nt * BN;
-      const int g8 = lane & (G8 - 1), rl = lane / G8;
-      const int co = n0 + wn * WCO + g8 * 8;
-      const bool co_ok = co < a.Co;          // Co % 8 == 0
-      const int n = cur.n, ty = cur.ty, tx = cur.tx;
-      const float osc = a.out_scale;
-      if constexpr (FUSE == 2) {
-        // ---- pooled epilogue: tile rows wm*MI + 2p, + 2p + 1 are acc[2p] / acc[2p + 1] of the SAME
-        // lane (summed in registers); horizontal pairs are neighbouring staging rows
-#pragma unroll
-        for (int p = 0; p < MI / 2; ++p) {
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              float4 t = make_float4(acc[2 * p][j][q4 * 4 + 0] + acc[2 * p + 1][j][q4 * 4 + 0],
-                                     acc[2 * p][j][q4 * 4 + 1] + acc[2 * p + 1][j][q4 * 4 + 1],
-                                     acc[2 * p][j][q4 * 4 + 2] + acc[2 * p + 1][j][q4 * 4 + 2],
-                                     acc[2 * p][j][q4 * 4 + 3] + acc[2 * p + 1][j][q4 * 4 + 3]);
-              *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q4 * 8 + 4 * half) * 4) = t;
-            }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int it = lane; it < 16 * G8; it += 64) {
-            const int x2 = it / G8, gg = it - x2 * G8;
-            const unsigned char* r0 = Sw + (2 * x2) * SP + gg * 32;
-            float v[8];
-            {
-              const float4 a0 = *reinterpret_cast<const float4*>(r0);
-              const float4 a1 = *reinterpret_cast<const float4*>(r0 + 16);
-              const float4 b0 = *reinterpret_cast<const float4*>(r0 + SP);
-              const float4 b1 = *reinterpret_cast<const float4*>(r0 + SP + 16);
-              v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
-              v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
-            }
-            const int cq = n0 + wn * WCO + gg * 8;
-            if (cq >= a.Co) continue;
-            const int oy = ty * (PC_TH / 2) + wm * (MI / 2) + p, ox = tx * (PC_TW / 2) + x2;
-            const int64_t o = ((int64_t)(n * (a.H >> 1) + oy) * (a.W >> 1) + ox) * a.Co + cq;
-            if (a.bias) {
-              const float4 b0 = *reinterpret_cast<const float4*>(a.bias + cq);
-              const float4 b1 = *reinterpret_cast<const float4*>(a.bias + cq + 4);
-              v[0] = 0.25f * v[0] + b0.x; v[1] = 0.25f * v[1] + b0.y; v[2] = 0.25f * v[2] + b0.z;
-              v[3] = 0.25f * v[3] + b0.w; v[4] = 0.25f * v[4] + b1.x; v[5] = 0.25f * v[5] + b1.y;
-              v[6] = 0.25f * v[6] + b1.z; v[7] = 0.25f * v[7] + b1.w;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= 0.25f;
-            }
-            if (a.residual) {
-              float rv[8];
-              unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rv[e];
-            }
-            if (a.out_f32) {
-              float* op = reinterpret_cast<float*>(a.out) + o;
-              *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-              *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      } else {
-        float bv[8], s1[8], s2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = s1[e] = s2[e] = 0.f;
-        if (a.bias && co_ok) {
-          const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
-          const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
-          bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-              *reinterpret_cast<float4*>(Sw + frow * SP + (j * 32 + q4 * 8 + 4 * half) * 4) =
-                  make_float4(acc[i][j][q4 * 4 + 0], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2],
-                              acc[i][j][q4 * 4 + 3]);
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int k = 0; k < 32 / RPI; ++k) {
-            const int row = rl + RPI * k;   // pixel column of tile row wm*MI + i
-            const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
-            const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
-            if (!co_ok) continue;
-            const int oy = ty * PC_TH + wm * MI + i, ox = tx * PC_TW + row;
-            const int64_t o = ((int64_t)(n * a.H + oy) * a.W + ox) * a.Co + co;
-            float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
-                          hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
-            if (a.self_gate) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (!(v[e] > 0.f)) v[e] *= a.slope_out;
-            }
-            if (a.gate_out) {
-              float gv[8];
-              unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (!(gv[e] > 0.f)) v[e] *= a.slope_out;
-            }
-            if (a.residual) {
-              float rv[8];
-              unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rv[e];
-            }
-            if (PC_DBG(8)) continue;
-            if (a.out_f32) {
-              float* op = reinterpret_cast<float*>(a.out) + o;
-              *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-              *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-              const uint4 pk = pack8_bf16(v);
-              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pk;
-              if (FUSE == 1 && a.stats) unpack8_bf16(pk, v);   // statistics of the STORED values
-            }
-            if (FUSE == 1 && a.stats) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                s1[e] += v[e];
-                s2[e] += v[e] * v[e];
-              }
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (FUSE == 1 && a.stats) {   // wave-uniform
-          // lanes with the same g8 hold partial sums of the same 8 channels: butterfly over the
-          // others, then the WM pixel-waves of a channel group are combined through LDS in a fixed
-          // order (deterministic)
-#pragma unroll
-          for (int m = G8; m < 64; m <<= 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              s1[e] += __shfl_xor(s1[e], m, 64);
-              s2[e] += __shfl_xor(s2[e], m, 64);
-            }
-          }
-          float* sreg = reinterpret_cast<float*>(smem + buf * PC_HB + 8 * 32 * SP);   // [8 waves][2][WCO]
-          if (lane < G8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              sreg[(wave * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
-              sreg[(wave * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
-            }
-          }
-          __syncthreads();
-          if (tid < BN) {
-            const int cw = tid / WCO, cc = tid - cw * WCO;
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int m4 = 0; m4 < WM; ++m4) {
-              t1 += sreg[((m4 * WN + cw) * 2 + 0) * WCO + cc];
-              t2 += sreg[((m4 * WN + cw) * 2 + 1) * WCO + cc];
-            }
-            const int cch = n0 + tid;
-            if (cch < a.Co) {
-              a.stats[(int64_t)cur.st * 2 * a.Co + cch] = t1;
-              a.stats[(int64_t)cur.st * 2 * a.Co + a.Co + cch] = t2;
-            }
-          }
-        }
-      }
+      pc_epilogue<BN, WM, WN, MI, NJ, FUSE, PC_TH, PC_HB>(a, acc, smem + buf * PC_HB, tid, lane, wave, wm, wn,
+                                                          frow, half, cur.n, cur.ty, cur.tx, cur.nt, cur.st);
       zero_acc();
       // the staging rows are dead before any wave stages a piece of the window after next into them
       __syncthreads();
@@ -733,6 +755,245 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PConvArgs a) {
     w[0] = t_blocks; w[1] = t_wait; w[2] = t_bar; w[3] = t_epi;
   }
 #endif
+}
+
+
+// -------------------------------------------------------------------------------------------
+// The same K loop in hconv_kernel's occupancy model ("qconv"): TWO independent 4-wave workgroups
+// per CU (one wave per SIMD each, 256 VGPRs), each owning one 8 x 32 pixel tile x BN out-channels
+// with ONE window buffer.  What the persistent kernel above taught (profiles/r04_pconv_*.txt,
+// scripts/probe/mfma_probe.hip): its K loop alone reaches 1.4-1.7 PFLOP/s, but every persistent
+// workgroup of the chip arrives at its epilogue in the same microsecond -- 33 MB of stores at the
+// HBM write rate, 9 k cycles per item during which no MFMA issues -- and the first window of a
+// launch is pure latency.  Two unsynchronised workgroups per CU hide exactly those phases behind
+// each other's MFMA work (what carries hconv_kernel), while the loop keeps what made the
+// persistent one lean: weights straight from the fragment-ordered image into registers (no
+// per-slice barrier: ONE barrier pair per 64-channel block), 128 x 64 wave tiles, window fragments
+// read one row pair ahead, ReLU applied once to the staged window.
+// -------------------------------------------------------------------------------------------
+constexpr int QC_TH = 8;
+constexpr int QC_HROWS = (QC_TH + 2) * PC_PITCH;          // 340 window rows
+constexpr int QC_PIECES = (QC_HROWS + 7) / 8;             // 43 pieces of 1 KiB
+constexpr int QC_HB = QC_PIECES * 1024;
+constexpr int QC_SLOTS = (QC_PIECES + 3) / 4;             // 11 pieces per wave (wave 3: 10)
+
+template <int BN, bool RELU, int FUSE>
+__global__ __launch_bounds__(256, 2) void qconv_kernel(PConvArgs a) {
+  constexpr int WM = 2, WN = 2, MI = 4;
+  constexpr int NJ = BN / (32 * WN);
+  constexpr int LB = 2 * NJ;
+  constexpr int TAB_OFF = QC_HB;
+  constexpr int LDS_BYTES = QC_HB + (FUSE == 1 ? 1024 : 0);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 31, half = lane >> 5;
+  const uint32_t lds0 = cg_lds_addr(smem);
+  const int us = a.in_up;
+
+  // ---- workgroup -> (image, tile row, tile column, out-channel tile), XCD-contiguous ----
+  const int q = pc_xcd_remap(blockIdx.x, gridDim.x);
+  const int st = (int)fdiv((uint32_t)q, a.dNt);
+  const int nt = q - st * a.ntiles;
+  const int t1 = (int)fdiv((uint32_t)st, a.dTx);
+  const int tx = st - t1 * a.tiles_x;
+  const int n = (int)fdiv((uint32_t)t1, a.dTy);
+  const int ty = t1 - n * a.tiles_y;
+
+  const cg_i32x4_t rs_b = cg_make_rsrc(a.btf, a.btf_bytes);
+  cg_i32x4_t rs_w;
+  {
+    const int py = ((ty * QC_TH) >> us) - 1, px = ((tx * PC_TW) >> us) - 1;
+    rs_w = cg_make_rsrc(a.in + (((int64_t)n * (a.H >> us) + py) * (a.W >> us) + px) * a.Ci, 0x7fffffffu);
+  }
+  // per piece one register (see pconv_kernel): offset | padding-condition bits
+  uint32_t prel[QC_SLOTS];
+#pragma unroll
+  for (int j = 0; j < QC_SLOTS; ++j) {
+    const int row = (wave + 4 * j) * 8 + (lane >> 3);
+    const int hy = row / PC_PITCH, hx = row - hy * PC_PITCH;
+    const int c8 = ((lane & 7) ^ ((hx >> 1) & 7)) * 8;
+    const uint32_t rel =
+        (uint32_t)(((((hy + us) >> us) * (a.W >> us) + ((hx + us) >> us)) * a.Ci + c8) * 2);
+    prel[j] = row < QC_HROWS ? (rel | (hy == 0 ? 1u : 0u) | (hy == QC_TH + 1 ? 2u : 0u) |
+                                (hx == 0 ? 4u : 0u) | (hx == PC_TW + 1 ? 8u : 0u) |
+                                (c8 >= 32 ? 0x40000000u : 0u))
+                             : PC_OOB;
+  }
+  const uint32_t edge = 0x80000000u | (ty == 0 ? 1u : 0u) | (ty == a.tiles_y - 1 ? 2u : 0u) |
+                        (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
+  auto window_issue = [&](int cb) {
+    const uint32_t pmask = edge | (a.Ci - cb * 64 < 64 ? 0x40000000u : 0u);
+    pc_static_for<0, QC_SLOTS>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int piece = wave + 4 * j;
+      if (piece < QC_PIECES) {
+        const uint32_t pr = prel[j];
+        pc_dma16(rs_w, (pr & pmask) != 0u ? PC_OOB : (pr & 0x3ffffff0u), (uint32_t)(cb * 128),
+                 lds0 + piece * 1024);
+      }
+    });
+  };
+  auto relu_own_pieces = [&]() {
+    pc_static_for<0, QC_SLOTS>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int piece = wave + 4 * j;
+      if (piece < QC_PIECES) {
+        bf16x8_t* p = reinterpret_cast<bf16x8_t*>(smem + piece * 1024 + lane * 16);
+        *p = pc_relu(*p);
+      }
+    });
+  };
+
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  // weight fragment `idx` (= j * 2 + k2) of half-slice (cb, tap, hh); past the last block: zeros
+  auto b_issue_one = [&](pc_frag_t (&dst)[NJ][2], int cb, int tap, auto hhc, auto idxc) {
+    constexpr int hh = decltype(hhc)::value, idx = decltype(idxc)::value;
+    constexpr int j = idx >> 1, k2 = idx & 1;
+    const int ct = nt * (BN / 32) + wn * NJ + j;
+    const bool ok = cb < a.cblocks && ct < a.cotiles;
+    const uint32_t soff = (uint32_t)(((ok ? ct : 0) * a.nslices + (ok ? cb : 0) * 9 + tap) * 4096);
+    pc_bload<hh * 2048 + k2 * 1024>(dst[j][k2], ok ? lane16 : PC_OOB, rs_b, soff);
+  };
+
+  // fused batch-norm prologue (hconv_kernel's, on the 10 x 34 window)
+  const bool bnp = FUSE == 1 && a.bn_mean != nullptr;
+  auto load_bn_table = [&](int cb) {
+    if (tid < 64) {
+      float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
+      const int ch = min(cb * 64 + tid, a.Ci - 1);
+      const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
+      const int64_t sidx = a.bn_stat_group > 0 ? (int64_t)(n / a.bn_stat_group) * a.Ci + ch : ch;
+      tab[tid] = a.bn_mean[sidx];
+      tab[64 + tid] = rsqrtf(a.bn_var[sidx] + a.bn_eps);
+      tab[128 + tid] = a.bn_gamma ? a.bn_gamma[pidx] : 1.f;
+      tab[192 + tid] = a.bn_beta ? a.bn_beta[pidx] : 0.f;
+    }
+  };
+  auto bn_transform = [&](int cb) {
+    const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
+    const int crem = a.Ci - cb * 64;
+    const int c8 = (tid & 7) * 8;
+    if (c8 >= crem) return;
+    float cm[8], cr[8], cg[8], cbt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      cm[e] = tab[c8 + e];
+      cr[e] = tab[64 + c8 + e];
+      cg[e] = tab[128 + c8 + e];
+      cbt[e] = tab[192 + c8 + e];
+    }
+    for (int row = tid >> 3; row < QC_HROWS; row += 32) {
+      const int hy = row / PC_PITCH, hx = row - hy * PC_PITCH;
+      const int iy = ty * QC_TH - 1 + hy, ix = tx * PC_TW - 1 + hx;
+      if (!((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)) continue;
+      uint4* p = reinterpret_cast<uint4*>(smem + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16);
+      float v[8];
+      unpack8_bf16(*p, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (v[e] - cm[e]) * cr[e];
+        t = t * cg[e] + cbt[e];
+        v[e] = fmaxf(t, 0.f);
+      }
+      *p = pack8_bf16(v);
+    }
+  };
+
+  int tsw[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) tsw[s] = (half ^ (((frow + s) >> 1) & 7)) << 4;
+  const int rb = ((wm * MI) * PC_PITCH + frow) * 128;
+
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  pc_frag_t Bq[3][NJ][2];
+
+  // the first two half-slices of weights leave before the window (their latency is the shorter one)
+  pc_static_for<0, LB>([&](auto ic) { b_issue_one(Bq[0], 0, 0, std::integral_constant<int, 0>(), ic); });
+  pc_static_for<0, LB>([&](auto ic) { b_issue_one(Bq[1], 0, 0, std::integral_constant<int, 1>(), ic); });
+
+  for (int cb = 0; cb < a.cblocks; ++cb) {
+    // ---- the block's window: staged by all four waves, ReLU'd by the wave that staged the piece ----
+    window_issue(cb);
+    if (bnp) load_bn_table(cb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pieces + the first weights of the block
+    if (RELU) relu_own_pieces();
+    __syncthreads();
+    if (bnp) {
+      bn_transform(cb);
+      __syncthreads();
+    }
+    auto a_read = [&](auto hc, auto k2c, auto i0c, bf16x8_t (&dst)[2]) {
+      constexpr int h = decltype(hc)::value, k2 = decltype(k2c)::value, i0 = decltype(i0c)::value;
+      constexpr int tap = h >> 1, hh = h & 1, r = tap / 3, s = tap % 3, kk = hh * 2 + k2;
+      const int ad = rb + (tsw[s] ^ (kk << 5));
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        dst[e] = *reinterpret_cast<const bf16x8_t*>(smem + ad + s * 128 + (i0 + e + r) * PC_ROWSTEP);
+    };
+    bf16x8_t afp[2][2];
+    a_read(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(),
+           std::integral_constant<int, 0>(), afp[0]);
+    pc_static_for<0, 18>([&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      constexpr int h2 = h + 2;
+      auto b_ahead = [&](auto idxc) {
+        if constexpr (h2 < 18)
+          b_issue_one(Bq[h2 % 3], cb, h2 >> 1, std::integral_constant<int, h2 & 1>(), idxc);
+        else
+          b_issue_one(Bq[h2 % 3], cb + 1, (h2 - 18) >> 1, std::integral_constant<int, h2 & 1>(), idxc);
+      };
+      // the last load of this half-slice left in the last row pair of half-slice h - 2; behind it only
+      // the LB loads of half-slice h - 1 (half-slices 0 and 1 of a block landed with its window)
+      if constexpr (h >= 2) {
+        if constexpr (NJ == 2)
+          pc_wait<LB>(Bq[h % 3][0][0], Bq[h % 3][0][1], Bq[h % 3][1][0], Bq[h % 3][1][1]);
+        else
+          pc_wait<LB>(Bq[h % 3][0][0], Bq[h % 3][0][1]);
+      }
+      constexpr int NP = MI;   // 2 k-steps x MI / 2 row pairs
+      pc_static_for<0, NP>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int k2 = g / (MI / 2), i0 = (g % (MI / 2)) * 2;
+        constexpr int gn = g + 1;
+        if constexpr (g % (NP / LB) == 0) b_ahead(std::integral_constant<int, g / (NP / LB)>());
+        if constexpr (gn < NP)
+          a_read(hc, std::integral_constant<int, gn / (MI / 2)>(),
+                 std::integral_constant<int, (gn % (MI / 2)) * 2>(), afp[gn & 1]);
+        else if constexpr (h + 1 < 18)
+          a_read(std::integral_constant<int, h + 1>(), std::integral_constant<int, 0>(),
+                 std::integral_constant<int, 0>(), afp[0]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i0 + e][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, Bq[h % 3][j][k2]), afp[g & 1][e], acc[i0 + e][j], 0, 0, 0);
+      });
+    });
+    // every wave is done with the window before it is restaged (or becomes the epilogue's staging)
+    __syncthreads();
+  }
+  // The zero reads issued past the last block are still in flight INTO the ring registers.  hipcc sees
+  // those registers as dead here and hands them to the epilogue's address arithmetic, which it is
+  // free to schedule above a bare `s_waitcnt` -- the late load then lands on top of it (one wave of a
+  // tile wrong, a few tiles per launch, different ones each time).  Naming the registers in the
+  // wait keeps them allocated until the loads are home.
+#pragma unroll
+  for (int q3 = 0; q3 < 3; ++q3)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bq[q3][j][0]), "+v"(Bq[q3][j][1])::"memory");
+  pc_epilogue<BN, WM, WN, MI, NJ, FUSE, QC_TH, QC_HB>(a, acc, smem, tid, lane, wave, wm, wn, frow, half, n,
+                                                      ty, tx, nt, st);
 }
 
 int pc_env(const char* name, int dflt) {
@@ -785,7 +1046,7 @@ size_t cg_weight_frag_elems(int T, int Cin, int R) {
   // launches and slower on gated data gradients, and inside the train steps the gain is eaten by the
   // second weight image (one more prep launch per network call): resnet128 D sub-step 5.12 -> 5.26 ms,
   // cifar step 7.05 -> 7.21 ms (profiles/r04_pconv_*.txt).  CGAMD_PCONV=1 switches it on.
-  static const int enabled = pc_env("CGAMD_PCONV", 0);
+  static const int enabled = pc_env("CGAMD_PCONV", 0) | pc_env("CGAMD_QCONV", 0);
   if (!enabled || T != 9 || (Cin % 32) != 0 || (R % 8) != 0 || R < 64) return 0;
   return (size_t)cdiv(R, 32) * cdiv(Cin, 64) * 9 * 2048;
 }
@@ -828,6 +1089,78 @@ bool cg_pconv_use(const cgConvGeom* g) {
   if (!enabled || !cg_pconv_geom_ok(g)) return false;
   const int64_t items = (int64_t)g->N * (g->Hin / PC_TH) * (g->Win / PC_TW) * cdiv(g->Co, pc_bn(g));
   return items >= min_items;
+}
+
+bool cg_qconv_use(const cgConvGeom* g) {
+  static const int enabled = pc_env("CGAMD_QCONV", 0);
+  static const int min_items = pc_env("CGAMD_QCONV_MIN", 100);
+  if (!enabled) return false;
+  if (g->S != 1 || g->U != 1 || g->kh != 3 || g->kw != 3 || g->pt != 1 || g->pl != 1) return false;
+  if (g->Ho != g->Hin || g->Wo != g->Win) return false;
+  if ((g->Hin % QC_TH) != 0 || (g->Win % PC_TW) != 0) return false;
+  if ((g->Ci % 32) != 0 || (g->Co % 8) != 0 || g->Co < 64) return false;
+  if (cg_weight_frag_elems(9, g->Ci, g->Co) == 0) return false;
+  if ((int64_t)(QC_TH + 2) * g->Win * g->Ci * 2 >= (1ll << 30)) return false;
+  const int64_t items = (int64_t)g->N * (g->Hin / QC_TH) * (g->Win / PC_TW) * cdiv(g->Co, pc_bn(g));
+  return items >= min_items;
+}
+
+void cg_qconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out, int out_is_f32,
+                     const float* bias, const void* gate_in, const void* gate_out, float slope_out,
+                     const void* residual, const cgConvFusion* fu, hipStream_t st) {
+  PConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.bn_mean = fu ? fu->bn_mean : nullptr;
+  a.bn_var = fu ? fu->bn_var : nullptr;
+  a.bn_gamma = fu ? fu->bn_gamma : nullptr;
+  a.bn_beta = fu ? fu->bn_beta : nullptr;
+  a.bn_eps = fu ? fu->bn_eps : 0.f;
+  a.bn_per_sample = fu ? fu->bn_per_sample : 0;
+  a.bn_stat_group = fu ? fu->bn_stat_group : 0;
+  a.stats = fu ? fu->stats_out : nullptr;
+  a.pool = fu ? fu->pool_out : 0;
+  a.in_up = fu ? fu->in_up : 0;
+  a.out_scale = (fu && fu->out_scale != 0.f) ? fu->out_scale : 1.f;
+  const int Kp = (9 * g->Ci + 7) & ~7;
+  a.in = (const bf16_t*)in;
+  a.btf = (const bf16_t*)bt + (size_t)g->Co * Kp;
+  a.btf_bytes = (uint32_t)(cg_weight_frag_elems(9, g->Ci, g->Co) * 2);
+  a.out = out;
+  a.bias = bias;
+  a.self_gate = (gate_out != nullptr && gate_out == out);
+  a.gate_out = a.self_gate ? nullptr : (const bf16_t*)gate_out;
+  a.residual = (const bf16_t*)residual;
+  a.N = g->N; a.H = g->Hin; a.W = g->Win; a.Ci = g->Ci; a.Co = g->Co;
+  a.cblocks = cdiv(g->Ci, 64);
+  a.nslices = 9 * a.cblocks;
+  a.cotiles = cdiv(g->Co, 32);
+  a.tiles_x = g->Win / PC_TW;
+  a.tiles_y = g->Hin / QC_TH;
+  const int bn = pc_bn(g);
+  a.ntiles = cdiv(g->Co, bn);
+  a.nitems = g->N * a.tiles_y * a.tiles_x * a.ntiles;
+  a.out_f32 = out_is_f32;
+  a.slope_out = slope_out;
+  a.dNt = make_fastdiv(a.ntiles);
+  a.dTx = make_fastdiv(a.tiles_x);
+  a.dTy = make_fastdiv(a.tiles_y);
+  const bool relu = gate_in != nullptr && a.bn_mean == nullptr;
+  CgProfScope prof(bn == 128 ? CG_PROF_PCONV_128 : CG_PROF_PCONV_64, g, st);
+#define QC_LAUNCH2(BN_, FUSE_)                                                       \
+  do {                                                                               \
+    if (relu) qconv_kernel<BN_, true, FUSE_><<<a.nitems, 256, 0, st>>>(a);           \
+    else qconv_kernel<BN_, false, FUSE_><<<a.nitems, 256, 0, st>>>(a);              \
+  } while (0)
+#define QC_LAUNCH(BN_)                                                               \
+  do {                                                                               \
+    if (a.pool) QC_LAUNCH2(BN_, 2);                                                  \
+    else if (a.bn_mean || a.stats) QC_LAUNCH2(BN_, 1);                               \
+    else QC_LAUNCH2(BN_, 0);                                                         \
+  } while (0)
+  if (bn == 128) QC_LAUNCH(128);
+  else QC_LAUNCH(64);
+#undef QC_LAUNCH
+#undef QC_LAUNCH2
 }
 
 int cg_pconv_stats_rows(const cgConvGeom* g) { return g->N * (g->Hin / PC_TH) * (g->Win / PC_TW); }

@@ -1107,6 +1107,9 @@ CONV_VARIANT_ENVS = [
     ("pconv_wm2", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
                    "CGAMD_PCONV_GRID": "5", "CGAMD_PCONV_WM2": "1", "CGAMD_PCONV_PIPE": "0",
                    "CGAMD_HCONV_MIN": "1"}),
+    # the same K loop as two 4-wave workgroups per CU on 8x32 tiles (qconv_kernel)
+    ("qconv_all", {"CGAMD_QCONV": "1", "CGAMD_QCONV_MIN": "1", "CGAMD_HCONV_MIN": "1",
+                   "CGAMD_HCONV_RW": "0"}),
     # default policy, kernel on: the full-size shapes go through it in their own test below
 ]
 
@@ -1131,19 +1134,21 @@ def test_conv_kernel_variants(dev, variant):
 
 @pytest.mark.gpu
 def test_persistent_conv_at_the_benchmark_shapes(dev):
-    """cg_conv_pers.hip under its own grid policy (CGAMD_PCONV=1: 256 persistent workgroups that walk
-    1-4 items each) on the geometries of the benchmark: the full-size forward / data-gradient /
-    fused batch-norm / pooled cases of this file in a child process."""
+    """cg_conv_pers.hip under its own grid policies (CGAMD_PCONV=1: 256 persistent workgroups that
+    walk 1-4 items each; CGAMD_QCONV=1: two 4-wave workgroups per CU) on the geometries of the
+    benchmark: the full-size forward / data-gradient / fused batch-norm / pooled cases of this file in
+    a child process."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ)
-    env.update({"CGAMD_PCONV": "1", "CGAMD_PCONV_GATED": "1"})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
-                        "-x", "-k", "full_size"], cwd=root, env=env, capture_output=True, text=True,
-                       timeout=900)
-    assert r.returncode == 0, "%s\n%s" % (r.stdout[-3000:], r.stderr[-1000:])
+    for extra in ({"CGAMD_PCONV": "1", "CGAMD_PCONV_GATED": "1"}, {"CGAMD_QCONV": "1"}):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
+                            "-x", "-k", "full_size"], cwd=root, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, "%s:\n%s\n%s" % (extra, r.stdout[-3000:], r.stderr[-1000:])
 
 
 @pytest.mark.gpu
