@@ -317,6 +317,18 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     // this wave's pieces of slice `it` (and of the halo, on a block's first tap) have landed; after
     // the barrier so have everybody's, and every wave is done with the weight slot restaged below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RELU && tap == 0) {
+      // ReLU of the input (resnet_ops.py:165,175): ONCE per staged window, in LDS, by the wave that
+      // staged the piece (its own pieces have landed), instead of on every one of the 9 x 8 fragment
+      // reads that consume the window (2 VALU instructions per MFMA in an issue-bound loop)
+#pragma unroll
+      for (int j = 0; j < HC_HSLOTS; ++j)
+        if (wave + 8 * j < npieces) {
+          bf16x8_t* p = reinterpret_cast<bf16x8_t*>(smem + (wave + 8 * j) * 1024 + lane * 16);
+          *p = hc_relu(*p);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if (bnp && tap == 0) {
       __syncthreads();   // window, weights and coefficient table are in LDS
       bn_transform(cb);
@@ -354,7 +366,6 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       for (int i = 0; i < 2; ++i) {
         af[i] = *reinterpret_cast<const bf16x8_t*>(smem + abase[i] +
                                                    (((kk * 2 + half) ^ aswz[i]) << 4));
-        if (RELU) af[i] = hc_relu(af[i]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -1324,6 +1335,17 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
   for (int sl = sbeg; sl < send; ++sl) {
     const int buf = (sl - sbeg) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RELU) {
+      // ReLU of the input operand: once per staged window, in LDS, by the wave that staged the piece
+      // (hconv_kernel), instead of on each of the 9 x 16 transposed fragment reads
+#pragma unroll
+      for (int j = 0; j < HC_HSLOTS; ++j)
+        if (wave + 8 * j < HC_HALO_PIECES) {
+          bf16x8_t* p = reinterpret_cast<bf16x8_t*>(smem + buf * BUF + (wave + 8 * j) * 1024 + lane * 16);
+          *p = hc_relu(*p);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     asm volatile("s_barrier" ::: "memory");   // slice landed for everybody; the other buffer is free
     // the next slice: all pieces at once (builtin DMA: hipcc waits for them before the first
     // transposed read anyway), or spread over the first NPIECE k-steps below (inline-asm DMA: the 8
@@ -1356,8 +1378,7 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
         for (int tt = 0; tt < NT; ++tt) {
           const int tap = TG * 5 + tt;
           const int sh = kc + (tap / 3) * PITCH + (tap % 3);
-          bf16x8_t xf = hc_tr_read2(lds + xb[sh & 3] + sh * 128);
-          if (RELU) xf = hc_relu(xf);
+          const bf16x8_t xf = hc_tr_read2(lds + xb[sh & 3] + sh * 128);
           acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc[tt], 0, 0, 0);
         }
       }
