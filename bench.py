@@ -115,10 +115,10 @@ def cpu_baseline(config, batch, budget_s=20.0, mode="step", no_penalty=False):
 
 
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r03_pmc_traffic.json")
+                                "r04_pmc_traffic.json")
 PMC_TRAFFIC_NOTE = ("HBM bytes per launch of this kernel family = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                     "from two rocprofv3 --pmc passes of this workload (scripts/pmc_traffic.py -> "
-                    "profiles/r03_pmc_traffic.json, one table per workload); null when that summary "
+                    "profiles/r04_pmc_traffic.json, one table per workload); null when that summary "
                     "is absent")
 
 
