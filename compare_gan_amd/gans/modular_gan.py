@@ -198,6 +198,14 @@ class _OptimizerState(object):
     self._inflight = True
 
   def disarm(self):
+    """Drops an armed state that apply_gradients() will not consume (the backward pass raised): the
+    gradient references go, and so does the in-flight mark of buckets that already left.
+    Collective ordering across ranks: the bucket all-reduces are issued from the autograd worker
+    thread and the cross-replica batch-norm collectives from the main thread; both orders are a
+    pure function of the (identical) graph on every rank, which is what keeps the ranks' sequences
+    of collectives aligned."""
+    if self._armed is not None and self._armed["order"]:
+      self.join()
     self._armed = None
 
   def _ensure(self, grads):
@@ -537,9 +545,13 @@ class ModularGAN(AbstractGAN):
     # torch.autograd.grad hands the gradients over directly: no AccumulateGrad nodes, whose
     # stream affinity would break hipGraph capture (they run on the stream they were created on)
     self.d_opt.arm()
-    with Fn.deferred_wgrads(self._wgrads_deferrable() and self.penalty_loss is None):
-      grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
-                                  allow_unused=True)
+    try:
+      with Fn.deferred_wgrads(self._wgrads_deferrable() and self.penalty_loss is None):
+        grads = torch.autograd.grad(self.d_loss, self.d_opt.params, grad_outputs=self._unit_grad(),
+                                    allow_unused=True)
+    except BaseException:
+      self.d_opt.disarm()   # a failed backward must not leave hooks armed / gradients referenced
+      raise
     self.d_opt.apply_gradients(self.global_step_disc, grads=self._fill_unused(self.d_opt, grads))
     self.d_loss = self.d_loss.detach()
     if self.penalty_loss is not None:
@@ -564,9 +576,13 @@ class ModularGAN(AbstractGAN):
         features["generated"] = self.generator(features["z"], y=sampled_y, is_training=True)
       self.create_loss(features, labels)
     self.g_opt.arm()
-    with Fn.deferred_wgrads(self._wgrads_deferrable()):
-      grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
-                                  allow_unused=True)
+    try:
+      with Fn.deferred_wgrads(self._wgrads_deferrable()):
+        grads = torch.autograd.grad(self.g_loss, self.g_opt.params, grad_outputs=self._unit_grad(),
+                                    allow_unused=True)
+    except BaseException:
+      self.g_opt.disarm()
+      raise
     self.g_opt.apply_gradients(self.global_step, ema_decay=self._ema_decay,
                                ema_start=self._ema_start_step,
                                grads=self._fill_unused(self.g_opt, grads))

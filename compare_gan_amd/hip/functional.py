@@ -107,7 +107,7 @@ def _wgrad_side_stream():
 # guarantees that no weight receives a second gradient contribution inside the context (autograd
 # would add to the unwritten tensor): modular_gan enables it for single-call discriminator /
 # generator graphs without penalties only.
-_DEFER = {"on": False, "jobs": []}
+_DEFER = {"on": False, "jobs": [], "wptrs": set()}
 
 
 class deferred_wgrads(object):
@@ -125,12 +125,14 @@ class deferred_wgrads(object):
       flush_wgrads()
     else:
       del _DEFER["jobs"][:]
+      _DEFER["wptrs"].clear()
 
 
 def flush_wgrads():
   """Runs every recorded weight gradient (their output tensors are valid afterwards)."""
   if _DEFER["jobs"]:
     jobs, _DEFER["jobs"] = _DEFER["jobs"], []
+    _DEFER["wptrs"].clear()
     K.gwgrad_multi(jobs)
 
 
@@ -211,10 +213,19 @@ class GConvFn(torch.autograd.Function):
              (spec.slope_in == 0.0 and gate_in.data_ptr() == x.data_ptr())) and
             K.gwgrad_groupable(spec.geom)):
         g = spec.geom
-        dw = torch.empty((g.kh, g.kw, g.Ci, g.Co), dtype=F32, device=x.device)
-        db = torch.empty((g.Co,), dtype=F32, device=x.device) if want_b else None
-        relu_in = gate_in is not None and spec.slope_in is not None
-        _DEFER["jobs"].append((g, x, dy16, relu_in, dw, db))
+        if w.data_ptr() in _DEFER["wptrs"]:
+          # a second contribution to a weight whose first one is still only recorded: autograd is
+          # about to ADD the two tensors, so the recorded ones are written now and this one is
+          # computed on the spot (the callers' static check makes this path unreachable
+          # for the example configs)
+          flush_wgrads()
+          dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
+        else:
+          _DEFER["wptrs"].add(w.data_ptr())
+          dw = torch.empty((g.kh, g.kw, g.Ci, g.Co), dtype=F32, device=x.device)
+          db = torch.empty((g.Co,), dtype=F32, device=x.device) if want_b else None
+          relu_in = gate_in is not None and spec.slope_in is not None
+          _DEFER["jobs"].append((g, x, dy16, relu_in, dw, db))
       else:
         dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
     return dx, dw, db, dr, None, None, None, None, None
@@ -470,10 +481,34 @@ def batch_norm_act(x, gamma, beta, mean=None, var=None, eps=1e-5, per_sample=Fal
   return BatchNormActFn.apply(x, gamma, beta, mean, var, eps, per_sample, relu, sync_fn, moving)
 
 
+class LayerNormBwdFn(torch.autograd.Function):
+  """dx (and dgamma, dbeta) of layer_norm as a differentiable node: only built under
+  create_graph=True, i.e. by a gradient penalty through D.layer_norm = True (resnet_ops.py:162-173
+  under penalty_lib.py:59-82).  Its backward is cg_layer_norm_bwd_bwd (closed form in cg_ln.hip)."""
+
+  @staticmethod
+  def forward(ctx, x3, dy3, mean, rstd, gamma, want_params):
+    dx, dg, db = K.layer_norm_bwd(x3, dy3, mean, rstd, gamma, want_params=want_params)
+    ctx.save_for_backward(x3, dy3, mean, rstd, gamma)
+    ctx.want_params = want_params
+    if not want_params:
+      dg = db = torch.zeros((gamma.numel(),), dtype=gamma.dtype, device=gamma.device)
+    ctx.mark_non_differentiable(dg, db)   # (the penalty's inner backward discards them)
+    return dx, dg, db
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, u, _ug, _ub):
+    x3, dy3, mean, rstd, gamma = ctx.saved_tensors
+    d_dy, d_x, d_g = K.layer_norm_bwd_bwd(x3, dy3, _bf16(u).reshape(x3.shape), mean, rstd, gamma,
+                                          want_dgamma=ctx.needs_input_grad[4])
+    return d_x, d_dy, None, None, d_g, None
+
+
 class LayerNormFn(torch.autograd.Function):
   """tf.contrib.layers.layer_norm (arch_ops.py:448-450): statistics per sample over (H, W, C),
-  gamma / beta per channel.  First-order (no example config combines it with a gradient penalty
-  whose second-order terms would cross it)."""
+  gamma / beta per channel.  Twice differentiable with respect to its input (LayerNormBwdFn): the
+  WGAN-GP discriminator normaliser."""
 
   @staticmethod
   def forward(ctx, x, gamma, beta, eps):
@@ -481,16 +516,24 @@ class LayerNormFn(torch.autograd.Function):
     x3 = x.contiguous().reshape(shape[0], -1, shape[-1])
     y3, mean, rstd = K.layer_norm_fwd(x3, gamma.contiguous(), beta.contiguous(), eps)
     ctx.shape = shape
-    ctx.save_for_backward(x3, mean, rstd, gamma)
+    # x itself (an input of the node), not the reshaped copy: under create_graph=True the second-order
+    # gradient with respect to x has to flow on into the layers below
+    ctx.save_for_backward(x, mean, rstd, gamma)
     return y3.reshape(shape)
 
   @staticmethod
-  @torch.autograd.function.once_differentiable
   def backward(ctx, dy):
-    x3, mean, rstd, gamma = ctx.saved_tensors
-    want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-    dx, dg, db = K.layer_norm_bwd(x3, _bf16(dy).reshape(x3.shape), mean, rstd, gamma.contiguous(),
-                                  want_params=want)
+    x, mean, rstd, gamma = ctx.saved_tensors
+    x3 = x.contiguous().reshape(ctx.shape[0], -1, ctx.shape[-1])
+    want = bool((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _SKIP_PARAM_GRADS[0])
+    if torch.is_grad_enabled():
+      dx, dg, db = LayerNormBwdFn.apply(x3, _bf16(dy).reshape(x3.shape), mean, rstd,
+                                        gamma.contiguous(), want)
+    else:
+      dx, dg, db = K.layer_norm_bwd(x3, _bf16(dy).reshape(x3.shape), mean, rstd, gamma.contiguous(),
+                                    want_params=want)
+    if not want:
+      dg = db = None
     return (dx.reshape(ctx.shape), dg if ctx.needs_input_grad[1] else None,
             db if ctx.needs_input_grad[2] else None, None)
 

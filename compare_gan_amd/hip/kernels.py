@@ -814,6 +814,21 @@ def layer_norm_bwd(x3, dy3, mean, rstd, gamma, want_params=True):
     return dx, dg, db
 
 
+def layer_norm_bwd_bwd(x3, dy3, u3, mean, rstd, gamma, want_dgamma=True):
+    """Second order of layer_norm_bwd: upstream u = dL/d(dx) -> (d_dy, d_x, d_gamma or None)."""
+    for t, nm in ((x3, "x"), (dy3, "dy"), (u3, "u")):
+        _req(t, BF16, nm)
+    N, M, C = x3.shape
+    d_dy = torch.empty_like(x3)
+    d_x = torch.empty_like(x3)
+    dg = torch.empty((C,), dtype=F32, device=x3.device) if want_dgamma else None
+    ws = _ws(lib().cg_layer_norm_bwd_bwd_workspace_bytes(N, C), x3)
+    check(lib().cg_layer_norm_bwd_bwd(_p(x3), _p(dy3), _p(u3), _p(mean), _p(rstd), _p(gamma), N, M, C,
+                                      _p(d_dy), _p(d_x), _p(dg), _p(ws), ws.numel(), _stream()),
+          "cg_layer_norm_bwd_bwd")
+    return d_dy, d_x, dg
+
+
 def colsum(x2):
     _req(x2, BF16, "x")
     rows, C = x2.shape

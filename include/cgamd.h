@@ -412,7 +412,8 @@ int cg_affine_f32_to_bf16(const float* x, float a, float b, void* y, int64_t n, 
  * sample over (H, W, C), gamma / beta per channel, variance_epsilon 1e-12; used when D.layer_norm =
  * True, resnet_ops.py:162-173):
  *   y[n,p,c] = ((x[n,p,c] - mean_n) * rstd_n) * gamma[c] + beta[c],  rstd_n = rsqrt(var_n + eps)
- * x, y, dy, dx bf16 [N, M, C] (C % 8 == 0); gamma, beta, dgamma, dbeta fp32 [C]; mean, rstd fp32 [N]
+ * x, y, dy, dx bf16 [N, M, C] (M * C % 8 == 0; C = 3 covers the RGB input of a first block); gamma,
+ * beta, dgamma, dbeta fp32 [C]; mean, rstd fp32 [N]
  * (written by the forward, read by the backward).  dgamma / dbeta may be NULL.
  * ws >= cg_layer_norm_bwd_workspace_bytes(N, C). */
 int cg_layer_norm_fwd(const void* x, int N, int64_t M, int C, const float* gamma, const float* beta,
@@ -421,6 +422,15 @@ size_t cg_layer_norm_bwd_workspace_bytes(int N, int C);
 int cg_layer_norm_bwd(const void* x, const void* dy, const float* mean, const float* rstd,
                       const float* gamma, int N, int64_t M, int C, void* dx, float* dgamma,
                       float* dbeta, void* ws, size_t ws_bytes, cgStream stream);
+/* Second order of the same backward (a gradient penalty through D.layer_norm = True,
+ * resnet_ops.py:162-173 under penalty_lib.py:59-82): for dx = cg_layer_norm_bwd(x, dy) and an
+ * upstream gradient u = dL/d(dx) [N, M, C] bf16 -> d_dy, d_x [N, M, C] bf16 and d_gamma [C] fp32
+ * (NULL to skip); ws >= cg_layer_norm_bwd_bwd_workspace_bytes(N, C). */
+size_t cg_layer_norm_bwd_bwd_workspace_bytes(int N, int C);
+int cg_layer_norm_bwd_bwd(const void* x, const void* dy, const void* u, const float* mean,
+                          const float* rstd, const float* gamma, int N, int64_t M, int C,
+                          void* d_dy, void* d_x, float* d_gamma, void* ws, size_t ws_bytes,
+                          cgStream stream);
 /* Column sums of a [rows, C] bf16 matrix into fp32 [C] (bias gradients).
  * ws >= cg_colsum_workspace_bytes(rows, C). */
 size_t cg_colsum_workspace_bytes(int64_t rows, int C);

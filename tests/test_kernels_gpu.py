@@ -238,7 +238,8 @@ def test_gconv_full_size_shapes(K, dev, case):
     _close_on_device(db, dy2.sum(dim=0), name + " dbias", 2e-4, 2e-4)
 
 
-@pytest.mark.parametrize("shape", [(3, 8, 8, 64), (2, 16, 16, 128), (4, 4, 4, 512), (2, 32, 32, 72)])
+@pytest.mark.parametrize("shape", [(3, 8, 8, 64), (2, 16, 16, 128), (4, 4, 4, 512), (2, 32, 32, 72),
+                                   (2, 16, 16, 3)])   # (RGB: the first block of a discriminator)
 def test_layer_norm(K, dev, shape):
     """cg_layer_norm_fwd / _bwd (arch_ops.py:448-450: tf.contrib.layers.layer_norm defaults --
     per-sample moments over (H, W, C), per-channel gamma / beta, variance_epsilon 1e-12) and the
@@ -269,6 +270,45 @@ def test_layer_norm(K, dev, shape):
     assert_close_bf16(dx, gx, "layer_norm dx", ulps=3.0, abs_rms=2.0 ** -7)
     assert_close_f32(dg, gg, "layer_norm dgamma", rtol=2e-3, abs_rms=2e-3)
     assert_close_f32(db, gb, "layer_norm dbeta", rtol=2e-3, abs_rms=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 8, 64), (2, 16, 16, 128), (2, 16, 16, 3)])
+def test_layer_norm_double_backward(K, dev, shape):
+    """Second order through layer_norm (cg_layer_norm_bwd_bwd): the gradient of a penalty on the
+    input-gradient, (||d sum(y * w) / dx||_2 - 1)^2 summed over the samples (penalty_lib.py:59-82
+    through resnet_ops.py:162-173 with D.layer_norm = True), with respect to x AND gamma, against
+    fp64 autograd of the oracle's restatement (create_graph=True on both sides)."""
+    from compare_gan_amd.hip import functional as Fn
+    from oracle import arch_ops as oops2
+    g = _gen(7 + sum(shape))
+    x64, xb = rand_bf16(shape, g, 1.5)
+    xb = (x64 + 0.25).float().to(BF16)
+    x64 = xb.double()
+    c = shape[-1]
+    gamma = (1.0 + 0.3 * torch.randn(c, generator=g)).float()
+    beta = (0.3 * torch.randn(c, generator=g)).float()
+    w64, wb = rand_bf16(shape, g)
+
+    def penalty(y, x, w):
+        (gx,) = torch.autograd.grad((y * w).sum(), x, create_graph=True)
+        nrm = gx.reshape(shape[0], -1).double().pow(2).sum(dim=1).add(1e-8).sqrt()
+        return ((nrm - 1.0) ** 2).sum()
+
+    vs = oops2.VarStore()
+    vs.vars["ln/beta"] = beta.double().requires_grad_(True)
+    vs.vars["ln/gamma"] = gamma.double().requires_grad_(True)
+    xr = x64.clone().requires_grad_(True)
+    pen_r = penalty(oops2.layer_norm(vs, xr, True, "ln"), xr, w64)
+    gx_r, gg_r = torch.autograd.grad(pen_r, [xr, vs.vars["ln/gamma"]])
+    xd = xb.to(dev).requires_grad_(True)
+    gd = gamma.to(dev).requires_grad_(True)
+    bd = beta.to(dev).requires_grad_(True)
+    pen = penalty(Fn.layer_norm(xd, gd, bd), xd, wb.to(dev))
+    assert abs(float(pen) - float(pen_r)) <= 2e-2 * max(1.0, abs(float(pen_r))), (float(pen), float(pen_r))
+    gx, gg = torch.autograd.grad(pen, [xd, gd])
+    from tests.gan_util import cosine, rel_l2
+    assert cosine(gx, gx_r) >= 0.999 and rel_l2(gx, gx_r) <= 0.05, (cosine(gx, gx_r), rel_l2(gx, gx_r))
+    assert cosine(gg, gg_r) >= 0.999 and rel_l2(gg, gg_r) <= 0.05, (cosine(gg, gg_r), rel_l2(gg, gg_r))
 
 
 def test_gwgrad_multi_grouped(K, dev):
