@@ -1081,7 +1081,10 @@ bool cg_pconv_geom_ok(const cgConvGeom* g) {
   return true;
 }
 
-static int pc_bn(const cgConvGeom* g) { return g->Co <= 64 ? 64 : 128; }
+static int pc_bn(const cgConvGeom* g) {
+  static const int force64 = pc_env("CGAMD_QCONV_BN64", 0);   // experiment: 64-channel tiles, 3 workgroups / CU
+  return (g->Co <= 64 || force64) ? 64 : 128;
+}
 
 bool cg_pconv_use(const cgConvGeom* g) {
   static const int enabled = pc_env("CGAMD_PCONV", 0);

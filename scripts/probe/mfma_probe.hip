@@ -9,6 +9,8 @@
 //   8  a workgroup barrier every 18 half-slices
 //  32  (with 4) the DMA pieces walk 8 MiB per workgroup of a 2 GiB buffer (HBM, never re-read) in the
 //      window pattern: 8 rows of 128 B at a 256-byte pitch per piece
+//  64  (with 4) the DMA pieces stream 8 MiB per workgroup of the 2 GiB buffer sequentially (full lines);
+//      template DMAX = pieces per wave and half-slice: how much does HBM traffic cost beside MFMA work?
 //  16  operands change between MFMAs (xor with the loop counter): register-resident operands that
 //      never toggle clock higher
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/probe/mfma_probe.hip -o scripts/probe/mfma_probe
@@ -53,7 +55,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int WIN = 77 * 1024;
 
-template <int MODE>
+template <int MODE, int DMAX = 1>
 __global__ __launch_bounds__(512, 2) void probe(const uint16_t* wts, uint32_t wbytes, const uint16_t* big,
                                                 int iters, float* sink) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WIN];
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void probe(const uint16_t* wts, uint32_t wb
   }
   __syncthreads();
   const i32x4_t rs_w = make_rsrc(wts, wbytes);
-  const uint32_t region = (MODE & 32) ? (8u << 20) : (1u << 20);
+  const uint32_t region = (MODE & (32 | 64)) ? (8u << 20) : (1u << 20);
   const i32x4_t rs_b = make_rsrc((const char*)big + (size_t)blockIdx.x * region, region + 4096u);
   const uint32_t dma_voff = (MODE & 32) ? (uint32_t)((lane >> 3) * 256 + (lane & 7) * 16) : (uint32_t)lane * 16u;
   const uint32_t dma_step = (MODE & 32) ? 2048u : 1024u;
@@ -107,11 +109,14 @@ __global__ __launch_bounds__(512, 2) void probe(const uint16_t* wts, uint32_t wb
           bload<(h2 & 1) * 2048 + (idx & 1) * 1024>(Bq[(h + 2) % 3][idx >> 1][idx & 1], lane16, rs_w,
                                                     soff_w + ((wave & 1) * 2 + (idx >> 1)) * 4096 * 18 + (h2 >> 1) * 4096);
       };
-      constexpr int allow = 4 + ((MODE & 4) ? 1 : 0);
+      constexpr int allow = 4 + ((MODE & 4) ? DMAX : 0);
       if (MODE & 2) wait4<allow>(Bq[h % 3][0][0], Bq[h % 3][0][1], Bq[h % 3][1][0], Bq[h % 3][1][1]);
       if (MODE & 4) {
-        dma16(rs_b, dma_voff, dma_off + wave * dma_step, lds0 + (buf ^ 1) * WIN + ((wave + 8 * (h % 9)) * 1024));
-        dma_off = (dma_off + 8 * dma_step) & (region - 1);
+#pragma unroll
+        for (int dx = 0; dx < DMAX; ++dx) {
+          dma16(rs_b, dma_voff, dma_off + wave * dma_step, lds0 + (buf ^ 1) * WIN + ((wave + 8 * ((h + dx) % 9)) * 1024));
+          dma_off = (dma_off + 8 * dma_step) & (region - 1);
+        }
       }
       static_for<0, 4>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -153,22 +158,24 @@ __global__ __launch_bounds__(512, 2) void probe(const uint16_t* wts, uint32_t wb
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int MODE>
+template <int MODE, int DMAX = 1>
 void run(const uint16_t* w, uint32_t wb, const uint16_t* big, float* sink, int iters) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  probe<MODE><<<256, 512>>>(w, wb, big, iters, sink);
+  probe<MODE, DMAX><<<256, 512>>>(w, wb, big, iters, sink);
   CK(hipDeviceSynchronize());
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0));
-    probe<MODE><<<256, 512>>>(w, wb, big, iters, sink);
+    probe<MODE, DMAX><<<256, 512>>>(w, wb, big, iters, sink);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
   }
   const double fl = 256.0 * 8 * iters * 16.0 * 2 * 32 * 32 * 16;
+  if (MODE & 4) printf("  [DMA x%d: %.2f GB moved, %.2f TB/s]  ", DMAX, 256.0 * 8 * iters * DMAX * 1024 / 1e9,
+                       256.0 * 8 * iters * DMAX * 1024 / best / 1e9);
   printf("mode %2d (%s%s%s%s%s): %.3f ms  %.0f TFLOP/s\n", MODE, (MODE & 1) ? "lds " : "", (MODE & 2) ? "wload " : "",
          (MODE & 4) ? "dma " : "", (MODE & 8) ? "barrier " : "", (MODE & 32) ? "hbm-window " : "", best, fl / best / 1e9);
 }
@@ -192,6 +199,15 @@ int main(int argc, char** argv) {
   run<7>(w, wb, big, sink, iters);
   run<39>(w, wb, big, sink, iters);
   run<47>(w, wb, big, sink, iters);
+  // is HBM traffic free beside MFMA work?  sequential full-line streaming, 0 / 1 / 2 / 4 KiB per wave and half-slice
+  run<0>(w, wb, big, sink, iters);
+  run<4 | 64, 1>(w, wb, big, sink, iters);
+  run<4 | 64, 2>(w, wb, big, sink, iters);
+  run<4 | 64, 4>(w, wb, big, sink, iters);
+  run<3>(w, wb, big, sink, iters);
+  run<7 | 64, 1>(w, wb, big, sink, iters);
+  run<7 | 64, 2>(w, wb, big, sink, iters);
+  run<7 | 64, 4>(w, wb, big, sink, iters);
   run<8>(w, wb, big, sink, iters);
   run<9>(w, wb, big, sink, iters);
   run<15>(w, wb, big, sink, iters);

@@ -18,9 +18,8 @@ sys.path.insert(0, ROOT)
 from tests import gan_util as U  # noqa: E402
 
 
-def run(dev, bindings, steps=2, bs=8, capture=True, not_unrolled=False):
-    gan, options, dataset = U.build_product("resnet_cifar10.gin", bs, dev, seed=3,
-                                            bindings=bindings)
+def run(dev, bindings, steps=2, bs=8, capture=True, not_unrolled=False, config="resnet_cifar10.gin"):
+    gan, options, dataset = U.build_product(config, bs, dev, seed=3, bindings=bindings)
     init = {k: v.detach().clone() for k, v in gan.store.vars.items()}
     nsub = 1 if not_unrolled else options["disc_iters"] + 1
     it = dataset.train_batches(bs * nsub, seed=11)
@@ -51,7 +50,12 @@ def main():
     # autograd-thread collectives (cross-replica batch norm backward) AFTER an earlier capture in
     # the same process made the group's watchdog thread query a captured event
     # (hipErrorCapturedEvent, torch 2.10 / RCCL 2.26); launchers capture once, group up first
-    if mode == "buckets_nu":
+    r5 = dict(config="resnet_lsun-bedroom128.gin", bs=2)
+    if mode == "buckets_r5":
+        # resnet_lsun-bedroom128.gin WITH its gradient penalty (the double backward runs inside the
+        # armed backward pass), batch 2, 128x128
+        init, base, gan = run(dev, local_bn, capture=True, **r5)
+    elif mode == "buckets_nu":
         # the NOT unrolled step (one sub-batch per call, host-side cadence of the G update: the reader
         # of the D step counter ADVICE r02 flagged) for 7 calls = one G update among them
         init, base, gan = run(dev, local_bn, steps=7, capture=False, not_unrolled=True)
@@ -93,6 +97,19 @@ def main():
         bad = [k for k in base if not torch.equal(base[k], eager[k])]
         assert not bad, "bucketed data parallel (eager) differs: %s" % bad[:5]
         del gan, gan2
+    if mode == "buckets_r5":
+        # the ResNet5 / WGAN-GP step under forced overlap, three buckets per
+        # network captured into the hipGraph, bit-identical to the single replica
+        from compare_gan_amd.gans import modular_gan as mg
+        mg._DP_OVERLAP, mg._DP_BUCKETS, mg._DP_BUCKET_MIN_BYTES = "1", 3, 1 << 16
+        _, forced, gan = run(dev, local_bn, capture=True, **r5)
+        stage("one-rank data parallel, ResNet5 + WGAN-GP, bucketed all-reduce captured, done")
+        for opt in (gan.d_opt, gan.g_opt):
+            assert opt._buckets is not None and len(opt._buckets) == 3, opt._buckets
+            assert sorted(opt.last_bucket_order) == [0, 1, 2], opt.last_bucket_order
+        bad = [k for k in base if not torch.equal(base[k], forced[k])]
+        assert not bad, "ResNet5 under forced overlap differs from single replica: %s" % bad[:5]
+        del gan
     if mode == "buckets_nu":
         from compare_gan_amd.gans import modular_gan as mg
         mg._DP_OVERLAP, mg._DP_BUCKETS, mg._DP_BUCKET_MIN_BYTES = "1", 3, 1 << 16

@@ -38,14 +38,15 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("mode", ["local", "buckets", "buckets_nu", "sync"])
+@pytest.mark.parametrize("mode", ["local", "buckets", "buckets_r5", "buckets_nu", "sync"])
 def test_force_dp_one_rank_group_matches_single_replica(mode):
     """mode local: per-replica batch norm, every variable bit-identical to the single replica;
     mode sync: cross-replica batch norm (SyncMoments) on the one-rank group, updates agree."""
     env = dict(os.environ)
     env.pop("CGAMD_FORCE_DP", None)
     env["MASTER_ADDR"] = "127.0.0.1"
-    env["MASTER_PORT"] = {"local": "29533", "buckets": "29537", "buckets_nu": "29539", "sync": "29535"}[mode]
+    env["MASTER_PORT"] = {"local": "29533", "buckets": "29537", "buckets_r5": "29541", "buckets_nu": "29539",
+                          "sync": "29535"}[mode]
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_force_worker.py"), mode],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
