@@ -411,12 +411,14 @@ def _conv_call(x, slope, w, bias, spec_geom, transpose, residual, out_f32, dx_f3
     return Fn.conv_pool(x, w, bias, residual, gate, spec, dx_f32, bt_pair)
   if (_FUSED_BN and not torch.is_grad_enabled() and not transpose and slope is None and
       bt_pair is not None and (pending_bn is not None or _EMIT_BN_STATS[0]) and
-      K.gconv_fused_rows(spec_geom) > 0):
+      (K.gconv_fused_rows(spec_geom) > 0 or
+       (pending_bn is not None and residual is None and   # (RGB outputs: the prologue only)
+        K.gconv_fused_prologue_supported(spec_geom)))):
     # no autograd graph: batch norm fused around the convolution (cg_gconv_fused)
     out, partials = K.gconv_fused(
         spec_geom, x.contiguous(), bt_pair[0], bias=bias, residual=residual, out_f32=out_f32,
         bn=None if pending_bn is None else pending_bn.bn_tuple(),
-        want_stats=_EMIT_BN_STATS[0] and not out_f32)
+        want_stats=_EMIT_BN_STATS[0] and not out_f32 and K.gconv_fused_rows(spec_geom) > 0)
     if partials is not None:
       out._cg_bn_partials = (partials, spec_geom.N * spec_geom.Ho * spec_geom.Wo,   # pylint: disable=protected-access
                              K.gconv_fused_phases(spec_geom))

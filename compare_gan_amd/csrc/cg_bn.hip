@@ -136,44 +136,67 @@ __global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_kernel(const float*
 // cg_gconv_fused stats_out) and group g owning t in [g * T / groups, (g + 1) * T / groups).
 // mean / var are [groups][C].  The moving averages take the groups' updates in order, as the
 // separate network calls they stand for would have applied them (arch_ops.py:105-114).
-__global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_groups_kernel(
+// Up to BN_GMAX groups are summed at once -- all their loads in flight, ONE barrier pair -- instead of
+// a load / barrier / combine round per group (5 groups: 13 us of serial latency per call).  Lanes
+// and summation order are those of bn_stats_final_kernel: a group's statistics are bit for bit the
+// ones of the separate call it stands for.
+constexpr int BN_GMAX = 6, BN_ZLG = BN_ZL;
+__global__ __launch_bounds__(32 * BN_ZLG) void bn_stats_final_groups_kernel(
     const float* __restrict__ part, int rows, int C, int groups, int phases, float inv_count,
     float* __restrict__ mean, float* __restrict__ var, float* __restrict__ mm,
     float* __restrict__ mv, float decay) {
-  __shared__ float sm[2][BN_ZL][33];
+  __shared__ float sm[2][BN_GMAX][BN_ZLG][33];
+  __shared__ float mo[2][BN_GMAX][32];
   const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int T = rows / phases, tg = T / groups, per_group = tg * phases;
   float mmc = 0.f, mvc = 0.f;
   if (mm && zl == 0 && c < C) { mmc = mm[c]; mvc = mv[c]; }
-  for (int g = 0; g < groups; ++g) {
-    float s = 0.f, q = 0.f;
+  for (int g0 = 0; g0 < groups; g0 += BN_GMAX) {
+    const int ng = min(BN_GMAX, groups - g0);
+    float s[BN_GMAX], q[BN_GMAX];
+#pragma unroll
+    for (int j = 0; j < BN_GMAX; ++j) s[j] = q[j] = 0.f;
     if (c < C) {
-#pragma unroll 4
-      for (int z = zl; z < per_group; z += BN_ZL) {
+      for (int z = zl; z < per_group; z += BN_ZLG) {
         const int ph = z / tg, t = z - ph * tg;
-        const int64_t row = (int64_t)ph * T + g * tg + t;
-        s += part[row * 2 * C + c];
-        q += part[row * 2 * C + C + c];
+#pragma unroll
+        for (int j = 0; j < BN_GMAX; ++j)
+          if (j < ng) {
+            const int64_t row = (int64_t)ph * T + (g0 + j) * tg + t;
+            s[j] += part[row * 2 * C + c];
+            q[j] += part[row * 2 * C + C + c];
+          }
       }
     }
+    __syncthreads();   // (the previous chunk's readers are done)
+#pragma unroll
+    for (int j = 0; j < BN_GMAX; ++j) {
+      sm[0][j][zl][cl] = s[j];
+      sm[1][j][zl][cl] = q[j];
+    }
     __syncthreads();
-    sm[0][zl][cl] = s;
-    sm[1][zl][cl] = q;
-    __syncthreads();
-    if (zl == 0 && c < C) {
+    if (zl < ng && c < C) {   // split-lane j finishes group g0 + j
       float ss = 0.f, qq = 0.f;
 #pragma unroll
-      for (int r = 0; r < BN_ZL; ++r) {
-        ss += sm[0][r][cl];
-        qq += sm[1][r][cl];
+      for (int r = 0; r < BN_ZLG; ++r) {
+        ss += sm[0][zl][r][cl];
+        qq += sm[1][zl][r][cl];
       }
       const float m = ss * inv_count;
       const float v = qq * inv_count - m * m;
-      mean[(int64_t)g * C + c] = m;
-      var[(int64_t)g * C + c] = v;
-      mmc -= (1.f - decay) * (mmc - m);
-      mvc -= (1.f - decay) * (mvc - v);
+      mean[(int64_t)(g0 + zl) * C + c] = m;
+      var[(int64_t)(g0 + zl) * C + c] = v;
+      mo[0][zl][cl] = m;
+      mo[1][zl][cl] = v;
+    }
+    if (mm) {   // (kernel-uniform) the moving averages take the groups' updates in order
+      __syncthreads();
+      if (zl == 0 && c < C)
+        for (int j = 0; j < ng; ++j) {
+          mmc -= (1.f - decay) * (mmc - mo[0][j][cl]);
+          mvc -= (1.f - decay) * (mvc - mo[1][j][cl]);
+        }
     }
   }
   if (mm && zl == 0 && c < C) { mm[c] = mmc; mv[c] = mvc; }
@@ -569,7 +592,7 @@ extern "C" int cg_bn_stats_groups(const void* x, int64_t rows, int C, int groups
                                                       (float*)ws);
   }
   CG_CHECK_LAUNCH("cg_bn_stats_groups(part)");
-  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(
+  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZLG, 0, st>>>(
       (const float*)ws, groups * spg, C, groups, 1, 1.0f / (float)grows, mean, var, moving_mean,
       moving_var, decay);
   CG_CHECK_LAUNCH("cg_bn_stats_groups(final)");
@@ -585,7 +608,7 @@ extern "C" int cg_bn_finalize_groups(const float* partials, int rows, int C, int
       ((moving_mean == nullptr) != (moving_var == nullptr)))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_finalize_groups: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(
+  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZLG, 0, st>>>(
       partials, rows, C, groups, phases, 1.0f / (float)count, mean, var, moving_mean, moving_var,
       decay);
   CG_CHECK_LAUNCH("cg_bn_finalize_groups");

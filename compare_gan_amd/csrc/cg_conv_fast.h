@@ -12,6 +12,8 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
 
 // halo-staged kernel for unit-stride <= 3x3 filters on >= 16x16 maps (cg_conv_halo.hip)
 bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in);
+bool cg_hconv_narrow(const cgConvGeom* g);   // Co < 8: scalar epilogue, no gate tensor / residual
+bool cg_hconv_narrow_ok(const cgConvGeom* g);   // ... and the geometry hconv_kernel<64, *, *, 3> covers
 void cg_hconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out,
                      int out_is_f32, const float* bias, const void* gate_in, const void* gate_out,
                      float slope_out, const void* residual, hipStream_t st);

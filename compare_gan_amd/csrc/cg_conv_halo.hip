@@ -104,9 +104,13 @@ __device__ __forceinline__ bf16x8_t hc_relu(bf16x8_t v) {
 
 // BN: output channels per workgroup (128 or 64); TWL: log2 of the tile width (5: 8x32, 4: 16x16)
 // FUSE: 0 = plain, 1 = batch-norm prologue / statistics epilogue, 2 = pooled epilogue (separate
-// instantiations: the fusions must not cost the plain kernel registers)
+// instantiations: the fusions must not cost the plain kernel registers), 3 = narrow outputs (Co < 8:
+// the RGB convolution that ends every generator, resnet_cifar.py:108-111, resnet5.py:90-93; BN = 64,
+// one 32-row MFMA tile whose K range the two channel-half waves split between them)
 template <int BN, bool RELU, int TWL, int FUSE>
 __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
+  constexpr bool NARROW = FUSE == 3;
+  static_assert(!NARROW || BN == 64, "narrow outputs use the 64-channel tile");
   constexpr int TW = 1 << TWL, TH = 256 >> TWL, PITCH = TW + 2;
   constexpr int TN = BN / 64;         // 32-channel MFMA tiles per wave (2 waves along channels)
   constexpr int BJ = BN / 64;         // weight staging pieces per wave and K-slice
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   };
 
   // fused batch-norm prologue: per channel block, the coefficients of its 64 channels go to LDS ...
-  const bool bnp = FUSE == 1 && a.bn_mean != nullptr;   // wave-uniform
+  const bool bnp = (FUSE == 1 || FUSE == 3) && a.bn_mean != nullptr;   // wave-uniform
   auto load_bn_table = [&](int cb) {
     if (bnp && tid < 64) {
       float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
@@ -300,7 +304,8 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   int bko[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
-    bko[kk] = (wn * (BN / 2) + frow) * 128 + (((kk * 2 + half) ^ ((frow >> 1) & 7)) << 4);
+    bko[kk] = ((NARROW ? 0 : wn * (BN / 2)) + frow) * 128 +
+              ((((NARROW ? 2 * wn + kk : kk) * 2 + half) ^ ((frow >> 1) & 7)) << 4);
 
   f32x16_t acc[2][TN];
 #pragma unroll
@@ -360,12 +365,14 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       aswz[i] = ((hx0[i] + si) >> 1) & 7;
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kq = 0; kq < (NARROW ? 2 : 4); ++kq) {
+      const int kk = kq;                             // index of bko[]
+      const int ka = NARROW ? 2 * wn + kq : kq;      // 16-channel step within the slice
       bf16x8_t af[2], bfr[TN];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         af[i] = *reinterpret_cast<const bf16x8_t*>(smem + abase[i] +
-                                                   (((kk * 2 + half) ^ aswz[i]) << 4));
+                                                   (((ka * 2 + half) ^ aswz[i]) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -407,6 +414,45 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   float bv[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = s1[e] = s2[e] = 0.f;
+  if constexpr (NARROW) {
+    // ---- narrow epilogue (Co < 8).  The two channel-half waves of a pixel group hold partial sums
+    // (over their halves of every 64-channel slice) of the same 32 accumulator rows, of which rows
+    // 0 .. Co-1 are real: lanes 0-31 hold rows 0-3 of pixel `frow` in acc[.][0][0..3], lanes 32-63
+    // rows 4-7.  The odd wave hands its four values over through LDS, the even wave adds, finishes
+    // (bias, leaky self-gate) and stores Co scalars per pixel.
+    __syncthreads();   // the halo / weight images are dead
+    float4* X = reinterpret_cast<float4*>(smem);   // [4 wm][2 i][64 lanes]
+    if (wn == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        X[(wm * 2 + i) * 64 + lane] = make_float4(acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3]);
+    }
+    __syncthreads();
+    if (wn == 0) {
+      const float osc = a.out_scale;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 o4 = X[(wm * 2 + i) * 64 + lane];
+        float v[4] = {acc[i][0][0] + o4.x, acc[i][0][1] + o4.y, acc[i][0][2] + o4.z, acc[i][0][3] + o4.w};
+        const int p = wm * 64 + i * 32 + frow;
+        const int y = p >> TWL, x = p & (TW - 1);
+        const int oy = ty * TH + y, ox = tx * TW + x;   // (U == 1)
+        const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = half * 4 + r;
+          if (c < a.Co) {
+            float t = v[r] * osc + (a.bias ? a.bias[c] : 0.f);
+            if (a.self_gate && !(t > 0.f)) t *= a.slope_out;
+            if (a.out_f32) reinterpret_cast<float*>(a.out)[o + c] = t;
+            else reinterpret_cast<bf16_t*>(a.out)[o + c] = f2bf(t);
+          }
+        }
+      }
+    }
+    HC_STAMP(4);
+    return;
+  }
   if (a.bias && co_ok) {
     const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
     const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
@@ -1911,10 +1957,15 @@ static void hconv_rw_launch_ex(const cgConvGeom* g, const void* in, const void* 
                                const void* gate_out, float slope_out, const void* residual,
                                int pool, int in_up, float out_scale, hipStream_t st);
 
-bool cg_hconv_geom_ok(const cgConvGeom* g) {
+static bool hc_geom_ok(const cgConvGeom* g, bool narrow) {
   if (g->S != 1 || (g->U != 1 && g->U != 2)) return false;
   if (g->kh > 3 || g->kw > 3) return false;
-  if (g->Ci % 32 != 0 || g->Co % 8 != 0 || g->Co < 64) return false;
+  if (g->Ci % 32 != 0) return false;
+  if (narrow) {   // RGB outputs: plain 3x3 only (hconv_kernel<64, *, *, 3>)
+    if (g->Co >= 8 || g->U != 1 || g->kh != 3 || g->kw != 3) return false;
+  } else if (g->Co % 8 != 0 || g->Co < 64) {
+    return false;
+  }
   if (g->Ho % g->U || g->Wo % g->U) return false;
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   if (Hp != g->Hin || Wp != g->Win) return false;   // 'SAME' unit-stride geometry only
@@ -1924,10 +1975,17 @@ bool cg_hconv_geom_ok(const cgConvGeom* g) {
   return true;
 }
 
+bool cg_hconv_geom_ok(const cgConvGeom* g) { return hc_geom_ok(g, false); }
+
+bool cg_hconv_narrow(const cgConvGeom* g) { return g->Co < 8; }
+bool cg_hconv_narrow_ok(const cgConvGeom* g) { return hc_geom_ok(g, true); }
+
 bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in) {
   static const int enabled = hc_env("CGAMD_HCONV", 1);
+  static const int narrow_on = hc_env("CGAMD_HCONV_NARROW", 1);
   static const int min_wgs = hc_env("CGAMD_HCONV_MIN", 100);
-  if (!enabled || !cg_hconv_geom_ok(g)) return false;
+  const bool narrow = g->Co < 8;
+  if (!enabled || (narrow && !narrow_on) || !hc_geom_ok(g, narrow)) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   const int bn = hc_pick_bn(g);
@@ -2026,6 +2084,8 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.tdbg = g_hconv_tdbg;
 #endif
   const bool relu = gate_in != nullptr && a.bn_mean == nullptr;   // the BN prologue includes the ReLU
+  const bool narrow = g->Co < 8;
+  // (narrow outputs: cg_gconv only comes here without gate tensor / residual; no fused form)
   if (hup) {
     a.tiles_x = g->Win / HU_TW;
     a.tiles_y = g->Hin / HU_TH;
@@ -2053,7 +2113,8 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   } while (0)
 #define HC_LAUNCH(BN_, TWL_)                                                             \
   do {                                                                                   \
-    if (a.pool) HC_LAUNCH2(BN_, TWL_, 2);                                                \
+    if (BN_ == 64 && narrow) HC_LAUNCH2(64, TWL_, 3);                                    \
+    else if (a.pool) HC_LAUNCH2(BN_, TWL_, 2);                                           \
     else if (a.bn_mean || a.stats) HC_LAUNCH2(BN_, TWL_, 1);                             \
     else HC_LAUNCH2(BN_, TWL_, 0);                                                       \
   } while (0)

@@ -223,13 +223,35 @@ __global__ void colsum_part_kernel(const bf16_t* __restrict__ x, int64_t rows, i
     part[(int64_t)blockIdx.y * C + c] = sm[0][l] + sm[1][l] + sm[2][l] + sm[3][l];
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int splits, int C,
-                                    float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one block per 64 columns: 16 split-lanes per column walk the partials (four loads in flight each;
+// one lane per column walking up to 512 splits alone was 16 us of load latency), LDS combines them
+// in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part,
+                                                            int splits, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float sm[16][64];
+  const int l = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * C + c];
-  out[c] = s;
+  if (c < C) {
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = zl;
+    for (; z + 48 < splits; z += 64) {
+      const float a0 = part[(int64_t)z * C + c], a1 = part[(int64_t)(z + 16) * C + c];
+      const float a2 = part[(int64_t)(z + 32) * C + c], a3 = part[(int64_t)(z + 48) * C + c];
+      s += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; z < splits; z += 16) s += part[(int64_t)z * C + c];
+    s = (s + s1) + (s2 + s3);
+  }
+  sm[zl][l] = s;
+  __syncthreads();
+  if (zl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][l];
+    out[c] = t;
+  }
 }
 inline int colsum_splits(int64_t rows, int C) {
   const int ct = cdiv(C, 64);
@@ -703,7 +725,7 @@ extern "C" int cg_colsum(const void* x, int64_t rows, int C, float* out, void* w
   hipStream_t st = (hipStream_t)stream;
   colsum_part_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, rows, C, rps, (float*)ws);
   CG_CHECK_LAUNCH("cg_colsum(part)");
-  colsum_final_kernel<<<cdiv(C, 256), 256, 0, st>>>((const float*)ws, splits, C, out);
+  colsum_final_kernel<<<cdiv(C, 64), 1024, 0, st>>>((const float*)ws, splits, C, out);
   CG_CHECK_LAUNCH("cg_colsum(final)");
   return CG_OK;
 }

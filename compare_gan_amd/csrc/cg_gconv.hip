@@ -882,7 +882,8 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
     CG_CHECK_LAUNCH("cg_gconv(halo-rw)");
     return CG_OK;
   }
-  if (cg_hconv_supported(g, in, gate_in, slope_in)) {
+  if (cg_hconv_supported(g, in, gate_in, slope_in) &&
+      !(cg_hconv_narrow(g) && ((gate_out && gate_out != out) || residual))) {
     hipStream_t fst = (hipStream_t)stream;
     cg_hconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fst);
     CG_CHECK_LAUNCH("cg_gconv(halo)");
@@ -956,6 +957,11 @@ extern "C" int cg_gconv_fused_rows(const cgConvGeom* g) {
   return cg_hconv_stats_rows(g);
 }
 
+extern "C" int cg_gconv_fused_prologue_supported(const cgConvGeom* g) {
+  if (!g || check_geom(g, "cg_gconv_fused_prologue_supported")) return 0;
+  return (cg_hconv_narrow(g) ? cg_hconv_narrow_ok(g) : cg_hconv_geom_ok(g)) ? 1 : 0;
+}
+
 extern "C" int cg_gconv_pool_supported(const cgConvGeom* g) {
   if (!g || check_geom(g, "cg_gconv_pool_supported")) return 0;
   if ((g->Ho & 1) || (g->Wo & 1) || g->U != 1) return 0;
@@ -992,7 +998,13 @@ extern "C" int cg_gconv_fused(const cgConvGeom* g, const void* in, const void* b
     CG_CHECK_LAUNCH("cg_gconv_fused(wstem)");
     return CG_OK;
   }
-  if (!cg_hconv_geom_ok(g)) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: geometry not covered");
+  if (cg_hconv_narrow(g)) {
+    if (!cg_hconv_narrow_ok(g)) CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: geometry not covered");
+    if (fu->stats_out || fu->pool_out || fu->in_up || residual || (gate_out && gate_out != out))
+      CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: fewer than 8 output channels: batch-norm prologue only");
+  } else if (!cg_hconv_geom_ok(g)) {
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_gconv_fused: geometry not covered");
+  }
   cg_hconv_launch_fused(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
                         fu, fst);
   CG_CHECK_LAUNCH("cg_gconv_fused");

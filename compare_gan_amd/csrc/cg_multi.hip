@@ -156,7 +156,12 @@ struct ScaleChunk {
   int blk[MAXT + 1];
   int cnt;
 };
-constexpr int EW_CHUNK = 8192;   // elements per block
+// Elements per block.  A block of 256 threads moves its chunk as 16-byte accesses, four in flight per
+// lane (the round-3 form -- 8192 elements per block, 4-byte accesses, 32 dependent trips -- ran a
+// 1 M-parameter network on 134 workgroups at 11-19 us per pass: profiles/r04_cifar_kernel_stats.csv)
+constexpr int EW_CHUNK = 4096;
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __global__ __launch_bounds__(256) void scale_multi_kernel(ScaleChunk c) {
   const int it = find_item(c.blk, c.cnt, blockIdx.x);
@@ -165,6 +170,17 @@ __global__ __launch_bounds__(256) void scale_multi_kernel(ScaleChunk c) {
   const float s = c.sigma[it][1];
   const float* __restrict__ w = c.w[it];
   float* __restrict__ o = c.out[it];
+  if (aligned16(w) && aligned16(o)) {
+    const int64_t vend = base + ((end - base) & ~3ll);
+#pragma unroll 4
+    for (int64_t i = base + threadIdx.x * 4; i < vend; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(w + i);
+      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      *reinterpret_cast<float4*>(o + i) = v;
+    }
+    for (int64_t i = vend + threadIdx.x; i < end; i += 256) o[i] = w[i] * s;
+    return;
+  }
   for (int64_t i = base + threadIdx.x; i < end; i += 256) o[i] = w[i] * s;
 }
 
@@ -190,30 +206,57 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_multi_kernel(SNBwdChunk c) {
   const float* __restrict__ x = c.dwbar[it];
   const float* __restrict__ w = c.w[it];
   float s = 0.f;
-  for (int64_t i = base + threadIdx.x; i < end; i += 256) s += x[i] * w[i];
+  if (aligned16(x) && aligned16(w)) {
+    const int64_t vend = base + ((end - base) & ~3ll);
+#pragma unroll 4
+    for (int64_t i = base + threadIdx.x * 4; i < vend; i += 1024) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i);
+      const float4 q = *reinterpret_cast<const float4*>(w + i);
+      s += (a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w);
+    }
+    for (int64_t i = vend + threadIdx.x; i < end; i += 256) s += x[i] * w[i];
+  } else {
+    for (int64_t i = base + threadIdx.x; i < end; i += 256) s += x[i] * w[i];
+  }
   s = block_sum_256(s, sm4);
   if (threadIdx.x == 0) c.part[it][b] = s;
 }
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_multi_kernel(SNBwdChunk c) {
-  __shared__ float s_coef;
+  __shared__ float sm4[4];
   const int it = find_item(c.blk, c.cnt, blockIdx.x);
   const int b = blockIdx.x - c.blk[it];
   const int nb = c.blk[it + 1] - c.blk[it];
   const float inv = 1.f / c.sigma[it][0];
-  if (threadIdx.x == 0) {
-    float dot = 0.f;   // fixed order: deterministic
-    for (int i = 0; i < nb; ++i) dot += c.part[it][i];
-    s_coef = dot * inv;   // <dwbar, w_bar>
-  }
-  __syncthreads();
-  const float coef = s_coef;
+  // <dwbar, w>: every block sums the item's partials in the same fixed order (deterministic)
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) dot += c.part[it][i];
+  dot = block_sum_256(dot, sm4);
+  const float coef = dot * inv;   // <dwbar, w_bar>
   const int Co = c.Co[it];
   const int64_t base = (int64_t)b * EW_CHUNK, end = min(c.n[it], base + EW_CHUNK);
   const float* __restrict__ x = c.dwbar[it];
   const float* __restrict__ ak = c.a_k[it];
   const float* __restrict__ bc = c.b_co[it];
   float* __restrict__ dw = c.dw[it];
+  if ((Co & 3) == 0 && aligned16(x) && aligned16(dw) && aligned16(bc)) {
+    // four consecutive elements share their row k (Co % 4 == 0; n = K * Co)
+#pragma unroll 4
+    for (int64_t i = base + threadIdx.x * 4; i < end; i += 1024) {
+      const int64_t k = i / Co;
+      const int co = (int)(i - k * Co);
+      const float4 a = *reinterpret_cast<const float4*>(x + i);
+      const float4 q = *reinterpret_cast<const float4*>(bc + co);
+      const float ck = coef * ak[k];
+      float4 r;
+      r.x = (a.x - ck * q.x) * inv;
+      r.y = (a.y - ck * q.y) * inv;
+      r.z = (a.z - ck * q.z) * inv;
+      r.w = (a.w - ck * q.w) * inv;
+      *reinterpret_cast<float4*>(dw + i) = r;
+    }
+    return;
+  }
   for (int64_t i = base + threadIdx.x; i < end; i += 256) {
     const int64_t k = i / Co;
     const int co = (int)(i - k * Co);
@@ -252,6 +295,9 @@ __global__ __launch_bounds__(256) void prep_fwd_multi_kernel(PrepChunk c) {
   }
 }
 
+// backward image bt[ci][(T-1-t) * Co + co] = w[t][ci][co] (row pitch Kbp): the rows of the image are
+// runs of Co consecutive source elements, so a thread converts 8 consecutive outputs from two
+// 16-byte loads and stores them as one (Co % 8 == 0: the 8 share their tap; one division per 8)
 __global__ __launch_bounds__(256) void prep_bwd_multi_kernel(PrepChunk c) {
   const int it = find_item(c.blk_b, c.cnt, blockIdx.x);
   const int b = blockIdx.x - c.blk_b[it];
@@ -261,6 +307,20 @@ __global__ __launch_bounds__(256) void prep_bwd_multi_kernel(PrepChunk c) {
   const int64_t base = (int64_t)b * EW_CHUNK, end = min(total, base + EW_CHUNK);
   const float* __restrict__ w = c.w[it];
   bf16_t* __restrict__ bt = c.bt_bwd[it];
+  if ((Co & 7) == 0 && aligned16(w) && aligned16(bt)) {   // (then Kbp = T * Co, no padding columns)
+#pragma unroll 2
+    for (int64_t i = base + threadIdx.x * 8; i < end; i += 2048) {
+      const int ci = (int)(i / Kbp);
+      const int kk = (int)(i - (int64_t)ci * Kbp);
+      const int tt = kk / Co, co = kk - tt * Co;
+      const float* src = w + ((int64_t)(T - 1 - tt) * Ci + ci) * Co + co;
+      const float4 lo = *reinterpret_cast<const float4*>(src);
+      const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      *reinterpret_cast<uint4*>(bt + i) = pack8_bf16(v);
+    }
+    return;
+  }
   for (int64_t i = base + threadIdx.x; i < end; i += 256) {
     const int ci = (int)(i / Kbp);
     const int kk = (int)(i - (int64_t)ci * Kbp);
@@ -287,6 +347,14 @@ __global__ __launch_bounds__(256) void flatten_multi_kernel(FlatChunk c, float* 
   const int64_t end = min(c.n[it], base + EW_CHUNK);
   const float* __restrict__ s = c.src[it];
   float* __restrict__ d = flat + c.off[it];
+  if (aligned16(s) && aligned16(d)) {
+    const int64_t vend = base + ((end - base) & ~3ll);
+#pragma unroll 4
+    for (int64_t i = base + threadIdx.x * 4; i < vend; i += 1024)
+      *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(s + i);
+    for (int64_t i = vend + threadIdx.x; i < end; i += 256) d[i] = s[i];
+    return;
+  }
   for (int64_t i = base + threadIdx.x; i < end; i += 256) d[i] = s[i];
 }
 

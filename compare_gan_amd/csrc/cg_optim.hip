@@ -265,30 +265,45 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const cgAdamEntry* __re
   __shared__ int s_e;
   const int64_t chunk = blockIdx.x / ADAM_SPLIT;
   const int sub = blockIdx.x % ADAM_SPLIT;
+  if (threadIdx.x == 0) s_e = find_entry(table, n_entries, chunk);
+  __syncthreads();
+  const cgAdamEntry e = table[s_e];
+  const int64_t base = (chunk - e.chunk_begin) * CG_ADAM_CHUNK + (int64_t)sub * ADAM_SUB;
+  const int64_t end = min(e.n, base + ADAM_SUB);
+  const uintptr_t bits = (uintptr_t)e.grad | (uintptr_t)e.m | (uintptr_t)e.v | (uintptr_t)e.param |
+                         (uintptr_t)e.ema;
+  const bool vec = (bits & 15) == 0 && base < end;
+  const int64_t vend = base + ((end - base) & ~(int64_t)3);
+  // the first trip's operands leave before the step size is known: thread 0's two fp64 pow() calls
+  // (a few microseconds of dependent arithmetic) run under the load latency instead of in front of it
+  const int64_t ifirst = base + 4 * (int64_t)threadIdx.x;
+  const bool pre = vec && ifirst < vend;
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = g4, v4 = g4, p4 = g4;
+  if (pre) {
+    g4 = *reinterpret_cast<const float4*>(e.grad + ifirst);
+    m4 = *reinterpret_cast<const float4*>(e.m + ifirst);
+    v4 = *reinterpret_cast<const float4*>(e.v + ifirst);
+    p4 = *reinterpret_cast<const float4*>(e.param + ifirst);
+  }
   if (threadIdx.x == 0) {
     const int64_t t0 = step ? *step : 0;
     const double t = (double)(t0 + 1);
     s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
     const float d = (t0 >= ema_start) ? ema_decay : 0.f;
     s_omd = 1.f - d;
-    s_e = find_entry(table, n_entries, chunk);
   }
   __syncthreads();
-  const cgAdamEntry e = table[s_e];
   const float lrt = s_lrt, omd = s_omd;
-  const int64_t base = (chunk - e.chunk_begin) * CG_ADAM_CHUNK + (int64_t)sub * ADAM_SUB;
-  const int64_t end = min(e.n, base + ADAM_SUB);
   if (base >= end) return;
-  const uintptr_t bits = (uintptr_t)e.grad | (uintptr_t)e.m | (uintptr_t)e.v | (uintptr_t)e.param |
-                         (uintptr_t)e.ema;
   int64_t i0 = base;
-  if ((bits & 15) == 0) {
-    const int64_t vend = base + ((end - base) & ~(int64_t)3);
-    for (int64_t i = base + 4 * (int64_t)threadIdx.x; i < vend; i += 1024) {
-      const float4 g4 = *reinterpret_cast<const float4*>(e.grad + i);
-      float4 m4 = *reinterpret_cast<const float4*>(e.m + i);
-      float4 v4 = *reinterpret_cast<const float4*>(e.v + i);
-      float4 p4 = *reinterpret_cast<const float4*>(e.param + i);
+  if (vec) {
+    for (int64_t i = ifirst; i < vend; i += 1024) {
+      if (i != ifirst) {
+        g4 = *reinterpret_cast<const float4*>(e.grad + i);
+        m4 = *reinterpret_cast<const float4*>(e.m + i);
+        v4 = *reinterpret_cast<const float4*>(e.v + i);
+        p4 = *reinterpret_cast<const float4*>(e.param + i);
+      }
       adam_one(g4.x * grad_scale, m4.x, v4.x, p4.x, beta1, beta2, eps, lrt);
       adam_one(g4.y * grad_scale, m4.y, v4.y, p4.y, beta1, beta2, eps, lrt);
       adam_one(g4.z * grad_scale, m4.z, v4.z, p4.z, beta1, beta2, eps, lrt);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "cg_weight_prep_elems": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
     "cg_gconv_fused_rows": (c_int, [GP]),
+    "cg_gconv_fused_prologue_supported": (c_int, [GP]),
     "cg_gconv_fused_phases": (c_int, [GP]),
     "cg_gconv_fused": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp, vp]),
     "cg_gconv_pool_supported": (c_int, [GP]),

@@ -152,6 +152,12 @@ def gconv_fused_rows(geom):
     return int(lib().cg_gconv_fused_rows(ctypes.byref(geom)))
 
 
+def gconv_fused_prologue_supported(geom):
+    """True when gconv_fused covers `geom` with the batch-norm prologue alone (also the RGB-output
+    convolutions, for which gconv_fused_rows is 0: no statistics epilogue there)."""
+    return bool(lib().cg_gconv_fused_prologue_supported(ctypes.byref(geom)))
+
+
 def gconv_pool_supported(geom):
     """True when the pooled-output convolution (gconv_fused(pool=True)) and its pooled-gradient
     weight gradient (gwgrad_pooled) cover `geom`."""

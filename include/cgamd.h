@@ -129,7 +129,9 @@ int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, 
  *     sum(out) in [0,Co) and sum(out^2) in [Co,2Co) over a disjoint part of the output pixels (of
  *     the values as stored, i.e. after the bf16 rounding); cg_bn_finalize reduces them.
  * cg_gconv_fused_rows returns 0 when the geometry is not covered by the fused kernel (unit-stride
- * <= 3x3 filters on >= 16x16 maps, Ci % 32 == 0): call cg_gconv and the cg_bn_* kernels then. */
+ * <= 3x3 filters on >= 16x16 maps, Ci % 32 == 0): call cg_gconv and the cg_bn_* kernels then.
+ * Fewer than 8 output channels (the RGB convolution that ends a generator, resnet_cifar.py:108-111):
+ * the prologue only -- stats_out, pool_out, in_up, residual and a gate tensor are refused. */
 typedef struct {
   const float* bn_mean;
   const float* bn_var;
@@ -153,6 +155,10 @@ typedef struct {
   int32_t bn_stat_group;
 } cgConvFusion;
 int cg_gconv_fused_rows(const cgConvGeom* geom);
+/* 1 when cg_gconv_fused covers `geom` with the batch-norm prologue alone (bn_mean set; no stats_out,
+ * pool_out, in_up, residual, gate tensor): every geometry with cg_gconv_fused_rows > 0, and 3x3
+ * convolutions to fewer than 8 output channels on the same maps. */
+int cg_gconv_fused_prologue_supported(const cgConvGeom* geom);
 /* Layout of those rows for cg_bn_finalize: [phases][rows / phases]; U*U when the output phases of a
  * zero-inserted input run as separate workgroups, 1 when one workgroup covers all of them (0 when
  * the geometry is not covered). */

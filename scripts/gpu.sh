@@ -16,6 +16,8 @@
 #   ab VAR V1,V2,... LEG [TAG]      the same build under VAR=V1, VAR=V2, ... on one box (boxes of the
 #                                   pool differ by +-15 % in clocks): bench.py --legs LEG, prints the
 #                                   headline step, the leg's step and its per-family kernel times
+#   ablib LEGS [TAG]                lib/libcgamd_prev.so (a build of an earlier commit, made by hand) against
+#                                   lib/libcgamd.so through CGAMD_LIB_PATH, alternating twice: bench.py --legs LEGS
 #   pconv [TAG]                     persistent convolution kernel (cg_conv_pers.hip): parity under its forced
 #                                   variants + per-shape timings with the kernel off / on / in its 2x4 wave layout
 #   dp [TAG]                        CGAMD_FORCE_DP=1: the data-parallel path on a one-rank RCCL group
@@ -95,6 +97,15 @@ case $task in
       env $VAR=$v timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fid --no-roofline --legs $LEG \
         > gpurun_out/${TAG}_${VAR}_$v.json 2> gpurun_out/${TAG}_${VAR}_$v.err
       echo "$VAR=$v: $(leg_summary gpurun_out/${TAG}_${VAR}_$v.json $LEG)"
+    done ;;
+  ablib) LEGS=$1; TAG=${2:-ablib}   # previous vs current library, alternating (A B A B) on one box
+    for rep in 1 2; do
+      for which in prev cur; do
+        LIBP=$R/compare_gan_amd/lib/libcgamd.so; [ $which = prev ] && LIBP=$R/compare_gan_amd/lib/libcgamd_prev.so
+        CGAMD_LIB_PATH=$LIBP timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fid --no-roofline \
+          --legs $LEGS > gpurun_out/${TAG}_${which}$rep.json 2> gpurun_out/${TAG}_${which}$rep.err
+        for L in ${LEGS//,/ }; do echo "$which $rep: $(leg_summary gpurun_out/${TAG}_${which}$rep.json $L)"; done
+      done
     done ;;
   pconv) TAG=${1:-pconv}   # the persistent kernel: parity under its forced variants, then per-shape A/B
     KSEL="(test_gconv_forward_adjoint_wgrad and (pc_ or fast_big or hc_)) or test_gconv_gates_residual or (test_conv_pool_fused and not full_size) or (test_gconv_fused_batch_norm and not full_size) or test_gconv_fused_statistics_groups"

@@ -93,6 +93,10 @@ CONV_CASES = [
     ("hc_up32_c64", 1, 32, 32, 64, 64, 3, 1, 2),
     ("hc_1x1", 2, 32, 32, 128, 136, 1, 1, 1),
     ("hc_c96", 2, 32, 32, 96, 160, 3, 1, 1),
+    # RGB outputs through the halo-staged kernel (scalar epilogue of its 64-channel tile): 8x32 tiles
+    # with two channel blocks, 16x16 tiles
+    ("hc_rgb_out_32", 26, 32, 32, 128, 3, 3, 1, 1),
+    ("hc_rgb_out_16", 100, 16, 16, 64, 3, 3, 1, 1),
     # persistent deep-pipelined kernel (cg_conv_pers.hip; selected for these small grids by the
     # "pconv_*" variants below): several 16x32 tiles per image, three channel blocks, three
     # out-channel tiles with a ragged last one
@@ -198,6 +202,8 @@ FULL_SIZE_CASES = [
     ("resnet128_D_64x64", 128, 64, 64, 128, 128),
     ("resnet128_D_128x128", 128, 128, 128, 64, 64),
     ("resnet128_D_4x4", 128, 4, 4, 512, 512),
+    ("cifar_G_rgb_out", 64, 32, 32, 256, 3),
+    ("resnet128_G_rgb_out", 32, 128, 128, 64, 3),
 ]
 
 
@@ -511,6 +517,9 @@ def test_gconv_gates_residual(K, dev, slope, size):
     ("cbn_1x1", 2, 32, 32, 64, 128, 1, 1, True, True),
     ("cbn_c96", 2, 16, 16, 96, 64, 3, 1, True, False),
     ("bn_up_c160_res", 1, 16, 32, 160, 96, 3, 2, False, True),
+    # RGB outputs (hconv_kernel<64, *, *, 3>): the prologue only, 8x32 and 16x16 tiles
+    ("bn_rgb_out", 2, 32, 32, 128, 3, 3, 1, False, False),
+    ("cbn_rgb_out_c96", 3, 16, 16, 96, 3, 3, 1, True, False),
 ], ids=lambda c: c[0])
 def test_gconv_fused_batch_norm(K, dev, case):
     """cg_gconv_fused: relu(batch_norm(x)) applied in LDS in front of the convolution
@@ -530,7 +539,7 @@ def test_gconv_fused_batch_norm(K, dev, case):
     mean = x64.mean(dim=(0, 1, 2)).float()
     var = (x64.pow(2).mean(dim=(0, 1, 2)) - x64.mean(dim=(0, 1, 2)).pow(2)).float()
     geom = K.geom_conv_same(N, H, W, Ci, Co, k, k, 1, up)
-    assert K.gconv_fused_rows(geom) > 0
+    assert K.gconv_fused_prologue_supported(geom) and (K.gconv_fused_rows(geom) > 0) == (Co >= 8)
     bt_f, _ = K.weight_prep(wb.to(torch.float32).to(dev))
     res64, resb = rand_bf16((N, geom.Ho, geom.Wo, Co), g)
     # oracle: fp32 statistics as given, normalisation in fp64, bf16 storage of the activation
@@ -544,10 +553,17 @@ def test_gconv_fused_batch_norm(K, dev, case):
     out, part = K.gconv_fused(geom, xb.to(dev), bt_f, bias=bias.to(dev),
                               residual=resb.to(dev) if with_res else None,
                               bn=(mean.to(dev), var.to(dev), gamma.to(dev), beta.to(dev), eps,
-                                  per_sample), want_stats=True)
+                                  per_sample), want_stats=Co >= 8)
     # the activation is rounded to bf16 before the MFMA: a value on a rounding boundary may land on
     # the other side than in the fp64 oracle -> 2^-8 relative noise on single products
     assert_close_bf16(out, ref, name + " fused fwd", ulps=3.0, abs_rms=2.0 ** -6)
+    if Co < 8:   # no statistics epilogue on narrow outputs: refused, not silently dropped
+        assert part is None
+        with pytest.raises(Exception, match="not covered"):
+            K.gconv_fused(geom, xb.to(dev), bt_f, bias=bias.to(dev),
+                          bn=(mean.to(dev), var.to(dev), gamma.to(dev), beta.to(dev), eps, per_sample),
+                          want_stats=True)
+        return
     # statistics of the STORED values
     stored = out.detach().float().cpu().double()
     cnt = N * geom.Ho * geom.Wo

@@ -226,7 +226,12 @@ def test_train_steps_resnet_cifar(dev, bsz):
         print("step", step, "d", d_p, d_o, "g", float(out["g_loss"]), g_o)
         for a, b in zip(d_p, d_o):
             assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (step, a, b)
-        assert abs(float(out["g_loss"]) - g_o) <= 2e-2 * max(1.0, abs(g_o)), step
+        # the generator loss is taken AFTER the five sign-like Adam updates of D: weights whose gradient
+        # is rounding noise move by +-lr on either side in product and oracle, and D(G(z)) feels it.
+        # Measured on one box with two builds that differ only in the summation order of a few fp32
+        # reductions: step 0 -1.6 % with both, step 1 -0.3 % with one and -2.1 % with the other
+        # (-2.9 % with the batch-norm fusion off), while the D losses stay within 1.5e-3
+        assert abs(float(out["g_loss"]) - g_o) <= 4e-2 * max(1.0, abs(g_o)), step
         # the step's weight UPDATE against the oracle's.  Adam's first updates are sign-like, so a
         # weight whose gradient is ~0 (a bias in front of batch norm) moves by +-lr at random on
         # either side: per element the two updates may differ by 2 lr per sub-step, and the
