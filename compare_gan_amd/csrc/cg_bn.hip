@@ -90,19 +90,20 @@ __global__ __launch_bounds__(256) void bn_stats_part_scalar_kernel(const bf16_t*
     p[C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
   }
 }
-// one block per 32 channels: BN_ZL split-lanes per channel sum the partials (4 loads in flight each:
-// a short serial walk, the finalize is pure load latency), LDS combines them.
+// one block per BN_CL channels: BN_ZL split-lanes per channel sum the partials (4 loads in flight
+// each: a short serial walk, the finalize is pure load latency), LDS combines them.  16 channels x 64
+// lanes: a 256-channel layer runs on 16 workgroups with 4-8 trips per lane (32 x 32 left it on 8).
 // Optionally folds the moving-average update m <- m - (1-decay)(m - batch) (arch_ops.py:105-114).
-constexpr int BN_ZL = 32;
-__global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_kernel(const float* __restrict__ part,
+constexpr int BN_CL = 16, BN_ZL = 64;
+__global__ __launch_bounds__(BN_CL * BN_ZL) void bn_stats_final_kernel(const float* __restrict__ part,
                                                              int splits, int C, float inv_rows,
                                                              float* __restrict__ mean,
                                                              float* __restrict__ var,
                                                              float* __restrict__ mm,
                                                              float* __restrict__ mv, float decay) {
-  __shared__ float sm[2][BN_ZL][33];
-  const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float sm[2][BN_ZL][BN_CL + 1];
+  const int cl = threadIdx.x & (BN_CL - 1), zl = threadIdx.x / BN_CL;
+  const int c = blockIdx.x * BN_CL + cl;
   float s = 0.f, q = 0.f;
   if (c < C) {
 #pragma unroll 4
@@ -140,15 +141,15 @@ __global__ __launch_bounds__(32 * BN_ZL) void bn_stats_final_kernel(const float*
 // a load / barrier / combine round per group (5 groups: 13 us of serial latency per call).  Lanes
 // and summation order are those of bn_stats_final_kernel: a group's statistics are bit for bit the
 // ones of the separate call it stands for.
-constexpr int BN_GMAX = 6, BN_ZLG = BN_ZL;
-__global__ __launch_bounds__(32 * BN_ZLG) void bn_stats_final_groups_kernel(
+constexpr int BN_GMAX = 6;
+__global__ __launch_bounds__(BN_CL * BN_ZL) void bn_stats_final_groups_kernel(
     const float* __restrict__ part, int rows, int C, int groups, int phases, float inv_count,
     float* __restrict__ mean, float* __restrict__ var, float* __restrict__ mm,
     float* __restrict__ mv, float decay) {
-  __shared__ float sm[2][BN_GMAX][BN_ZLG][33];
-  __shared__ float mo[2][BN_GMAX][32];
-  const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float sm[2][BN_GMAX][BN_ZL][BN_CL + 1];
+  __shared__ float mo[2][BN_GMAX][BN_CL];
+  const int cl = threadIdx.x & (BN_CL - 1), zl = threadIdx.x / BN_CL;
+  const int c = blockIdx.x * BN_CL + cl;
   const int T = rows / phases, tg = T / groups, per_group = tg * phases;
   float mmc = 0.f, mvc = 0.f;
   if (mm && zl == 0 && c < C) { mmc = mm[c]; mvc = mv[c]; }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(32 * BN_ZLG) void bn_stats_final_groups_kernel(
 #pragma unroll
     for (int j = 0; j < BN_GMAX; ++j) s[j] = q[j] = 0.f;
     if (c < C) {
-      for (int z = zl; z < per_group; z += BN_ZLG) {
+      for (int z = zl; z < per_group; z += BN_ZL) {
         const int ph = z / tg, t = z - ph * tg;
 #pragma unroll
         for (int j = 0; j < BN_GMAX; ++j)
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(32 * BN_ZLG) void bn_stats_final_groups_kernel(
     if (zl < ng && c < C) {   // split-lane j finishes group g0 + j
       float ss = 0.f, qq = 0.f;
 #pragma unroll
-      for (int r = 0; r < BN_ZLG; ++r) {
+      for (int r = 0; r < BN_ZL; ++r) {
         ss += sm[0][zl][r][cl];
         qq += sm[1][zl][r][cl];
       }
@@ -364,18 +365,19 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(
     p[(int64_t)N * C + (int64_t)n * C + c] = sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l];
   }
 }
-// finalize: block = 32 channels x BN_ZL lanes.  per-sample: lanes split the samples (each sample's
+// finalize: block = 32 channels x BN_BZL lanes.  per-sample: lanes split the samples (each sample's
 // dgamma/dbeta is complete after the hw-split sum); otherwise lanes split (n, z) jointly.
-__global__ __launch_bounds__(32 * BN_ZL) void bn_bwd_final_kernel(
+constexpr int BN_BZL = 32;   // split-lanes of the backward finaliser (32 channels x 32 lanes)
+__global__ __launch_bounds__(32 * BN_BZL) void bn_bwd_final_kernel(
     const float* __restrict__ part, int hsplits, int N, int C, float inv_rows,
     const float* __restrict__ gamma, int per_sample, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ m12) {
-  __shared__ float sm[2][BN_ZL][33];
+  __shared__ float sm[2][BN_BZL][33];
   const int cl = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float a1 = 0.f, a2 = 0.f;
   if (c < C) {
-    for (int n = zl; n < N; n += BN_ZL) {
+    for (int n = zl; n < N; n += BN_BZL) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
       for (int z = 0; z < hsplits; ++z) {
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(32 * BN_ZL) void bn_bwd_final_kernel(
   if (zl == 0 && c < C) {
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < BN_ZL; ++r) {
+    for (int r = 0; r < BN_BZL; ++r) {
       t1 += sm[0][r][cl];
       t2 += sm[1][r][cl];
     }
@@ -556,7 +558,7 @@ extern "C" int cg_bn_stats(const void* x, int64_t rows, int C, float* mean, floa
                                                       (float*)ws);
   }
   CG_CHECK_LAUNCH("cg_bn_stats(part)");
-  bn_stats_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>((const float*)ws, splits, C,
+  bn_stats_final_kernel<<<cdiv(C, BN_CL), BN_CL * BN_ZL, 0, st>>>((const float*)ws, splits, C,
                                                      1.0f / (float)rows, mean, var, moving_mean,
                                                      moving_var, decay);
   CG_CHECK_LAUNCH("cg_bn_stats(final)");
@@ -592,7 +594,7 @@ extern "C" int cg_bn_stats_groups(const void* x, int64_t rows, int C, int groups
                                                       (float*)ws);
   }
   CG_CHECK_LAUNCH("cg_bn_stats_groups(part)");
-  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZLG, 0, st>>>(
+  bn_stats_final_groups_kernel<<<cdiv(C, BN_CL), BN_CL * BN_ZL, 0, st>>>(
       (const float*)ws, groups * spg, C, groups, 1, 1.0f / (float)grows, mean, var, moving_mean,
       moving_var, decay);
   CG_CHECK_LAUNCH("cg_bn_stats_groups(final)");
@@ -608,7 +610,7 @@ extern "C" int cg_bn_finalize_groups(const float* partials, int rows, int C, int
       ((moving_mean == nullptr) != (moving_var == nullptr)))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_finalize_groups: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  bn_stats_final_groups_kernel<<<cdiv(C, 32), 32 * BN_ZLG, 0, st>>>(
+  bn_stats_final_groups_kernel<<<cdiv(C, BN_CL), BN_CL * BN_ZL, 0, st>>>(
       partials, rows, C, groups, phases, 1.0f / (float)count, mean, var, moving_mean, moving_var,
       decay);
   CG_CHECK_LAUNCH("cg_bn_finalize_groups");
@@ -666,7 +668,7 @@ extern "C" int cg_bn_finalize(const float* partials, int rows, int C, int64_t co
       ((moving_mean == nullptr) != (moving_var == nullptr)))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_bn_finalize: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  bn_stats_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(partials, rows, C, 1.0f / (float)count,
+  bn_stats_final_kernel<<<cdiv(C, BN_CL), BN_CL * BN_ZL, 0, st>>>(partials, rows, C, 1.0f / (float)count,
                                                              mean, var, moving_mean, moving_var,
                                                              decay);
   CG_CHECK_LAUNCH("cg_bn_finalize");
@@ -741,7 +743,7 @@ extern "C" int cg_bn_backward_reduce(const void* x, const void* y, const void* d
                                              part);
   }
   CG_CHECK_LAUNCH("cg_bn_backward_reduce(sums)");
-  bn_bwd_final_kernel<<<cdiv(C, 32), 32 * BN_ZL, 0, st>>>(part, hs, N, C,
+  bn_bwd_final_kernel<<<cdiv(C, 32), 32 * BN_BZL, 0, st>>>(part, hs, N, C,
                                                     1.0f / ((float)N * (float)HW), gamma,
                                                     per_sample, dgamma, dbeta, m12);
   CG_CHECK_LAUNCH("cg_bn_backward_reduce(final)");

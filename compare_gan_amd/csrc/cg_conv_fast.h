@@ -80,6 +80,15 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
 
 // out_a[i] (+)= sum_z part_a[z][i] over n4_a float4 items (and the same for the optional b pair:
 // bias-gradient partials), 8 split lanes per output; splits >= 1
+// scope in which the split reductions run at once even under cg_reduce_defer_begin() (call sites
+// that reuse the workspace the partials sit in before the caller could flush)
+class ReduceDeferSuspend {
+ public:
+  explicit ReduceDeferSuspend(bool on);
+  ~ReduceDeferSuspend();
+ private:
+  bool on_;
+};
 void cg_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a, const float* part_b,
                            int64_t n4_b, float* out_b, int splits, int accumulate,
                            hipStream_t st);

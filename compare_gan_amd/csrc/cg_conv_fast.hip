@@ -24,6 +24,9 @@
 //    row-major LDS image, so the DMA staging is shared with the forward kernel.
 #include "cg_conv_fast.h"
 
+#include <mutex>
+#include <vector>
+
 #include <stdlib.h>
 
 #define CG_FAST_BIAS_SPLITS 512
@@ -1883,20 +1886,155 @@ __global__ __launch_bounds__(256) void split_reduce4x8_kernel(
     *o = t;
   }
 }
+// ---- deferred reductions (cg_reduce_defer_begin / _flush, include/cgamd.h) ----------------------
+// A backward pass launches one small fixed-order reduction behind every weight-gradient kernel that
+// splits its pixels (60 launches of 4-6 us per ResNet-CIFAR step).  While deferral is on, those
+// reductions are only RECORDED -- same partial layout, same summation order per output -- and
+// cg_reduce_defer_flush() runs all of them in one launch per kernel form.  The state is process-wide
+// and mutex-protected: autograd runs the backward pass on its own thread.
+struct ReduceJob {
+  const float* part;
+  float* out;
+  int64_t n;        // outputs: float4 units (kinds 0, 1) or floats (kind 2)
+  int64_t stride;   // kind 2: floats between consecutive partials
+  int splits, accumulate;
+  int kind;         // 0: split_reduce4x8 (8 split lanes), 1: split_reduce4 (serial), 2: strided
+};
+static std::mutex g_defer_mu;
+static bool g_defer_on = false;
+static int g_defer_suspend = 0;
+static std::vector<ReduceJob> g_defer_jobs;
+
+static bool defer_reduce(const ReduceJob& j) {
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  if (!g_defer_on || g_defer_suspend > 0) return false;
+  g_defer_jobs.push_back(j);
+  return true;
+}
+
+constexpr int RJ_MAX = 48;   // jobs per launch (their descriptors travel by value in the kernel arguments)
+struct ReduceChunk {
+  const float* part[RJ_MAX];
+  float* out[RJ_MAX];
+  int64_t n[RJ_MAX], stride[RJ_MAX];
+  int splits[RJ_MAX], flags[RJ_MAX];   // flags: bit 0 accumulate, bit 1 serial form (kind 1)
+  int blk[RJ_MAX + 1];
+  int cnt;
+};
+__device__ __forceinline__ int rj_find(const int* blk, int n, int b) {
+  int i = 0;
+  while (i + 1 < n && blk[i + 1] <= b) ++i;
+  return i;
+}
+// kinds 0 / 1 of many jobs in one launch; per output the arithmetic of split_reduce4x8_kernel /
+// split_reduce4_kernel (bit-identical to the separate launches)
+__global__ __launch_bounds__(256) void split_reduce4_multi_kernel(ReduceChunk c) {
+  __shared__ float4 sm[8][32];
+  const int it = rj_find(c.blk, c.cnt, blockIdx.x);
+  const int b = blockIdx.x - c.blk[it];
+  const float* __restrict__ part = c.part[it];
+  float* __restrict__ out = c.out[it];
+  const int64_t n4 = c.n[it];
+  const int splits = c.splits[it], accumulate = c.flags[it] & 1;
+  if (c.flags[it] & 2) {   // (block-uniform)
+    const int64_t i = (int64_t)b * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 p = reinterpret_cast<const float4*>(part)[(int64_t)z * n4 + i];
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out) + i;
+    if (accumulate) {
+      const float4 q = *o;
+      s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    *o = s;
+    return;
+  }
+  const int il = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)b * 32 + il;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p4 = reinterpret_cast<const float4*>(part) + i;
+#pragma unroll 4
+    for (int z = zl; z < splits; z += 8) {
+      const float4 p = p4[(int64_t)z * n4];
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+  }
+  sm[zl][il] = s;
+  __syncthreads();
+  if (zl == 0 && i < n4) {
+    float4 t = sm[0][il];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const float4 q = sm[r][il];
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out) + i;
+    if (accumulate) {
+      const float4 q = *o;
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    *o = t;
+  }
+}
+// kind 2 (split_reduce_strided_kernel's arithmetic)
+__global__ __launch_bounds__(32 * SR_ZL) void split_reduce_strided_multi_kernel(ReduceChunk c) {
+  __shared__ float sm[SR_ZL][33];
+  const int it = rj_find(c.blk, c.cnt, blockIdx.x);
+  const float* __restrict__ part = c.part[it];
+  float* __restrict__ out = c.out[it];
+  const int64_t n = c.n[it], stride = c.stride[it];
+  const int splits = c.splits[it], accumulate = c.flags[it] & 1;
+  const int il = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)(blockIdx.x - c.blk[it]) * 32 + il;
+  float s = 0.f;
+  if (i < n) {
+#pragma unroll 4
+    for (int z = zl; z < splits; z += SR_ZL) s += part[(int64_t)z * stride + i];
+  }
+  sm[zl][il] = s;
+  __syncthreads();
+  if (zl == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < SR_ZL; ++r) t += sm[r][il];
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
 // weight-gradient partials (+ optionally the bias-gradient partials of the same splits) in one launch
 static void launch_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a,
                                       const float* part_b, int64_t n4_b, float* out_b, int splits,
                                       int accumulate, hipStream_t st) {
+  {
+    std::unique_lock<std::mutex> lk(g_defer_mu);
+    if (g_defer_on && g_defer_suspend == 0) {
+      g_defer_jobs.push_back({part_a, out_a, n4_a, 0, splits, accumulate, 0});
+      if (out_b) g_defer_jobs.push_back({part_b, out_b, n4_b, 0, splits, accumulate, 0});
+      return;
+    }
+  }
   const int ba = cdiv(n4_a, 32), bb = out_b ? cdiv(n4_b, 32) : 0;
   split_reduce4x8_kernel<<<ba + bb, 256, 0, st>>>(part_a, n4_a, out_a, ba, part_b, n4_b, out_b,
                                                   splits, accumulate);
 }
 static void launch_split_reduce4(const float* part, int splits, int64_t n4, float* out,
                                  int accumulate, hipStream_t st) {
-  if (splits >= 8)
+  if (splits >= 8) {
     launch_split_reduce4_pair(part, n4, out, nullptr, 0, nullptr, splits, accumulate, st);
-  else
+  } else {
+    if (defer_reduce({part, out, n4, 0, splits, accumulate, 1})) return;
     split_reduce4_kernel<<<cdiv(n4, 256), 256, 0, st>>>(part, splits, n4, out, accumulate);
+  }
+}
+static void launch_split_reduce_strided(const float* part, int splits, int64_t stride, int64_t n,
+                                        float* out, int accumulate, hipStream_t st) {
+  if (defer_reduce({part, out, n, stride, splits, accumulate, 2})) return;
+  split_reduce_strided_kernel<<<cdiv(n, 32), 32 * SR_ZL, 0, st>>>(part, splits, stride, n, out,
+                                                                  accumulate);
 }
 
 // part[z][c] = sum over rows [z*rps, (z+1)*rps) of y[row][c]   (bias gradient when the weight
@@ -1940,6 +2078,70 @@ bool phase_ok(const cgConvGeom* g) {
 }
 
 }  // namespace
+
+ReduceDeferSuspend::ReduceDeferSuspend(bool on) : on_(on) {
+  if (on_) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    ++g_defer_suspend;
+  }
+}
+ReduceDeferSuspend::~ReduceDeferSuspend() {
+  if (on_) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    --g_defer_suspend;
+  }
+}
+
+extern "C" int cg_reduce_defer_begin(void) {
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  g_defer_on = true;
+  return CG_OK;
+}
+extern "C" int cg_reduce_defer_pending(void) {
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  return (int)g_defer_jobs.size();
+}
+extern "C" int cg_reduce_defer_abort(void) {
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  g_defer_on = false;
+  g_defer_jobs.clear();
+  return CG_OK;
+}
+extern "C" int cg_reduce_defer_flush(cgStream stream) {
+  std::vector<ReduceJob> jobs;
+  {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_defer_on = false;
+    jobs.swap(g_defer_jobs);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int form = 0; form < 2; ++form) {   // 0: float4 kinds (0, 1), 1: strided
+    ReduceChunk c;
+    c.cnt = 0;
+    int blk = 0;
+    auto launch = [&]() {
+      if (c.cnt == 0) return;
+      c.blk[c.cnt] = blk;
+      if (form == 0) split_reduce4_multi_kernel<<<blk, 256, 0, st>>>(c);
+      else split_reduce_strided_multi_kernel<<<blk, 32 * SR_ZL, 0, st>>>(c);
+      c.cnt = 0;
+      blk = 0;
+    };
+    for (const ReduceJob& j : jobs) {
+      if ((j.kind == 2) != (form == 1)) continue;
+      const int i = c.cnt++;
+      c.part[i] = j.part; c.out[i] = j.out; c.n[i] = j.n; c.stride[i] = j.stride;
+      c.splits[i] = j.splits;
+      c.flags[i] = (j.accumulate ? 1 : 0) | (j.kind == 1 ? 2 : 0);
+      c.blk[i] = blk;
+      blk += (int)(j.kind == 1 ? cdiv(j.n, 256) : cdiv(j.n, 32));
+      if (c.cnt == RJ_MAX) launch();
+    }
+    launch();
+  }
+  CG_CHECK_LAUNCH("cg_reduce_defer_flush");
+  return CG_OK;
+}
 
 void cg_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a, const float* part_b,
                            int64_t n4_b, float* out_b, int splits, int accumulate,
@@ -2236,11 +2438,9 @@ void cg_narrow_wgrad_launch(const cgConvGeom* g, const void* in, const void* dy,
 void cg_stem_partial_reduce(const cgConvGeom* g, const void* ws, int splits, float* dw,
                             float* dbias, int accumulate, hipStream_t st) {
   const int64_t KC = (int64_t)g->kh * g->kw * g->Ci * g->Co, stride = KC + g->Co;
-  split_reduce_strided_kernel<<<cdiv(KC, 32), 32 * SR_ZL, 0, st>>>((const float*)ws, splits, stride,
-                                                                    KC, dw, accumulate);
+  launch_split_reduce_strided((const float*)ws, splits, stride, KC, dw, accumulate, st);
   if (dbias)
-    split_reduce_strided_kernel<<<cdiv(g->Co, 32), 32 * SR_ZL, 0, st>>>(
-        (const float*)ws + KC, splits, stride, g->Co, dbias, accumulate);
+    launch_split_reduce_strided((const float*)ws + KC, splits, stride, g->Co, dbias, accumulate, st);
 }
 
 void cg_stem_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_in,
@@ -2278,12 +2478,9 @@ static void stem_wgrad_run(const cgConvGeom* g, const void* in, int relu_in, con
     default: stem_wgrad_kernel<128><<<grid, 256, 0, st>>>(a); break;
   }
   const int64_t KC = (int64_t)a.K * g->Co, stride = KC + g->Co;
-  split_reduce_strided_kernel<<<cdiv(KC, 32), 32 * SR_ZL, 0, st>>>((const float*)ws, splits, stride, KC,
-                                                            dw, accumulate);
+  launch_split_reduce_strided((const float*)ws, splits, stride, KC, dw, accumulate, st);
   if (dbias)
-    split_reduce_strided_kernel<<<cdiv(g->Co, 32), 32 * SR_ZL, 0, st>>>((const float*)ws + KC, splits,
-                                                                  stride, g->Co, dbias,
-                                                                  accumulate);
+    launch_split_reduce_strided((const float*)ws + KC, splits, stride, g->Co, dbias, accumulate, st);
 }
 
 bool cg_fast_wgrad_supported(const cgConvGeom* g, const void* in, const void* gate_in,
@@ -2481,6 +2678,8 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
   const int64_t c4 = g->Co / 4;
   if (splits > 1) {
     const int64_t n4 = (int64_t)(KC / 4);  // Ci % 64 == 0 and Co % 8 == 0 -> divisible
+    // (not deferred when the bias partials below reuse the workspace the dw partials sit in)
+    ReduceDeferSuspend keep(dbias && !bias_in_kernel);
     launch_split_reduce4_pair(wsf, n4, dw, wsf + (size_t)splits * KC, c4,
                               bias_in_kernel ? dbias : nullptr, splits, accumulate, st);
   }

@@ -275,11 +275,18 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       uint4* p = reinterpret_cast<uint4*>(smem + i * 16);
       float v[8];
       unpack8_bf16(*p, v);
+      // the chunk's 4 x 8 coefficients as eight 16-byte LDS reads (element-wise reads were 32 of the
+      // ~36 LDS operations a chunk cost, and this pass is not overlapped with the MFMA loop); four
+      // channels at a time: the 128-channel kernel has no registers to spare
+      const float4* t4 = reinterpret_cast<const float4*>(tab + c8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (v[e] - tab[c8 + e]) * tab[64 + c8 + e];
-        t = t * tab[128 + c8 + e] + tab[192 + c8 + e];
-        v[e] = fmaxf(t, 0.f);
+      for (int h = 0; h < 2; ++h) {
+        const float4 m = t4[h], r = t4[16 + h], g = t4[32 + h], b = t4[48 + h];
+        float t;
+        t = (v[4 * h + 0] - m.x) * r.x; t = t * g.x + b.x; v[4 * h + 0] = fmaxf(t, 0.f);
+        t = (v[4 * h + 1] - m.y) * r.y; t = t * g.y + b.y; v[4 * h + 1] = fmaxf(t, 0.f);
+        t = (v[4 * h + 2] - m.z) * r.z; t = t * g.z + b.z; v[4 * h + 2] = fmaxf(t, 0.f);
+        t = (v[4 * h + 3] - m.w) * r.w; t = t * g.w + b.w; v[4 * h + 3] = fmaxf(t, 0.f);
       }
       *p = pack8_bf16(v);
     }

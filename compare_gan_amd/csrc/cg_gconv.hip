@@ -1101,6 +1101,7 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
   }
   if (cg_narrow_wgrad_supported(g, gate_in, gate_dy)) {
     hipStream_t fst = (hipStream_t)stream;
+    ReduceDeferSuspend keep(dbias != nullptr);   // cg_colsum below reuses the workspace
     cg_narrow_wgrad_launch(g, in, dy, dw, accumulate, ws, fst);
     CG_CHECK_LAUNCH("cg_gwgrad(narrow)");
     int rc2 = CG_OK;
@@ -1231,6 +1232,7 @@ extern "C" int cg_gwgrad_multi(const cgWgradItem* items_host, int n, void* ws, s
         if (rc) return rc;
       }
     } else {
+      ReduceDeferSuspend keep(true);   // the one-by-one items share `ws`: reduce before the next one
       rc = cg_gwgrad(&it.geom, it.in, it.gate_in, it.slope_in, it.dy, nullptr, 0.f, it.dw,
                      it.accumulate, it.dbias, ws, ws_bytes, stream);
       if (rc) return rc;

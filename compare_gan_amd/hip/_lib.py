@@ -82,6 +82,10 @@ SIGNATURES = {
     "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
     "cg_weight_prep_elems": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
+    "cg_reduce_defer_begin": (c_int, []),
+    "cg_reduce_defer_flush": (c_int, [vp]),
+    "cg_reduce_defer_abort": (c_int, []),
+    "cg_reduce_defer_pending": (c_int, []),
     "cg_gconv_fused_rows": (c_int, [GP]),
     "cg_gconv_fused_prologue_supported": (c_int, [GP]),
     "cg_gconv_fused_phases": (c_int, [GP]),

@@ -6,6 +6,8 @@ are themselves expressed through these Functions, so torch.autograd.grad(create_
 Conventions: activations NHWC bf16; weights fp32 in the reference layouts; fp32 for logits,
 losses, CBN gamma/beta and generator outputs.
 """
+import os
+
 import torch
 
 from compare_gan_amd.hip import kernels as K
@@ -107,7 +109,11 @@ def _wgrad_side_stream():
 # guarantees that no weight receives a second gradient contribution inside the context (autograd
 # would add to the unwritten tensor): modular_gan enables it for single-call discriminator /
 # generator graphs without penalties only.
+# The weight gradients that do run at once inside the context (the large maps: one launch fills the
+# chip) still leave a small fixed-order reduction of their per-split partials behind; those are
+# recorded by the library (K.reduce_defer_begin) and run in ONE launch at the same flush points.
 _DEFER = {"on": False, "jobs": [], "wptrs": set()}
+_DEFER_REDUCE = os.environ.get("CGAMD_DEFER_REDUCE", "1") != "0"   # A/B switch (read once)
 
 
 class deferred_wgrads(object):
@@ -117,23 +123,33 @@ class deferred_wgrads(object):
   def __enter__(self):
     self._old = _DEFER["on"]
     _DEFER["on"] = self._enabled
+    if self._enabled and _DEFER_REDUCE:
+      K.reduce_defer_begin()
     return self
 
   def __exit__(self, etype, *exc):
     _DEFER["on"] = self._old
     if etype is None:
       flush_wgrads()
+      if self._old and _DEFER_REDUCE:
+        K.reduce_defer_begin()    # an enclosing context keeps recording
     else:
       del _DEFER["jobs"][:]
       _DEFER["wptrs"].clear()
+      K.reduce_defer_abort()
 
 
 def flush_wgrads():
-  """Runs every recorded weight gradient (their output tensors are valid afterwards)."""
+  """Runs every recorded weight gradient and every recorded reduction (their output tensors are
+  valid afterwards).  Inside a context, recording continues behind the flush."""
   if _DEFER["jobs"]:
     jobs, _DEFER["jobs"] = _DEFER["jobs"], []
-    _DEFER["wptrs"].clear()
     K.gwgrad_multi(jobs)
+  _DEFER["wptrs"].clear()
+  if K.reduce_defer_active():
+    K.reduce_defer_flush()
+    if _DEFER["on"] and _DEFER_REDUCE:
+      K.reduce_defer_begin()
 
 
 def join_wgrad_stream():
@@ -172,6 +188,7 @@ class GConvFn(torch.autograd.Function):
     # the operand images of THIS call travel with the node: a later call of the same module
     # (gradient penalty, next sub-step) prepares new ones
     ctx.bt_pair = bt_pair
+    ctx.w_late = _weight_grad_read_late(w)
     ctx.save_for_backward(x, w, gate_in, gate_out)
     return y
 
@@ -207,7 +224,7 @@ class GConvFn(torch.autograd.Function):
           if t is not None:
             t.record_stream(main)    # allocated on the side stream, consumed on the main one
         _WGRAD["dirty"] = True
-      elif (_DEFER["on"] and need_w and not spec.transpose and x.is_cuda and
+      elif (_DEFER["on"] and ctx.w_late and need_w and not spec.transpose and x.is_cuda and
             (gate_out is None or spec.slope_out is None) and
             (gate_in is None or spec.slope_in is None or
              (spec.slope_in == 0.0 and gate_in.data_ptr() == x.data_ptr())) and
@@ -220,6 +237,7 @@ class GConvFn(torch.autograd.Function):
           # for the example configs)
           flush_wgrads()
           dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
+          flush_wgrads()   # (its split reduction is recorded too)
         else:
           _DEFER["wptrs"].add(w.data_ptr())
           dw = torch.empty((g.kh, g.kw, g.Ci, g.Co), dtype=F32, device=x.device)
@@ -227,8 +245,47 @@ class GConvFn(torch.autograd.Function):
           relu_in = gate_in is not None and spec.slope_in is not None
           _DEFER["jobs"].append((g, x, dy16, relu_in, dw, db))
       else:
+        dup = _note_weight_contribution(w)
         dw, db = _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b)
+        if dup or not ctx.w_late:
+          flush_wgrads()
     return dx, dw, db, dr, None, None, None, None, None
+
+
+_VIEW_NODES = ("ViewBackward0", "ReshapeAliasBackward0", "UnsafeViewBackward0", "AliasBackward0")
+
+
+def _weight_grad_read_late(w):
+  """True when nothing reads the gradient of the kernel tensor `w` before a flush point: `w` is a
+  variable (its gradient goes to the optimiser), a view of one, or the output of the spectral-norm
+  Functions (whose backward flushes first).  Anything else -- e.g. the zero-padding of the
+  self-attention projections, whose backward is a torch slice of dw -- reads it inside the backward
+  pass, so such a gradient must be complete when GConvFn.backward returns."""
+  fn = w.grad_fn
+  for _ in range(4):
+    if fn is None:
+      return True
+    name = type(fn).__name__
+    if name == "AccumulateGrad" or name.startswith("SpectralNorm"):
+      return True
+    if name in _VIEW_NODES and fn.next_functions:
+      fn = fn.next_functions[0][0]
+      continue
+    return False
+  return False
+
+
+def _note_weight_contribution(w):
+  """Inside a deferred_wgrads() context a weight gradient computed now is only valid after the flush
+  (its split reduction is recorded, not run): a SECOND contribution to the same weight would be
+  added by autograd to an unwritten tensor, so everything recorded is written first.
+  The caller flushes again behind the second computation when this returns True."""
+  if _DEFER["on"] and K.reduce_defer_active():
+    if w.data_ptr() in _DEFER["wptrs"]:
+      flush_wgrads()
+      return True
+    _DEFER["wptrs"].add(w.data_ptr())
+  return False
 
 
 def _gated(t, gate, slope):
@@ -307,6 +364,7 @@ class ConvPoolFn(torch.autograd.Function):
                          out_f32=spec.out_f32)
     ctx.spec, ctx.dx_f32, ctx.bt_pair = spec, dx_f32, bt_pair
     ctx.has_bias, ctx.has_res = bias is not None, residual_p is not None
+    ctx.w_late = _weight_grad_read_late(w)
     ctx.save_for_backward(x, w, gate_in)
     return y
 
@@ -346,7 +404,10 @@ class ConvPoolFn(torch.autograd.Function):
         dx = K.gconv(ag, K.avgpool2_bwd(dy16), bt_b, gate_out=gi, slope_out=spec.slope_in or 0.0,
                      out_f32=ctx.dx_f32)
     if need_w or want_b:
+      dup = _note_weight_contribution(w)
       dw, db = K.gwgrad_pooled(g, x, dy16, gate_in=gi, want_dbias=want_b)
+      if dup or not ctx.w_late:
+        flush_wgrads()
       if not need_w:
         dw = None
     return dx, dw, db, dr, None, None, None, None

@@ -39,8 +39,42 @@ def _req(t, dtype, name, allow_none=False):
         raise ValueError("%s must be contiguous" % name)
 
 
+# workspaces of weight-gradient calls whose reductions are only recorded (reduce_defer_begin):
+# kept until reduce_defer_flush() has launched the reductions that read them
+_REDUCE_DEFER = {"on": False, "keep": []}
+
+
 def _ws(nbytes, like):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+    if _REDUCE_DEFER["on"]:
+        _REDUCE_DEFER["keep"].append(ws)
+    return ws
+
+
+def reduce_defer_begin():
+    """cg_reduce_defer_begin: the split reductions behind gwgrad / gwgrad_pooled are recorded, not
+    launched; their outputs are valid after reduce_defer_flush() (on the stream current there)."""
+    check(lib().cg_reduce_defer_begin(), "cg_reduce_defer_begin")
+    _REDUCE_DEFER["on"] = True
+
+
+def reduce_defer_flush():
+    """Runs every recorded reduction in one launch per kernel form; recording is off afterwards."""
+    if not _REDUCE_DEFER["on"]:
+        return
+    _REDUCE_DEFER["on"] = False
+    check(lib().cg_reduce_defer_flush(_stream()), "cg_reduce_defer_flush")
+    del _REDUCE_DEFER["keep"][:]   # (stream-ordered: a later allocation reuses them after the launch)
+
+
+def reduce_defer_active():
+    return _REDUCE_DEFER["on"]
+
+
+def reduce_defer_abort():
+    _REDUCE_DEFER["on"] = False
+    del _REDUCE_DEFER["keep"][:]
+    lib().cg_reduce_defer_abort()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -175,6 +175,22 @@ int cg_gconv_pool_supported(const cgConvGeom* geom);
 int cg_gwgrad_pooled(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
                      const void* dy_pooled, float* dw, int accumulate, float* dbias, void* ws,
                      size_t ws_bytes, cgStream stream);
+
+/* Deferred reductions.  Weight-gradient kernels that split their pixels leave per-split partials in
+ * the workspace and a small fixed-order reduction behind them (60 launches per ResNet-CIFAR train
+ * step).  After cg_reduce_defer_begin(), cg_gwgrad / cg_gwgrad_pooled still launch the partial-sum
+ * kernels but only RECORD those reductions; cg_reduce_defer_flush(stream) runs every recorded one in
+ * one launch per kernel form (same summation order per output as the separate launches: results are
+ * bit-identical) and switches recording off.  Until the flush the caller must keep every workspace
+ * and output of the recorded calls alive, unread, and on `stream`.  The switch is process-wide
+ * (autograd runs backward passes on its own thread).  cg_reduce_defer_abort() drops the recorded
+ * reductions (error paths); cg_reduce_defer_pending() returns how many are recorded.
+ * tf.gradients hands the optimiser all kernel gradients at once (modular_gan.py:480-483,494-497):
+ * nothing in the data-gradient chain reads them earlier. */
+int cg_reduce_defer_begin(void);
+int cg_reduce_defer_flush(cgStream stream);
+int cg_reduce_defer_abort(void);
+int cg_reduce_defer_pending(void);
 /* mean / var (and the moving averages, as cg_bn_stats) from `rows` rows of partial sums
  * [rows][2*C] over `count` values per channel. */
 int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean, float* var,

@@ -372,6 +372,90 @@ def test_deferred_wgrads_match_immediate(K, dev):
         assert_close_f32(b, a.double().cpu(), "deferred vs immediate", rtol=1e-4, abs_rms=1e-4)
 
 
+def test_deferred_wgrads_with_a_torch_op_on_the_weight_path(K, dev):
+    """The self-attention projections run with zero-padded kernels (arch_ops.conv2d pad_out_to): the
+    padding's backward is a torch slice of dw INSIDE the backward pass, so inside
+    Fn.deferred_wgrads() such a weight gradient must be complete when the convolution's backward
+    returns (its split reduction is not left recorded).  Bit-identical to the undeferred pass."""
+    from compare_gan_amd.hip import functional as Fn
+    g = _gen(29)
+    N, H, W, C = 2, 64, 64, 32
+    _, xb = rand_bf16((N, H, W, C), g)
+    w_small = rand_bf16((1, 1, C, 4), g, 0.1)[1].float().to(dev).requires_grad_(True)
+    w_plain = rand_bf16((3, 3, C, 64), g, 0.05)[1].float().to(dev).requires_grad_(True)
+    g1 = K.geom_conv_same(N, H, W, C, 32, 1, 1, 1, 1)
+    g3 = K.geom_conv_same(N, H, W, 32, 64, 3, 3, 1, 1)
+
+    def run(defer):
+        wp = torch.nn.functional.pad(w_small, (0, 28))
+        h = Fn.gconv(xb.to(dev), wp, None, spec=Fn.ConvSpec(g1))
+        h = Fn.gconv(h, w_plain, None, gate_in=h, spec=Fn.ConvSpec(g3, slope_in=0.0))
+        loss = Fn.relu_mean(h).sum()
+        with Fn.deferred_wgrads(defer):
+            grads = torch.autograd.grad(loss, [w_small, w_plain])
+        return [t.clone() for t in grads]
+
+    immediate = run(False)
+    deferred = run(True)
+    for a, b in zip(immediate, deferred):
+        assert float(a.abs().max()) > 0.0
+        assert torch.equal(a, b)
+
+
+def test_deferred_reductions_are_bit_identical(K, dev):
+    """cg_reduce_defer_begin / _flush: the split reductions behind the weight-gradient kernels (halo:
+    float4 partials, 8 split lanes; RGB stem: strided partials; pooled-gradient forms; a layer with
+    the bias partials in the reused workspace, whose dw reduction must NOT be deferred), recorded and
+    run in one launch per form, give bit for bit the tensors of the separate launches -- and nothing
+    is written before the flush."""
+    g = _gen(23)
+    cases = [  # N, H, W, Ci, Co, relu, pooled
+        (6, 32, 32, 128, 128, True, False), (4, 32, 32, 64, 64, False, True), (9, 32, 32, 3, 128, False, False),
+        (5, 32, 32, 3, 64, False, True), (8, 16, 16, 128, 256, True, False), (3, 64, 64, 64, 64, True, False),
+        (40, 8, 8, 512, 512, False, False), (8, 16, 16, 256, 128, False, False),
+        (16, 32, 32, 128, 256, False, "s2"), (8, 64, 64, 64, 128, False, "s2")]   # 4x4 stride 2 (sndcgan.py:109-121)
+    ops = []
+    for (N, H, W, Ci, Co, relu, pooled) in cases:
+        _, xb = rand_bf16((N, H, W, Ci), g)
+        if pooled == "s2":
+            geom = K.geom_conv_same(N, H, W, Ci, Co, 4, 4, 2, 1)
+            pooled = False
+        else:
+            geom = K.geom_conv_same(N, H, W, Ci, Co, 3, 3, 1, 1)
+        _, dyb = rand_bf16((N, geom.Ho // 2, geom.Wo // 2, Co) if pooled else (N, geom.Ho, geom.Wo, Co), g)
+        ops.append((geom, xb.to(dev), dyb.to(dev), relu, pooled))
+
+    def run_all():
+        outs = []
+        for geom, x, dy, relu, pooled in ops:
+            gi = x if relu else None
+            if pooled:
+                outs.extend(K.gwgrad_pooled(geom, x, dy, gate_in=gi, want_dbias=True))
+            else:
+                outs.extend(K.gwgrad(geom, x, dy, gate_in=gi, slope_in=0.0, want_dbias=True))
+        return outs
+
+    ref = [t.clone() for t in run_all()]
+    K.reduce_defer_begin()
+    try:
+        outs = run_all()
+        pending = int(K.lib().cg_reduce_defer_pending())
+        K.reduce_defer_flush()
+    except Exception:
+        K.reduce_defer_abort()
+        raise
+    assert pending >= 8, pending          # (most of the layers above split their pixels)
+    assert int(K.lib().cg_reduce_defer_pending()) == 0 and not K.reduce_defer_active()
+    for i, (a, b) in enumerate(zip(ref, outs)):
+        assert torch.equal(a, b), "output %d of case %s" % (i % 2, cases[i // 2])
+    # an aborted recording leaves the switch off: the next call reduces at once
+    K.reduce_defer_begin()
+    K.reduce_defer_abort()
+    again = run_all()
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+
+
 FUSED_FULL_SIZE = [
     # name, N, H, W, Ci, Co, relu_in, residual -- the pooled convolutions of the ResNet5-128 D-step at
     # the benchmark's batch (2 x 64 images): B0 conv2 and its RGB shortcut at 128x128, B1 shortcut
