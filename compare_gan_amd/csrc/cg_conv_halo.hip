@@ -111,11 +111,20 @@ template <int BN, bool RELU, int TWL, int FUSE>
 __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   constexpr bool NARROW = FUSE == 3;
   static_assert(!NARROW || BN == 64, "narrow outputs use the 64-channel tile");
-  constexpr int TW = 1 << TWL, TH = 256 >> TWL, PITCH = TW + 2;
+  // TWL == 3: FOUR whole 8x8 images per 256-pixel tile (the 8x8 x 512-channel blocks of the ResNet5
+  // discriminator, resnet5.py:99-145: a single image is a quarter of a tile); pixel p of the tile
+  // is (image p >> 6, row (p >> 3) & 7, column p & 7), every image has its own 10x10 halo window
+  constexpr bool MI = TWL == 3;
+  static_assert(!MI || (FUSE == 0 && BN == 64), "multi-image tiles: plain epilogue, 64-channel tile");
+  constexpr int TW = MI ? 8 : (1 << TWL), TH = MI ? 8 : (256 >> TWL), PITCH = TW + 2;
+  constexpr int IMG_ROWS = (TH + 2) * PITCH;                       // halo rows of one image (MI)
+  constexpr int HALO_PIECES = MI ? (4 * IMG_ROWS + 7) / 8 : HC_HALO_PIECES;
+  constexpr int HALO_BYTES = HALO_PIECES * 1024;
+  constexpr int HSLOTS = (HALO_PIECES + 7) / 8;                    // halo pieces per wave
   constexpr int TN = BN / 64;         // 32-channel MFMA tiles per wave (2 waves along channels)
   constexpr int BJ = BN / 64;         // weight staging pieces per wave and K-slice
   constexpr int B_BYTES = BN * 128;   // one K-slice of weights: BN rows x 64 k x 2 B
-  constexpr int LDS_BYTES = HC_HALO_BYTES + 2 * B_BYTES;
+  constexpr int LDS_BYTES = HALO_BYTES + 2 * B_BYTES;
   constexpr int TAB_OFF = LDS_BYTES;  // [4][64] floats: mean, rstd, gamma, beta of the channel block
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES + 1024];
 
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   const int ntaps = nr * ns;
   const int nk = ntaps * a.cblocks;
   const int HH = TH + nr - 1, HWID = TW + ns - 1;        // halo rows / columns actually read
-  const int npieces = (HH * PITCH + 7) >> 3;             // <= HC_HALO_PIECES
+  const int npieces = MI ? HALO_PIECES : (HH * PITCH + 7) >> 3;   // <= HALO_PIECES
 
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
@@ -169,14 +178,27 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   // ---- staging descriptors: byte offsets, computed once ----
   // halo piece p = wave + 8 j covers halo rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3), LDS
   // chunk (lane & 7) which must hold source chunk (lane & 7) ^ ((hx >> 1) & 7)
-  uint32_t hvoff[HC_HSLOTS];
-  int hc8[HC_HSLOTS];   // source channel offset of the slot's chunk (only read when Ci % 64 != 0)
+  uint32_t hvoff[HSLOTS];
+  int hc8[HSLOTS];   // source channel offset of the slot's chunk (only read when Ci % 64 != 0)
   const int iy0 = ty * TH + bh, ix0 = tx * TW + bw;
   const bool ragged_ci = (a.Ci & 63) != 0;   // last channel block half empty (Ci % 32 == 0)
   {
 #pragma unroll
-    for (int j = 0; j < HC_HSLOTS; ++j) {
+    for (int j = 0; j < HSLOTS; ++j) {
       const int row = (wave + 8 * j) * 8 + (lane >> 3);
+      if constexpr (MI) {
+        // chunk swizzle ((hx >> 1) & 3) | ((hy & 1) << 2): the 16 lanes of a fragment read cover 8
+        // columns of two rows, whose halo rows are 10 apart (the same bank half)
+        const int img = row / IMG_ROWS, rr = row - img * IMG_ROWS;
+        const int hy = rr / PITCH, hx = rr - hy * PITCH;
+        const int c = (lane & 7) ^ (((hx >> 1) & 3) | ((hy & 1) << 2));
+        const int iy = iy0 + hy, ix = ix0 + hx, ni = n * 4 + img;
+        const bool ok = img < 4 && ni < a.N && (unsigned)iy < (unsigned)a.Hin &&
+                        (unsigned)ix < (unsigned)a.Win;
+        hvoff[j] = ok ? (uint32_t)((((ni * a.Hin + iy) * a.Win + ix) * a.Ci + c * 8) * 2) : HC_OOB;
+        hc8[j] = c * 8;
+        continue;
+      }
       const int hy = row / PITCH, hx = row - hy * PITCH;
       const int c = (lane & 7) ^ ((hx >> 1) & 7);
       const int iy = iy0 + hy, ix = ix0 + hx;
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   auto issue_halo = [&](int cb) {
     const int crem = a.Ci - cb * 64;   // channels left in this block (32 in a ragged last block)
 #pragma unroll
-    for (int j = 0; j < HC_HSLOTS; ++j)
+    for (int j = 0; j < HSLOTS; ++j)
       if (wave + 8 * j < npieces) {
         const uint32_t vo = (ragged_ci && hc8[j] >= crem) ? HC_OOB : hvoff[j];
         hc_dma16(rs_in, vo, (uint32_t)(cb * 128), smem + (wave + 8 * j) * 1024);
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
 #pragma unroll
     for (int j = 0; j < BJ; ++j)
       hc_dma16(rs_bt, bvoff[j], (uint32_t)(koff * 2),
-               smem + HC_HALO_BYTES + slot * B_BYTES + (wave * BJ + j) * 1024);
+               smem + HALO_BYTES + slot * B_BYTES + (wave * BJ + j) * 1024);
   };
 
   // fused batch-norm prologue: per channel block, the coefficients of its 64 channels go to LDS ...
@@ -299,13 +321,14 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
 
   // ---- fragment addressing ----
   // pixel p = wm*64 + i*32 + frow of the tile -> (y, x); halo row of its tap-(0,0) input pixel
-  int hb[2], hx0[2];
+  int hb[2], hx0[2], hy0[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = wm * 64 + i * 32 + frow;
-    const int y = p >> TWL, x = p & (TW - 1);
-    hb[i] = (y * PITCH + x) * 128;
+    const int y = MI ? (p >> 3) & 7 : p >> TWL, x = p & (TW - 1);
+    hb[i] = ((MI ? (p >> 6) * IMG_ROWS : 0) + y * PITCH + x) * 128;
     hx0[i] = x;
+    hy0[i] = y;
   }
   // weights: row = wn*(BN/2) + j*32 + frow, chunk (kk*2 + half) ^ ((frow >> 1) & 7)
   int bko[4];
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       // staged the piece (its own pieces have landed), instead of on every one of the 9 x 8 fragment
       // reads that consume the window (2 VALU instructions per MFMA in an issue-bound loop)
 #pragma unroll
-      for (int j = 0; j < HC_HSLOTS; ++j)
+      for (int j = 0; j < HSLOTS; ++j)
         if (wave + 8 * j < npieces) {
           bf16x8_t* p = reinterpret_cast<bf16x8_t*>(smem + (wave + 8 * j) * 1024 + lane * 16);
           *p = hc_relu(*p);
@@ -363,13 +386,14 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     if (it + 1 < nk)
       issue_b((it + 1) & 1, ((r0 + a.U * nri) * a.kw + (s0 + a.U * nsi)) * a.Ci + ncb * 64);
 
-    const unsigned char* Bs = smem + HC_HALO_BYTES + (it & 1) * B_BYTES;
+    const unsigned char* Bs = smem + HALO_BYTES + (it & 1) * B_BYTES;
     const int tshift = (ri * PITCH + si) * 128;
     int abase[2], aswz[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       abase[i] = hb[i] + tshift;
-      aswz[i] = ((hx0[i] + si) >> 1) & 7;
+      aswz[i] = MI ? ((((hx0[i] + si) >> 1) & 3) | (((hy0[i] + ri) & 1) << 2))
+                   : (((hx0[i] + si) >> 1) & 7);
     }
 #pragma unroll
     for (int kq = 0; kq < (NARROW ? 2 : 4); ++kq) {
@@ -564,9 +588,11 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
       if (!co_ok) continue;
       const int p = wm * 64 + i * 32 + row;
-      const int y = p >> TWL, x = p & (TW - 1);
+      const int y = MI ? (p >> 3) & 7 : p >> TWL, x = p & (TW - 1);
       const int oy = (ty * TH + y) * a.U + ph, ox = (tx * TW + x) * a.U + pw;
-      const int64_t o = ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Co + co;
+      const int ni = MI ? n * 4 + (p >> 6) : n;
+      if (MI && ni >= a.N) continue;   // ragged last image group
+      const int64_t o = ((int64_t)(ni * a.Ho + oy) * a.Wo + ox) * a.Co + co;
       float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
                     hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
       if (a.self_gate) {
@@ -1984,6 +2010,21 @@ static bool hc_geom_ok(const cgConvGeom* g, bool narrow) {
 
 bool cg_hconv_geom_ok(const cgConvGeom* g) { return hc_geom_ok(g, false); }
 
+// hconv_kernel<64, *, 3, 0>: four whole 8x8 images per tile.  Only where the one-tap kernel is the
+// alternative (sconv takes the small grids) and the K loop is long enough to pay for a 50 KiB window
+static bool hc_mi_use(const cgConvGeom* g) {
+  static const int enabled = hc_env("CGAMD_HCONV_MI", 1);
+  static const int min_wgs = hc_env("CGAMD_HCONV_MI_MIN", 192);
+  static const int min_ci = hc_env("CGAMD_HCONV_MI_CI", 256);
+  if (!enabled) return false;
+  if (g->S != 1 || g->U != 1 || g->kh != 3 || g->kw != 3 || g->pt != 1 || g->pl != 1) return false;
+  if (g->Hin != 8 || g->Win != 8 || g->Ho != 8 || g->Wo != 8) return false;
+  if ((g->Ci % 32) != 0 || (g->Co % 8) != 0 || g->Co < 64 || g->Ci < min_ci) return false;
+  if ((int64_t)g->N * 64 * g->Ci * 2 >= (1ll << 31)) return false;
+  if ((int64_t)g->Co * 9 * g->Ci * 2 >= (1ll << 31)) return false;
+  return (int64_t)cdiv(g->N, 4) * cdiv(g->Co, 64) >= min_wgs;
+}
+
 bool cg_hconv_narrow(const cgConvGeom* g) { return g->Co < 8; }
 bool cg_hconv_narrow_ok(const cgConvGeom* g) { return hc_geom_ok(g, true); }
 
@@ -1992,6 +2033,7 @@ bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in
   static const int narrow_on = hc_env("CGAMD_HCONV_NARROW", 1);
   static const int min_wgs = hc_env("CGAMD_HCONV_MIN", 100);
   const bool narrow = g->Co < 8;
+  if (enabled && hc_mi_use(g)) return !(gate_in && !(gate_in == in && slope_in == 0.f));
   if (!enabled || (narrow && !narrow_on) || !hc_geom_ok(g, narrow)) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
@@ -2048,7 +2090,8 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
     cg_pconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fu, st);
     return;
   }
-  const bool hup = hup_geom_ok(g) && !(fu && (fu->pool_out || fu->in_up));
+  const bool mi = hc_mi_use(g);   // (8x8 maps: no fused form reaches this launcher)
+  const bool hup = !mi && hup_geom_ok(g) && !(fu && (fu->pool_out || fu->in_up));
   HConvArgs a;
   a.bn_mean = fu ? fu->bn_mean : nullptr;
   a.bn_var = fu ? fu->bn_var : nullptr;
@@ -2078,9 +2121,9 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   const int twl = hc_tile_log(Hp, Wp);
   const int TW = 1 << twl, TH = 256 >> twl;
-  a.tiles_x = Wp / TW;
-  a.tiles_y = Hp / TH;
-  const int bn = hc_pick_bn(g);
+  a.tiles_x = mi ? 1 : Wp / TW;
+  a.tiles_y = mi ? 1 : Hp / TH;
+  const int bn = mi ? 64 : hc_pick_bn(g);
   a.ntiles = cdiv(g->Co, bn);
   a.out_f32 = out_is_f32;
   a.slope_out = slope_out;
@@ -2091,6 +2134,13 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
   a.tdbg = g_hconv_tdbg;
 #endif
   const bool relu = gate_in != nullptr && a.bn_mean == nullptr;   // the BN prologue includes the ReLU
+  if (mi) {
+    dim3 mgrid(cdiv(g->N, 4) * a.ntiles, 1);
+    CgProfScope prof(CG_PROF_HCONV_64, g, st);
+    if (relu) hconv_kernel<64, true, 3, 0><<<mgrid, 512, 0, st>>>(a);
+    else hconv_kernel<64, false, 3, 0><<<mgrid, 512, 0, st>>>(a);
+    return;
+  }
   const bool narrow = g->Co < 8;
   // (narrow outputs: cg_gconv only comes here without gate tensor / residual; no fused form)
   if (hup) {

@@ -202,6 +202,10 @@ FULL_SIZE_CASES = [
     ("resnet128_D_64x64", 128, 64, 64, 128, 128),
     ("resnet128_D_128x128", 128, 128, 128, 64, 64),
     ("resnet128_D_4x4", 128, 4, 4, 512, 512),
+    # four whole 8x8 images per halo tile (hconv_kernel<64, *, 3, 0>): blocks B4 / B5 of the ResNet5
+    # discriminator at the benchmark batch, and a batch that leaves the last image group ragged
+    ("resnet128_D_8x8_c512", 128, 8, 8, 512, 512),
+    ("mi_ragged_n98", 98, 8, 8, 256, 512),
     ("cifar_G_rgb_out", 64, 32, 32, 256, 3),
     ("resnet128_G_rgb_out", 32, 128, 128, 64, 3),
 ]
@@ -228,6 +232,15 @@ def test_gconv_full_size_shapes(K, dev, case):
     y = K.gconv(geom, xb, bt_f, bias=bias)
     _close_on_device(y, ref, name + " fwd bf16", 2.0 * 2.0 ** -8, 2.0 ** -8)
     del ref, y
+    if Co >= 8:
+        # the form a residual block's second convolution / a data gradient takes: ReLU on the input,
+        # gate tensor and residual in the epilogue (resnet_ops.py:165-181)
+        go = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
+        res = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
+        ref = _ref_conv3x3_dev64(torch.relu(x64), w64) * (go > 0).double() + res.double()
+        y = K.gconv(geom, xb, bt_f, gate_in=xb, slope_in=0.0, gate_out=go, slope_out=0.0, residual=res)
+        _close_on_device(y, ref, name + " gated fwd bf16", 2.0 * 2.0 ** -8, 2.0 ** -8)
+        del ref, y, go, res
     # data gradient = convolution of dy with the flipped, transposed filter
     ref_dx = _ref_conv3x3_dev64(dy64, w64.flip(0, 1).transpose(2, 3).contiguous())
     dx = K.gconv(K.geom_adjoint(geom), dyb, bt_b, out_f32=True)
