@@ -147,13 +147,15 @@ class ImageDatasetV2(object):
     return images, labels
 
   # -- on-disk arrays (see the module docstring) ---------------------------------------------------
-  def _load_arrays(self, split):
+  def _load_arrays(self, split, max_examples=None):
     path = os.path.join(self._data_dir, self._name, split + ".npz")
     if not os.path.exists(path):
-      # a TFDS data dir (the reference's --tfds_data_dir): decode the records themselves
+      # a TFDS data dir (the reference's --tfds_data_dir): decode the records themselves (the
+      # evaluation only decodes the examples it takes)
       from compare_gan_amd import tfrecord
       if tfrecord.has_split(self._data_dir, self._name, split == "train"):
-        return tfrecord.load_split(self._data_dir, self._name, split == "train")
+        return tfrecord.load_split(self._data_dir, self._name, split == "train",
+                                   max_examples=max_examples)
       raise ValueError("Dataset %s: no %s (expected arrays `image` uint8 [N,h,w,c] and `label`)" % (
           self._name, path))
     with np.load(path, allow_pickle=False) as f:
@@ -227,7 +229,7 @@ class ImageDatasetV2(object):
     """[num_examples,H,W,C] fp32 in [0,1] from the eval split: the first examples of the
     unshuffled "test" arrays (datasets.py:283-307), or seeded synthetic images."""
     if not self._fake:
-      images, labels = self._load_arrays("test")
+      images, labels = self._load_arrays("test", max_examples=num_examples)
       if len(images) < num_examples:
         raise ValueError("%s: %d eval examples requested, %d on disk" % (
             self._name, num_examples, len(images)))

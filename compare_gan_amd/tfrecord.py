@@ -163,8 +163,8 @@ def decode_image(data):
 
 
 # dataset name -> (TFDS name, train split, eval split, percent slice of the train records or None)
-# (datasets.py:338-514; LSUN: `Split.TRAIN.subsplit([99, 1])` = the first 99 % / the last 1 % of
-# every training shard, datasets.py:413-418)
+# (datasets.py:338-514; LSUN: `Split.TRAIN.subsplit([99, 1])` = records i with i % 100 < 99 / the
+# others of every training shard, datasets.py:413-418)
 TFDS = {
     "mnist": ("mnist", "train", "test", None),
     "fashion_mnist": ("fashion_mnist", "train", "test", None),
@@ -180,9 +180,16 @@ TFDS = {
 
 
 def shard_files(data_dir, tfds_name, split):
+  """The split's shards under <data_dir>/<tfds name>: ONE directory -- with several installed
+  versions / configs (…/3.0.0, …/3.0.1) the last one in sorted order, as TFDS picks the highest
+  version -- never their concatenation."""
   root = os.path.join(data_dir, *tfds_name.split("/"))
   files = sorted(glob.glob(os.path.join(root, "**", "*-%s.tfrecord*" % split), recursive=True))
-  return [f for f in files if not f.endswith(".json")]
+  files = [f for f in files if not f.endswith(".json")]
+  if not files:
+    return files
+  last_dir = sorted(set(os.path.dirname(f) for f in files))[-1]
+  return [f for f in files if os.path.dirname(f) == last_dir]
 
 
 def has_split(data_dir, name, training):
@@ -200,11 +207,12 @@ def load_split(data_dir, name, training, max_examples=None, verify_payload=False
     raise ValueError("no TFRecord shards of %s (%s) under %s" % (name, tname, data_dir))
   images, labels = [], []
   for path in files:
-    recs = list(read_records(path, verify_payload))
-    if pct is not None:
-      cut = len(recs) * pct[0] // 100
-      recs = recs[:cut] if training else recs[cut:]
-    for data in recs:
+    # records are streamed (nothing but the decoded examples that are kept stays in memory).  The
+    # legacy `subsplit([99, 1])` is a repeating 100-record mask per shard: record i of a shard
+    # belongs to the first part iff i % 100 < 99
+    for i, data in enumerate(read_records(path, verify_payload)):
+      if pct is not None and ((i % 100) < pct[0]) != bool(training):
+        continue
       ex = parse_example(data)
       if "image" not in ex:
         raise ValueError("%s: record without an `image` feature (has %s)" % (path, sorted(ex)))

@@ -101,3 +101,25 @@ def test_lsun_subsplit_takes_the_tail_of_every_shard(tmp_path):
     ev, lab = tfrecord.load_split(str(root), "lsun-bedroom", False)
     assert len(tr) == 198 and len(ev) == 2 and lab.tolist() == [0, 0]
     assert tr[0].shape == (140, 150, 3)
+
+
+def test_lsun_subsplit_mask_repeats_every_100_records_and_one_version_is_read(tmp_path):
+    """Legacy `Split.TRAIN.subsplit([99, 1])` (datasets.py:413-418) is a repeating 100-record mask per
+    shard: records 99 and 199 of a 250-record shard are the evaluation part.  With two installed
+    versions of a dataset only the highest one is read (never their concatenation)."""
+    root = tmp_path / "tfds"
+    rng = np.random.RandomState(2)
+    for version, n in (("0.1.0", 120), ("0.1.1", 250)):
+        d = root / "lsun" / "bedroom" / version
+        d.mkdir(parents=True)
+        ims = [np.full((8, 8, 3), i % 256, dtype=np.uint8) for i in range(n)]
+        tfrecord.write_records(str(d / "lsun-train.tfrecord-00000-of-00001"),
+                               [tfrecord.make_example({"image": _png(im)}) for im in ims])
+    del rng
+    tr, _ = tfrecord.load_split(str(root), "lsun-bedroom", True)
+    ev, _ = tfrecord.load_split(str(root), "lsun-bedroom", False)
+    assert len(tr) == 248 and len(ev) == 2
+    assert [int(im[0, 0, 0]) for im in ev] == [99, 199]
+    # max_examples stops the decoding early (the evaluation only takes the first N)
+    few, _ = tfrecord.load_split(str(root), "lsun-bedroom", True, max_examples=5)
+    assert len(few) == 5 and [int(im[0, 0, 0]) for im in few] == [0, 1, 2, 3, 4]
