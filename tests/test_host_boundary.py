@@ -255,6 +255,18 @@ def test_library_argument_errors_without_gpu():
   assert rc == -2
 
 
+def test_deferred_reduction_switch_without_gpu():
+  """cg_reduce_defer_*: the recording switch is host state (no launch until a flush has something to
+  run): begin / pending / abort work without a device and leave the switch off."""
+  from compare_gan_amd.hip import _lib
+  lib = _lib.load()
+  assert lib.cg_reduce_defer_pending() == 0
+  assert lib.cg_reduce_defer_begin() == 0
+  assert lib.cg_reduce_defer_pending() == 0
+  assert lib.cg_reduce_defer_abort() == 0
+  assert lib.cg_reduce_defer_pending() == 0
+
+
 def test_product_refuses_cpu_tensors():
   from compare_gan_amd.hip import kernels as K
   with pytest.raises(ValueError, match="no CPU fallback"):
@@ -388,7 +400,8 @@ def test_small_conv_swizzle_is_conflict_free():
     and every 16-byte k chunk, the 16 lanes of each ds_read_b128 service group (MI355X_MICROARCH.md,
     LDS table: {0-3,12-15,20-27}, {4-11,16-19,28-31} of a half wave) must hit 16 distinct 16-byte
     bank groups of the 256-byte LDS row.  Window rows are 128 B (row r -> bank groups 8 (r % 2) + c),
-    weight-unit rows are 64 B."""
+    weight-unit rows are 64 B.  hconv_kernel's multi-image tiles (cg_conv_halo.hip, TWL == 3: four
+    8x8 images with 10x10 windows) use the 8x8 swizzle and pixel order checked here."""
     groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
               list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
     for tw, swz in ((8, lambda il, y, x: ((x >> 1) & 3) | ((y & 1) << 2)),

@@ -232,9 +232,14 @@ def test_gconv_full_size_shapes(K, dev, case):
     y = K.gconv(geom, xb, bt_f, bias=bias)
     _close_on_device(y, ref, name + " fwd bf16", 2.0 * 2.0 ** -8, 2.0 ** -8)
     del ref, y
-    if Co >= 8:
+    import os
+    off_by_default = os.environ.get("CGAMD_PCONV", "0") != "0" or os.environ.get("CGAMD_QCONV", "0") != "0"
+    if Co >= 8 and not off_by_default:
         # the form a residual block's second convolution / a data gradient takes: ReLU on the input,
-        # gate tensor and residual in the epilogue (resnet_ops.py:165-181)
+        # gate tensor and residual in the epilogue (resnet_ops.py:165-181).  (Not under the child runs
+        # of test_persistent_conv_at_the_benchmark_shapes: the off-by-default kernels' gated forms are
+        # covered at the variant test's sizes only -- this check was added after the round's last GPU
+        # visit and has only been run with the default dispatch.)
         go = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
         res = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
         ref = _ref_conv3x3_dev64(torch.relu(x64), w64) * (go > 0).double() + res.double()
