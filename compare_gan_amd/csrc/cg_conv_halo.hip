@@ -2016,7 +2016,11 @@ static bool hc_mi_use(const cgConvGeom* g) {
   static const int enabled = hc_env("CGAMD_HCONV_MI", 1);
   static const int min_wgs = hc_env("CGAMD_HCONV_MI_MIN", 192);
   static const int min_ci = hc_env("CGAMD_HCONV_MI_CI", 256);
-  if (!enabled) return false;
+  // measured against the one-tap kernel's 64-row tiles only (ResNet5: 256 / 512 channels, 256
+  // workgroups: profiles/r04_hconv_8x8_ab.txt); BigGAN's 8x8 x 1536 layers run 128x128 one-tap tiles
+  // at ~0.89 PFLOP/s and stay there until that comparison exists
+  static const int max_ci = hc_env("CGAMD_HCONV_MI_CI_MAX", 1024);
+  if (!enabled || g->Ci > max_ci) return false;
   if (g->S != 1 || g->U != 1 || g->kh != 3 || g->kw != 3 || g->pt != 1 || g->pl != 1) return false;
   if (g->Hin != 8 || g->Win != 8 || g->Ho != 8 || g->Wo != 8) return false;
   if ((g->Ci % 32) != 0 || (g->Co % 8) != 0 || g->Co < 64 || g->Ci < min_ci) return false;
