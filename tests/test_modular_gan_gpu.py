@@ -15,6 +15,8 @@ Two oracles are used (both fp64 arithmetic, see oracle/arch_ops.py VarStore.emul
 Stated tolerances:
   images      max |diff| <= 0.03 (values in [0,1]), mean |diff| <= 5e-3                 (exact)
   losses      |diff| <= 2e-2 * max(1, |ref|)                                             (exact)
+              generator loss taken AFTER several Adam updates of D within a step: 4e-2 (its
+              spread is 0.3-2.9 % between builds that differ in fp32 summation order only)
   gradients   per tensor: cosine >= COS and rel-L2 <= REL, or (tensors that are ~0 by
               construction, e.g. a bias in front of batch norm) |diff| <= 2e-3 * largest grad norm
               exact oracle:        COS 0.97, REL 0.35 (sndcgan_celebahq128.gin, whose generator
@@ -773,7 +775,9 @@ def test_joint_gen_for_disc_step_against_oracle(dev):
     print("joint: product", d_p, "oracle", d_o, "oracle with separate calls", d_s)
     for a, b in zip(d_p, d_o):
         assert abs(a - b) <= 2e-2 * max(1.0, abs(b))
-    assert abs(float(out["g_loss"]) - g_o) <= 2e-2 * max(1.0, abs(g_o))
+    # (generator loss after five sign-like Adam updates of D: the 4e-2 band of
+    # test_train_steps_resnet_cifar, where the measured spread is written down)
+    assert abs(float(out["g_loss"]) - g_o) <= 4e-2 * max(1.0, abs(g_o))
     # the option is not a no-op: joint statistics move the first loss away from the separate calls'
     assert abs(d_o[0] - d_s[0]) > 1e-6
 
@@ -804,7 +808,7 @@ def test_not_unrolled_step_against_oracle(dev):
         d_p, g_p = float(out["d_losses"][0]), float(out["g_loss"])
         print("call", call, "d", d_p, d_o, "g", g_p, g_o)
         assert abs(d_p - d_o) <= 2e-2 * max(1.0, abs(d_o))
-        assert abs(g_p - g_o) <= 2e-2 * max(1.0, abs(g_o))
+        assert abs(g_p - g_o) <= 4e-2 * max(1.0, abs(g_o))   # (see test_train_steps_resnet_cifar)
         moved = any(not torch.equal(v, g_before[n])
                     for n, v in gan.store.trainable_variables("generator"))
         assert moved == (call >= 1), "generator update on the wrong call (%d)" % call
