@@ -123,7 +123,9 @@ class deferred_wgrads(object):
   def __enter__(self):
     self._old = _DEFER["on"]
     _DEFER["on"] = self._enabled
-    if self._enabled and _DEFER_REDUCE:
+    # (not together with the side-stream weight gradients: the recorded reductions are launched on
+    # the stream that is current at the flush, the partials would be written on the side stream)
+    if self._enabled and _DEFER_REDUCE and not _WGRAD["enabled"]:
       K.reduce_defer_begin()
     return self
 
@@ -131,7 +133,7 @@ class deferred_wgrads(object):
     _DEFER["on"] = self._old
     if etype is None:
       flush_wgrads()
-      if self._old and _DEFER_REDUCE:
+      if self._old and _DEFER_REDUCE and not _WGRAD["enabled"]:
         K.reduce_defer_begin()    # an enclosing context keeps recording
     else:
       del _DEFER["jobs"][:]
@@ -148,7 +150,7 @@ def flush_wgrads():
   _DEFER["wptrs"].clear()
   if K.reduce_defer_active():
     K.reduce_defer_flush()
-    if _DEFER["on"] and _DEFER_REDUCE:
+    if _DEFER["on"] and _DEFER_REDUCE and not _WGRAD["enabled"]:
       K.reduce_defer_begin()
 
 
