@@ -94,12 +94,20 @@ def cpu_baseline(config, batch, budget_s=20.0, mode="step", no_penalty=False):
         d_loss, _, _ = ora.create_loss(sub["images"], generated, None, None, sub["alpha"])
         ora.d_opt.step(torch.autograd.grad(d_loss, ora.d_vars()))
 
-    steps, t0 = 0, time.time()
-    while True:
+    def one():
         if mode == "step":
             ora.train_step(subs)
         else:
             dstep(subs[0])
+
+    # the first unit creates the variables and the optimiser slots and pages the oneDNN kernels in
+    # (5x run-to-run spread when it was part of the sample): run it untimed
+    t_first = time.time()
+    one()
+    t_first = time.time() - t_first
+    steps, t0 = 0, time.time()
+    while True:
+        one()
         steps += 1
         dt = time.time() - t0
         if dt >= budget_s or steps >= 8:
@@ -110,8 +118,8 @@ def cpu_baseline(config, batch, budget_s=20.0, mode="step", no_penalty=False):
     return {"value": round(batch * nsub * steps / dt, 2), "unit": "img/s",
             "cores": cores, "kind": "port", "batch": batch,
             "sample": "%s of %s at batch %d in %.1f s, fp32 PyTorch-CPU restatement of the "
-                      "reference (oracle/); the first one includes variable creation" % (
-                          what, config, batch, dt)}
+                      "reference (oracle/); one untimed unit before them (variable creation, %.1f s)" % (
+                          what, config, batch, dt, t_first)}
 
 
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
@@ -428,6 +436,16 @@ def main():
         eval_utils.get_inception(dev)
         torch.cuda.synchronize()
         t_setup = time.perf_counter() - t_setup
+        # one small untimed evaluation first (two generator batches through every phase), as the
+        # train steps have their warm-up: on a freshly leased box the first use of each kernel
+        # pages its code object in from a cold image (30 s in the sampling phase on the
+        # driver's fresh box, 0.3 s on a warm one).  Its wall-clock is REPORTED (cold_start_s)
+        t_cold = time.perf_counter()
+        eval_gan_lib.evaluate_gan(gan, [is_lib.InceptionScoreTask(), fid_lib.FIDScoreTask()],
+                                  num_averaging_runs=1, num_test_examples=128)
+        torch.cuda.synchronize()
+        t_cold = time.perf_counter() - t_cold
+        cold_split = {k: round(v, 3) for k, v in eval_gan_lib.LAST_TIMING.items()}
         t0 = time.perf_counter()
         res = eval_gan_lib.evaluate_gan(gan, [is_lib.InceptionScoreTask(), fid_lib.FIDScoreTask()],
                                         num_averaging_runs=1)
@@ -437,8 +455,11 @@ def main():
             "wall_s": round(t_eval + t_setup, 3), "eval_s": round(t_eval, 3),
             "num_examples": n_eval,
             "extractor_setup_s": round(t_setup, 3),
+            "cold_start_s": round(t_cold, 3), "cold_start_split_s": cold_split,
             "wall_definition": "building the Inception extractor (weights, MFMA operand images) + "
-                               "sampling + features of 2 x 10,000 images + fp64 statistics",
+                               "sampling + features of 2 x 10,000 images + fp64 statistics; NOT "
+                               "included: cold_start_s, one untimed 128-image evaluation before it "
+                               "(first use of every kernel of the evaluation path)",
             "split_s": {k: round(v, 3) for k, v in eval_gan_lib.LAST_TIMING.items()},
             "fid": round(float(res["fid_score_mean"]), 4),
             "inception_score": round(float(res["inception_score_mean"]), 4),
@@ -526,7 +547,16 @@ def main():
             # only the tail of a long line still sees them
             f = result["fid10k"]
             result["fid10k_wall_s"] = f["wall_s"]
+            result["fid10k_cold_start_s"] = f["cold_start_s"]
             result["fid10k_split_s"] = f["split_s"]
+        # ... and so do the north-star legs (they sat mid-line and were cut off)
+        for key in ("resnet128_dstep", "resnet128_dstep_gp", "biggan128", "biggan128_bs256",
+                    "sndcgan128"):
+            leg = result.get(key)
+            if isinstance(leg, dict) and "ms" in leg:
+                result[key + "_ms"] = leg["ms"]
+                result[key + "_frac"] = leg["frac"]
+                result[key + "_img_per_s"] = leg["img_per_s"]
         sys.stdout.write(json.dumps(result) + "\n")
     sys.stdout.flush()
     sys.stderr.flush()

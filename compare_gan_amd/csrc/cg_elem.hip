@@ -425,6 +425,36 @@ __global__ void axpby_f32_kernel(const float* __restrict__ a, float alpha,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
+// out = x * scale; *nan_count += NaNs of x (one atomic per wave that saw one)
+__global__ __launch_bounds__(256) void scale_count_nan_kernel(const float* __restrict__ x,
+                                                              float scale, float* __restrict__ out,
+                                                              int64_t n, int* __restrict__ nan_count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int bad = 0;
+  if ((((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      bad += (v.x != v.x) + (v.y != v.y) + (v.z != v.z) + (v.w != v.w);
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      reinterpret_cast<float4*>(out)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      const float v = x[i];
+      bad += v != v;
+      out[i] = v * scale;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      const float v = x[i];
+      bad += v != v;
+      out[i] = v * scale;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(nan_count, bad);
+}
 __global__ void axpy_dev_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ o,
                                 const float* __restrict__ sigma, bf16_t* __restrict__ out,
                                 int64_t n) {
@@ -796,6 +826,19 @@ extern "C" int cg_axpby_f32(const float* a, float alpha, const float* b, float b
   if (!a || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_axpby_f32: null pointer");
   axpby_f32_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(a, alpha, b, beta, out, n);
   CG_CHECK_LAUNCH("cg_axpby_f32");
+  return CG_OK;
+}
+
+extern "C" int cg_scale_count_nan_f32(const float* x, float scale, float* out, int64_t n,
+                                      int32_t* nan_count, cgStream stream) {
+  CG_NONNEG(n, "cg_scale_count_nan_f32");
+  if (n == 0) return CG_OK;
+  if (!x || !out || !nan_count) CG_FAIL(CG_ERR_BAD_ARG, "cg_scale_count_nan_f32: null pointer");
+  int64_t b = (n / 4 + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  scale_count_nan_kernel<<<(int)b, 256, 0, (hipStream_t)stream>>>(x, scale, out, n, nan_count);
+  CG_CHECK_LAUNCH("cg_scale_count_nan_f32");
   return CG_OK;
 }
 

@@ -87,8 +87,8 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
     return gan.generate(z, labels)
 
   import time
-  timing = {"accumulators": 0.0, "sample": 0.0, "inception": 0.0, "gather": 0.0, "stats": 0.0,
-            "ranks": world}
+  timing = {"accumulators": 0.0, "sample": 0.0, "sample_first_batch": 0.0, "inception": 0.0,
+            "gather": 0.0, "stats": 0.0, "ranks": world}
 
   def tick():
     torch.cuda.synchronize(device)
@@ -105,8 +105,9 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
     fake_dsets = []
     for i in range(num_averaging_runs):
       images, activations, logits, nan_found = eval_shard.sharded_fake_features(
-          lambda index: eval_utils.to_eval_images(generate(index)), transform, num_batches,
-          next_index, rank, world, keep_images=(world == 1 and i == 0), timing=timing, tick=tick)
+          generate, transform, num_batches, next_index, rank, world,
+          keep_images=(world == 1 and i == 0), timing=timing, tick=tick,
+          sink_cls=eval_utils.FakeImageSink)
       next_index += num_batches
       if nan_found:
         raise eval_utils.NanFoundError("Detected NaN in fake images.")

@@ -107,10 +107,29 @@ def any_rank(flag, device, world, group=None):
   return bool(t.item() > 0)
 
 
+class TorchImageSink(object):
+  """Collects the batches of one rank: concatenation + NaN test with torch ops (any device)."""
+
+  def __init__(self, num_batches):
+    del num_batches
+    self._imgs = []
+
+  def add(self, images):
+    self._imgs.append(images)
+
+  def finish(self):
+    local = torch.cat(self._imgs, dim=0)
+    return local, bool(torch.isnan(local).any())
+
+
 def sharded_fake_features(generate_batch, transform, num_batches, first_index, rank, world,
-                          keep_images=True, group=None, timing=None, tick=None):
-  """One fake evaluation set.  generate_batch(index) -> [B, H, W, C] images in [0, 255] of global
-  batch `index`; transform(images) -> (activations, logits).  Returns (images or None, activations,
+                          keep_images=True, group=None, timing=None, tick=None, sink_cls=None):
+  """One fake evaluation set.  generate_batch(index) -> [B, H, W, C] images of global batch
+  `index`; transform(images) -> (activations, logits).  sink_cls(num_local_batches) collects this
+  rank's batches (add) and returns (all of them [n * B, H, W, C], NaN seen) from finish():
+  TorchImageSink keeps them as they come (images already in [0, 255]); the product passes
+  eval_utils.FakeImageSink, whose one HIP pass per batch scales [0, 1] -> [0, 255] straight into the
+  set's buffer and counts NaNs (eval_utils.py:144-162).  Returns (images or None, activations,
   logits, nan_found) with all `num_batches` batches in order on every rank."""
   def lap(key, since):
     if timing is None or tick is None:
@@ -121,15 +140,22 @@ def sharded_fake_features(generate_batch, transform, num_batches, first_index, r
 
   t = tick() if tick is not None else None
   mine = shard_indices(num_batches, rank, world)
-  imgs = [generate_batch(first_index + i) for i in mine]
-  local = torch.cat(imgs, dim=0)
-  nan_found = any_rank(bool(torch.isnan(local).any()), local.device, world, group)
+  sink = (sink_cls or TorchImageSink)(len(mine))
+  for j, i in enumerate(mine):
+    sink.add(generate_batch(first_index + i))
+    if j == 0 and timing is not None and tick is not None:
+      # the first batch on its own: a one-off cost (code objects paged in on a fresh box, allocator
+      # growth) shows up here instead of hiding in the phase total
+      timing["sample_first_batch"] = tick() - t
+  local, local_nan = sink.finish()
+  nan_found = any_rank(local_nan, local.device, world, group)
   t = lap("sample", t)
   if nan_found:
     return None, None, None, True
   act, logits = transform(local)
   t = lap("inception", t)
-  bsz = imgs[0].shape[0]
+  bsz = local.shape[0] // max(1, len(mine))
+  imgs = list(local.reshape((len(mine), bsz) + tuple(local.shape[1:]))) if world > 1 else None
   if world == 1:
     return (local if keep_images else None), act, logits, False
   act = gather_in_order(list(act.reshape((len(mine), bsz) + tuple(act.shape[1:]))), num_batches,

@@ -533,6 +533,19 @@ def scale_f32(x, scale_dev=None, scale_host=1.0):
     return out
 
 
+def scale_count_nan(x, scale, out, nan_count):
+    """out = x * scale (fp32, same shape, may be a slice of a larger buffer) and nan_count[0] +=
+    NaNs of x (int32 device tensor): eval_utils.FakeImageSink."""
+    _req(x, F32, "x")
+    _req(out, F32, "out")
+    _req(nan_count, torch.int32, "nan_count")
+    if out.numel() != x.numel():
+        raise ValueError("out must have as many elements as x")
+    check(lib().cg_scale_count_nan_f32(_p(x), float(scale), _p(out), x.numel(), _p(nan_count),
+                                       _stream()), "cg_scale_count_nan_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------------

@@ -388,6 +388,12 @@ int cg_axpby(const void* a, float alpha, const void* b, float beta, void* out, i
  * d_loss += lambda * penalty, modular_gan.py:670).  b may be NULL. */
 int cg_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, int64_t n,
                  cgStream stream);
+/* out = x * scale on fp32 and *nan_count += (number of NaNs in x): the sampled images of an
+ * evaluation set are scaled to [0, 255] and tested with np.isnan (eval_utils.py:144-162) -- one
+ * pass per generator batch, written straight into the batch's slot of the set.  nan_count: int32 on
+ * the device, zeroed by the caller; out may alias x. */
+int cg_scale_count_nan_f32(const float* x, float scale, float* out, int64_t n, int32_t* nan_count,
+                           cgStream stream);
 /* out = x + (*sigma) * o on bf16 with a device-resident trainable scalar
  * (arch_ops.py:755-758 `x + sigma * attn_g`); x may be NULL (out = sigma * o). */
 int cg_axpy_dev(const void* x, const void* o, const float* sigma, void* out, int64_t n,
