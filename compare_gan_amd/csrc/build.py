@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcgamd.so")
-SOURCES = ["cg_error.hip", "cg_gconv.hip", "cg_conv_fast.hip", "cg_conv_halo.hip", "cg_conv_pers.hip", "cg_conv_small.hip", "cg_multi.hip", "cg_elem.hip", "cg_bn.hip", "cg_sn.hip",
+SOURCES = ["cg_error.hip", "cg_gconv.hip", "cg_conv_fast.hip", "cg_conv_halo.hip", "cg_conv_small.hip", "cg_multi.hip", "cg_elem.hip", "cg_bn.hip", "cg_sn.hip",
            "cg_optim.hip", "cg_attn.hip", "cg_fid.hip", "cg_calib.hip", "cg_ln.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -71,31 +71,8 @@ def build_timing():
     return out
 
 
-def build_ablate():
-    """libcgamd_ablate.so: the regular objects with cg_conv_pers.hip rebuilt under -DCG_CONV_ABLATE
-    (CGAMD_PCONV_DBG switches parts of the persistent kernel off: scripts/pconv_ablate.py)."""
-    build()
-    odir = os.path.join(LIB_DIR, "obj")
-    obj = os.path.join(LIB_DIR, "obj_timing", "cg_conv_pers_ablate.o")
-    os.makedirs(os.path.dirname(obj), exist_ok=True)
-    r = subprocess.run([HIPCC] + FLAGS + ["-DCG_CONV_ABLATE", "-c", os.path.join(HERE, "cg_conv_pers.hip"),
-                        "-o", obj], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n%s\n%s" % (r.stdout, r.stderr))
-    objs = [obj if s == "cg_conv_pers.hip" else os.path.join(odir, os.path.splitext(s)[0] + ".o")
-            for s in SOURCES]
-    out = os.path.join(LIB_DIR, "libcgamd_ablate.so")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return out
-
-
 if __name__ == "__main__":
-    if "--ablate" in sys.argv:
-        print(build_ablate())
-    elif "--timing" in sys.argv:
+    if "--timing" in sys.argv:
         print(build_timing())
     else:
         print(build(force="--force" in sys.argv))

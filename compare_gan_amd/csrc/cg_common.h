@@ -120,8 +120,6 @@ enum {
   CG_PROF_GWGRAD_GENERIC,         // gwgrad_kernel<...>
   CG_PROF_SCONV,                  // sconv_kernel<*> (cg_conv_small.hip)
   CG_PROF_SWGRAD,                 // swgrad_kernel<*> (cg_conv_small.hip)
-  CG_PROF_PCONV_128,              // pconv_kernel<128, *> (cg_conv_pers.hip)
-  CG_PROF_PCONV_64,               // pconv_kernel<64, *>
   CG_PROF_COUNT
 };
 void cg_prof_begin(int family, double flops, double bytes, hipStream_t st);

@@ -25,27 +25,6 @@ void cg_hconv_rw_launch(const cgConvGeom* g, const void* in, const void* bt, voi
                         int out_is_f32, const float* bias, const void* gate_in,
                         const void* gate_out, float slope_out, const void* residual,
                         hipStream_t st);
-// persistent deep-pipelined form for 3x3 'SAME' filters on maps of 16x32-pixel tiles
-// (cg_conv_pers.hip).  Its weights come from a fragment-ordered image that cg_weight_prep* append
-// to the row-major one: cg_weight_frag_elems(taps, Cin, rows) bf16 elements (0: not eligible).
-size_t cg_weight_frag_elems(int T, int Cin, int R);
-struct cgFragJob {
-  const void* rowmajor;   // [R][Kp] bf16, k = tap * Cin + c
-  void* frag;
-  int R, Cin;
-};
-void cg_weight_frag_launch(const cgFragJob* jobs, int n, hipStream_t st);
-bool cg_pconv_geom_ok(const cgConvGeom* g);
-bool cg_pconv_use(const cgConvGeom* g);   // geometry + grid-size policy
-int cg_pconv_stats_rows(const cgConvGeom* g);
-// the same K loop as two independent 4-wave workgroups per CU on 8x32 tiles (hconv_kernel's rows)
-bool cg_qconv_use(const cgConvGeom* g);
-void cg_qconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out, int out_is_f32,
-                     const float* bias, const void* gate_in, const void* gate_out, float slope_out,
-                     const void* residual, const cgConvFusion* fu, hipStream_t st);
-void cg_pconv_launch(const cgConvGeom* g, const void* in, const void* bt, void* out, int out_is_f32,
-                     const float* bias, const void* gate_in, const void* gate_out, float slope_out,
-                     const void* residual, const cgConvFusion* fu, hipStream_t st);
 // small-map 3x3 form: 64-pixel x 64-channel workgroups, K split over the waves (cg_conv_small.hip)
 bool cg_sconv_geom_ok(const cgConvGeom* g);
 bool cg_sconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in);

@@ -2049,7 +2049,6 @@ bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in
 int cg_hconv_stats_phases(const cgConvGeom* g) { return hup_geom_ok(g) ? 1 : g->U * g->U; }
 
 int cg_hconv_stats_rows(const cgConvGeom* g) {
-  if (!cg_qconv_use(g) && cg_pconv_use(g)) return cg_pconv_stats_rows(g);   // one row per 16x32 tile
   if (hup_geom_ok(g)) return g->N * (g->Hin / HU_TH) * (g->Win / HU_TW);   // one row per tile
   const int Hp = g->Ho / g->U, Wp = g->Wo / g->U;
   return g->U * g->U * g->N * (Hp * Wp / 256);
@@ -2077,21 +2076,6 @@ void cg_hconv_launch_fused(const cgConvGeom* g, const void* in, const void* bt, 
     hconv_rw_launch_ex(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual,
                        fu->pool_out ? 1 : 0, fu->in_up ? 1 : 0,
                        fu->out_scale != 0.f ? fu->out_scale : 1.f, st);
-    return;
-  }
-  // persistent deep-pipelined form (cg_conv_pers.hip) wherever its 16x32 tiles fill the chip.  Not
-  // with a gate tensor in the epilogue (data gradients): every persistent workgroup reaches its
-  // epilogue at the same time, and reading the gate on top of writing the output doubles a burst that
-  // is already bound by HBM (measured: 180 -> 190 us on 128 x 64^2 x 128 -> 128; CGAMD_PCONV_GATED=1)
-  if (cg_qconv_use(g) && !(fu && fu->pool_out && fu->in_up)) {
-    cg_qconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fu, st);
-    return;
-  }
-  static const int pc_gated = hc_env("CGAMD_PCONV_GATED", 0);
-  const bool gated = gate_out != nullptr && gate_out != out;
-  if (!cg_qconv_use(g) && cg_pconv_use(g) && !(fu && fu->pool_out && fu->in_up) &&
-      (pc_gated || !gated || (fu && fu->stats_out))) {   // (statistics rows follow cg_pconv_use)
-    cg_pconv_launch(g, in, bt, out, out_is_f32, bias, gate_in, gate_out, slope_out, residual, fu, st);
     return;
   }
   const bool mi = hc_mi_use(g);   // (8x8 maps: no fused form reaches this launcher)

@@ -35,8 +35,7 @@ const char* const g_prof_names[CG_PROF_COUNT] = {
     "fast_conv_kernel<128, 32, *>",  "stem_fwd_kernel<*>",           "gconv_kernel<...>",
     "hwgrad_kernel<*>",              "halo_wgrad_kernel<*>",
     "fast_wgrad_kernel<128, *>",     "fast_wgrad_kernel<64, *>",     "stem_wgrad_kernel<*>",
-    "gwgrad_kernel<...>",            "sconv_kernel<*>",              "swgrad_kernel<*>",
-    "pconv_kernel<128, *>",          "pconv_kernel<64, *>"};
+    "gwgrad_kernel<...>",            "sconv_kernel<*>",              "swgrad_kernel<*>"};
 }  // namespace
 
 bool cg_prof_enabled() { return g_prof_on; }

@@ -776,7 +776,7 @@ extern "C" size_t cg_weight_prep_elems(int kh, int kw, int Ci, int Co, int which
   if (kh <= 0 || kw <= 0 || Ci <= 0 || Co <= 0) return 0;
   const int T = kh * kw;
   const int Cin = which ? Co : Ci, R = which ? Ci : Co;
-  return (size_t)R * ((T * Cin + 7) & ~7) + cg_weight_frag_elems(T, Cin, R);
+  return (size_t)R * ((T * Cin + 7) & ~7);
 }
 
 extern "C" int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,
@@ -798,25 +798,6 @@ extern "C" int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, co
     if (blocks > 4096) blocks = 4096;
     prep_bwd_kernel<<<blocks, 256, 0, st>>>(w, T, Ci, Co, Kbp, scale, (bf16_t*)bt_bwd);
     CG_CHECK_LAUNCH("cg_weight_prep(bwd)");
-  }
-  // the fragment-ordered copies behind the row-major images (cg_weight_prep_elems)
-  cgFragJob jobs[2];
-  int nj = 0;
-  if (bt_fwd && cg_weight_frag_elems(T, Ci, Co)) {
-    jobs[nj].rowmajor = bt_fwd;
-    jobs[nj].frag = (bf16_t*)bt_fwd + (size_t)Co * ((T * Ci + 7) & ~7);
-    jobs[nj].R = Co; jobs[nj].Cin = Ci;
-    ++nj;
-  }
-  if (bt_bwd && cg_weight_frag_elems(T, Co, Ci)) {
-    jobs[nj].rowmajor = bt_bwd;
-    jobs[nj].frag = (bf16_t*)bt_bwd + (size_t)Ci * ((T * Co + 7) & ~7);
-    jobs[nj].R = Ci; jobs[nj].Cin = Co;
-    ++nj;
-  }
-  if (nj) {
-    cg_weight_frag_launch(jobs, nj, st);
-    CG_CHECK_LAUNCH("cg_weight_prep(fragments)");
   }
   return CG_OK;
 }

@@ -475,19 +475,6 @@ extern "C" int cg_weight_prep_multi(const cgPrepItem* items, int n, cgStream str
     if (bb > 0) prep_bwd_multi_kernel<<<bb, 256, 0, st>>>(c);
     CG_CHECK_LAUNCH("cg_weight_prep_multi");
   }
-  // the fragment-ordered copies behind the row-major images (cg_weight_prep_elems)
-  std::vector<cgFragJob> jobs;
-  for (int i = 0; i < n; ++i) {
-    const cgPrepItem& t = items[i];
-    if (t.bt_fwd && cg_weight_frag_elems(t.T, t.Ci, t.Co))
-      jobs.push_back({t.bt_fwd, (bf16_t*)t.bt_fwd + (size_t)t.Co * ((t.T * t.Ci + 7) & ~7), t.Co, t.Ci});
-    if (t.bt_bwd && cg_weight_frag_elems(t.T, t.Co, t.Ci))
-      jobs.push_back({t.bt_bwd, (bf16_t*)t.bt_bwd + (size_t)t.Ci * ((t.T * t.Co + 7) & ~7), t.Ci, t.Co});
-  }
-  if (!jobs.empty()) {
-    cg_weight_frag_launch(jobs.data(), (int)jobs.size(), st);
-    CG_CHECK_LAUNCH("cg_weight_prep_multi(fragments)");
-  }
   return CG_OK;
 }
 

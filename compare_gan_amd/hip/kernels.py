@@ -113,8 +113,6 @@ def weight_prep(w, scale=None, want_fwd=True, want_bwd=False):
     _req(scale, F32, "scale", True)
     kh, kw, Ci, Co = w.shape
     bt_f = bt_b = None
-    # the allocations may be larger than the row-major image: the fragment-ordered copy of the
-    # same weights follows it (cg_weight_prep_elems, cgamd.h); the returned view keeps it alive
     if want_fwd:
         Kp = (kh * kw * Ci + 7) // 8 * 8
         buf = torch.empty(_prep_elems(kh, kw, Ci, Co, 0), dtype=BF16, device=w.device)
@@ -484,8 +482,7 @@ def weight_prep_multi(weights4d, want_fwd=True, want_bwd=False):
         kh, kw, Ci, Co = w.shape
         f_sizes.append(_prep_elems(kh, kw, Ci, Co, 0) if want_fwd else 0)
         b_sizes.append(_prep_elems(kh, kw, Ci, Co, 1) if want_bwd else 0)
-    # every image starts 16-byte aligned (sizes are multiples of 8 bf16 elements); an image may be
-    # followed by its fragment-ordered copy (cg_weight_prep_elems)
+    # every image starts 16-byte aligned (sizes are multiples of 8 bf16 elements)
     fbuf = _carve(torch.empty(sum(f_sizes), dtype=BF16, device=dev), f_sizes)
     bbuf = _carve(torch.empty(sum(b_sizes), dtype=BF16, device=dev), b_sizes)
     items = (_lib.PrepItem * n)()

@@ -91,12 +91,7 @@ typedef struct {
  *            k' = (r'*kw+s')*Co+co contiguous                                    -> data-gradient /
  *            conv2d_transpose form.
  * Buffer sizes: cg_weight_prep_elems(kh, kw, Ci, Co, which) bf16 elements (which = 0: bt_fwd,
- * 1: bt_bwd).  For 3x3 filters with channel counts that are multiples of 32 this is MORE than the
- * row-major image: the same weights follow it in MFMA-fragment order ([rows/32][Cin/64][9 taps]
- * [4 k-steps][64 lanes][8]: every wave load of the persistent convolution kernel is 1 KiB
- * contiguous), and cg_gconv / cg_gconv_fused read that second image behind the `bt` they are
- * given.  Both prep entry points write both images; a `bt` built any other way must have the
- * size this function returns and carry the fragment image too.
+ * 1: bt_bwd): the row-major image with K padded to a multiple of 8.
  */
 size_t cg_weight_prep_elems(int kh, int kw, int Ci, int Co, int which);
 int cg_weight_prep(const float* w, int kh, int kw, int Ci, int Co, const float* scale,

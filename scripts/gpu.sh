@@ -11,15 +11,13 @@
 #   stats WORKLOAD [TAG]            rocprofv3 --kernel-trace --stats summary (csv):
 #                                   WORKLOAD = cifar | fid | resnet128_dstep | resnet128_dstep_gp | biggan128
 #   traffic WORKLOAD                the two --pmc passes (FETCH_SIZE, WRITE_SIZE; own runs, no other
-#                                   trace domain) + scripts/pmc_traffic.py -> gpurun_out/r04_pmc_traffic.json
+#                                   trace domain) + scripts/pmc_traffic.py -> gpurun_out/r05_pmc_traffic.json
 #                                   WORKLOAD = cifar | resnet128_dstep
 #   ab VAR V1,V2,... LEG [TAG]      the same build under VAR=V1, VAR=V2, ... on one box (boxes of the
 #                                   pool differ by +-15 % in clocks): bench.py --legs LEG, prints the
 #                                   headline step, the leg's step and its per-family kernel times
 #   ablib LEGS [TAG]                lib/libcgamd_prev.so (a build of an earlier commit, made by hand) against
 #                                   lib/libcgamd.so through CGAMD_LIB_PATH, alternating twice: bench.py --legs LEGS
-#   pconv [TAG]                     persistent convolution kernel (cg_conv_pers.hip): parity under its forced
-#                                   variants + per-shape timings with the kernel off / on / in its 2x4 wave layout
 #   dp [TAG]                        CGAMD_FORCE_DP=1: the data-parallel path on a one-rank RCCL group
 #                                   (bucket, all-reduce captured in the hipGraph, bucketed overlap on / off)
 #   final [TAG]                     full + bench (all legs) + stats cifar / resnet128_dstep / fid + dp
@@ -91,7 +89,7 @@ case $task in
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$W /tmp/pw_$W &&
       timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$W -o p -- $CMD > "$R/gpurun_out/traffic_pf_$W.log" 2>&1 &&
       timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$W -o p -- $CMD > "$R/gpurun_out/traffic_pw_$W.log" 2>&1 )
-    python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r04_pmc_traffic.json $W | head -14 ;;
+    python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r05_pmc_traffic.json $W | head -14 ;;
   ab) VAR=$1; VALS=$2; LEG=$3; TAG=${4:-ab}
     for v in ${VALS//,/ }; do
       env $VAR=$v timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fid --no-roofline --legs $LEG \
@@ -106,25 +104,6 @@ case $task in
           --legs $LEGS > gpurun_out/${TAG}_${which}$rep.json 2> gpurun_out/${TAG}_${which}$rep.err
         for L in ${LEGS//,/ }; do echo "$which $rep: $(leg_summary gpurun_out/${TAG}_${which}$rep.json $L)"; done
       done
-    done ;;
-  pconv) TAG=${1:-pconv}   # the persistent kernel: parity under its forced variants, then per-shape A/B
-    KSEL="(test_gconv_forward_adjoint_wgrad and (pc_ or fast_big or hc_)) or test_gconv_gates_residual or (test_conv_pool_fused and not full_size) or (test_gconv_fused_batch_norm and not full_size) or test_gconv_fused_statistics_groups"
-    CGAMD_PCONV_MIN=1 CGAMD_HCONV_MIN=1 CGAMD_HCONV_RW=0 timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "$KSEL" 2>&1 | tail -12 | tee gpurun_out/${TAG}_t_all.txt
-    CGAMD_PCONV_MIN=1 CGAMD_PCONV_GRID=3 CGAMD_HCONV_MIN=1 CGAMD_HCONV_RW=0 timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "$KSEL" 2>&1 | tail -12 | tee gpurun_out/${TAG}_t_walk.txt
-    CGAMD_PCONV_MIN=1 CGAMD_PCONV_GRID=5 CGAMD_PCONV_WM2=1 CGAMD_HCONV_MIN=1 timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "$KSEL" 2>&1 | tail -12 | tee gpurun_out/${TAG}_t_wm2.txt
-    timeout 900 python -m pytest -q -m gpu tests/test_kernels_gpu.py -x -k "full_size" 2>&1 | tail -8 | tee gpurun_out/${TAG}_t_full.txt
-    for v in "CGAMD_PCONV=0" "CGAMD_PCONV=1" "CGAMD_PCONV_WM2=1"; do
-      echo "== $v" | tee -a gpurun_out/${TAG}_convs.txt
-      env $v BENCH_NO_WGRAD=1 timeout 600 python scripts/bench_convs.py hc 2>&1 | tee -a gpurun_out/${TAG}_convs.txt | tail -16
-    done ;;
-  pconv_ab) TAG=${1:-pconv_ab}   # per-shape timings under each setting of the persistent kernel's switches
-    shift; for v in "$@"; do
-      echo "== $v" | tee -a gpurun_out/${TAG}.txt
-      env $v BENCH_NO_WGRAD=1 timeout 600 python scripts/bench_convs.py hc 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}.txt | tail -13
-    done ;;
-  pconv_timeline) TAG=${1:-pconv_timeline}; shift   # s_memtime phases (timing build), shapes N,H,W,Ci,Co,relu
-    for sh in "$@"; do
-      CGAMD_LIB_PATH=$R/compare_gan_amd/lib/libcgamd_timing.so timeout 300 python scripts/pconv_timeline.py $sh 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}.txt
     done ;;
   sq) TAG=$1; SHAPE=$2; KINDS=${3:-fwd}; shift 3   # SQ counter passes over one conv shape; extra args: VAR=V settings
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sq_$TAG && i=0 &&

@@ -97,9 +97,8 @@ CONV_CASES = [
     # with two channel blocks, 16x16 tiles
     ("hc_rgb_out_32", 26, 32, 32, 128, 3, 3, 1, 1),
     ("hc_rgb_out_16", 100, 16, 16, 64, 3, 3, 1, 1),
-    # persistent deep-pipelined kernel (cg_conv_pers.hip; selected for these small grids by the
-    # "pconv_*" variants below): several 16x32 tiles per image, three channel blocks, three
-    # out-channel tiles with a ragged last one
+    # several 16x32 tiles per image, three channel blocks, three out-channel tiles with a ragged
+    # last one
     ("pc_64x64_c192", 1, 64, 64, 192, 128, 3, 1, 1),
     ("pc_32x64_co320", 3, 32, 64, 64, 320, 3, 1, 1),
     # 64 -> 64 channels with register-resident weights (hconv_rw_kernel; "hconv_all" variant)
@@ -232,14 +231,9 @@ def test_gconv_full_size_shapes(K, dev, case):
     y = K.gconv(geom, xb, bt_f, bias=bias)
     _close_on_device(y, ref, name + " fwd bf16", 2.0 * 2.0 ** -8, 2.0 ** -8)
     del ref, y
-    import os
-    off_by_default = os.environ.get("CGAMD_PCONV", "0") != "0" or os.environ.get("CGAMD_QCONV", "0") != "0"
-    if Co >= 8 and not off_by_default:
+    if Co >= 8:
         # the form a residual block's second convolution / a data gradient takes: ReLU on the input,
-        # gate tensor and residual in the epilogue (resnet_ops.py:165-181).  (Not under the child runs
-        # of test_persistent_conv_at_the_benchmark_shapes: the off-by-default kernels' gated forms are
-        # covered at the variant test's sizes only -- this check was added after the round's last GPU
-        # visit and has only been run with the default dispatch.)
+        # gate tensor and residual in the epilogue (resnet_ops.py:165-181)
         go = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
         res = torch.randn((N, H, W, Co), generator=g, device=dev, dtype=torch.float32).to(BF16)
         ref = _ref_conv3x3_dev64(torch.relu(x64), w64) * (go > 0).double() + res.double()
@@ -1255,20 +1249,6 @@ CONV_VARIANT_ENVS = [
     # small-map kernels (cg_conv_small.hip) wherever their geometry fits / nowhere
     ("small_all", {"CGAMD_SCONV": "2", "CGAMD_SWGRAD": "2"}),
     ("no_small", {"CGAMD_SCONV": "0", "CGAMD_SWGRAD": "0"}),
-    # persistent kernel (off by default, CGAMD_PCONV=1) wherever its 16x32 tiles fit: one item per
-    # workgroup; three workgroups that walk all the items (window / weight prefetch across items,
-    # epilogue between them); the 2 x 4 wave layout without the fragment read-ahead
-    ("pconv_all", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
-                   "CGAMD_HCONV_MIN": "1", "CGAMD_HCONV_RW": "0"}),
-    ("pconv_walk", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
-                    "CGAMD_PCONV_GRID": "3", "CGAMD_HCONV_MIN": "1", "CGAMD_HCONV_RW": "0"}),
-    ("pconv_wm2", {"CGAMD_PCONV": "1", "CGAMD_PCONV_MIN": "1", "CGAMD_PCONV_GATED": "1",
-                   "CGAMD_PCONV_GRID": "5", "CGAMD_PCONV_WM2": "1", "CGAMD_PCONV_PIPE": "0",
-                   "CGAMD_HCONV_MIN": "1"}),
-    # the same K loop as two 4-wave workgroups per CU on 8x32 tiles (qconv_kernel)
-    ("qconv_all", {"CGAMD_QCONV": "1", "CGAMD_QCONV_MIN": "1", "CGAMD_HCONV_MIN": "1",
-                   "CGAMD_HCONV_RW": "0"}),
-    # default policy, kernel on: the full-size shapes go through it in their own test below
 ]
 
 
@@ -1288,25 +1268,6 @@ def test_conv_kernel_variants(dev, variant):
                         "test_gconv_fused_statistics_groups"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
-
-
-@pytest.mark.gpu
-def test_persistent_conv_at_the_benchmark_shapes(dev):
-    """cg_conv_pers.hip under its own grid policies (CGAMD_PCONV=1: 256 persistent workgroups that
-    walk 1-4 items each; CGAMD_QCONV=1: two 4-wave workgroups per CU) on the geometries of the
-    benchmark: the full-size forward / data-gradient / fused batch-norm / pooled cases of this file in
-    a child process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"CGAMD_PCONV": "1", "CGAMD_PCONV_GATED": "1"}, {"CGAMD_QCONV": "1"}):
-        env = dict(os.environ)
-        env.update(extra)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
-                            "-x", "-k", "full_size"], cwd=root, env=env, capture_output=True, text=True,
-                           timeout=900)
-        assert r.returncode == 0, "%s:\n%s\n%s" % (extra, r.stdout[-3000:], r.stderr[-1000:])
 
 
 @pytest.mark.gpu
