@@ -59,8 +59,19 @@ void cg_fast_wgrad_launch(const cgConvGeom* g, const void* in, const void* gate_
 
 // out_a[i] (+)= sum_z part_a[z][i] over n4_a float4 items (and the same for the optional b pair:
 // bias-gradient partials), 8 split lanes per output; splits >= 1
-// scope in which the split reductions run at once even under cg_reduce_defer_begin() (call sites
-// that reuse the workspace the partials sit in before the caller could flush)
+// Deferred reductions (cgDeferCtx, include/cgamd.h).  The context is CALLER-owned and arrives as an
+// argument of cg_gwgrad_deferred / cg_gwgrad_pooled_deferred; ReduceDeferScope makes it visible to
+// the launchers below the entry point for the duration of THAT call on THAT thread (a thread-local
+// pointer restored on exit: nothing outlives the call, the library keeps no process-wide state).
+class ReduceDeferScope {
+ public:
+  explicit ReduceDeferScope(cgDeferCtx* ctx);
+  ~ReduceDeferScope();
+ private:
+  cgDeferCtx* old_;
+};
+// scope in which the split reductions run at once even inside a ReduceDeferScope (call sites that
+// reuse the workspace the partials sit in before the caller could flush)
 class ReduceDeferSuspend {
  public:
   explicit ReduceDeferSuspend(bool on);

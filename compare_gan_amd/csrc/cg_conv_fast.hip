@@ -25,6 +25,7 @@
 #include "cg_conv_fast.h"
 
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include <stdlib.h>
@@ -1886,13 +1887,15 @@ __global__ __launch_bounds__(256) void split_reduce4x8_kernel(
     *o = t;
   }
 }
-// ---- deferred reductions (cg_reduce_defer_begin / _flush, include/cgamd.h) ----------------------
+// ---- deferred reductions (cgDeferCtx, include/cgamd.h) -------------------------------------------
 // A backward pass launches one small fixed-order reduction behind every weight-gradient kernel that
-// splits its pixels (60 launches of 4-6 us per ResNet-CIFAR step).  While deferral is on, those
-// reductions are only RECORDED -- same partial layout, same summation order per output -- and
-// cg_reduce_defer_flush() runs all of them in one launch per kernel form.  The state is process-wide
-// and mutex-protected: autograd runs the backward pass on its own thread.
-struct ReduceJob {
+// splits its pixels (60 launches of 4-6 us per ResNet-CIFAR step).  Through cg_gwgrad_deferred /
+// cg_gwgrad_pooled_deferred those reductions are only RECORDED in the caller's context -- same
+// partial layout, same summation order per output -- and cg_defer_flush() runs all of them in one
+// launch per kernel form.  The context belongs to the caller (one per stream / replica); the only
+// library-side state is the thread-local pointer a ReduceDeferScope holds during one call.
+}  // namespace
+struct cgReduceJob {
   const float* part;
   float* out;
   int64_t n;        // outputs: float4 units (kinds 0, 1) or floats (kind 2)
@@ -1900,15 +1903,20 @@ struct ReduceJob {
   int splits, accumulate;
   int kind;         // 0: split_reduce4x8 (8 split lanes), 1: split_reduce4 (serial), 2: strided
 };
-static std::mutex g_defer_mu;
-static bool g_defer_on = false;
-static int g_defer_suspend = 0;
-static std::vector<ReduceJob> g_defer_jobs;
+struct cgDeferCtx {
+  std::mutex mu;    // (a context is meant for one thread at a time; the lock makes misuse benign)
+  std::vector<cgReduceJob> jobs;
+};
+namespace {
+typedef cgReduceJob ReduceJob;
+thread_local cgDeferCtx* t_defer = nullptr;
+thread_local int t_defer_suspend = 0;
 
 static bool defer_reduce(const ReduceJob& j) {
-  std::lock_guard<std::mutex> lk(g_defer_mu);
-  if (!g_defer_on || g_defer_suspend > 0) return false;
-  g_defer_jobs.push_back(j);
+  cgDeferCtx* c = t_defer;
+  if (!c || t_defer_suspend > 0) return false;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->jobs.push_back(j);
   return true;
 }
 
@@ -2009,13 +2017,9 @@ __global__ __launch_bounds__(32 * SR_ZL) void split_reduce_strided_multi_kernel(
 static void launch_split_reduce4_pair(const float* part_a, int64_t n4_a, float* out_a,
                                       const float* part_b, int64_t n4_b, float* out_b, int splits,
                                       int accumulate, hipStream_t st) {
-  {
-    std::unique_lock<std::mutex> lk(g_defer_mu);
-    if (g_defer_on && g_defer_suspend == 0) {
-      g_defer_jobs.push_back({part_a, out_a, n4_a, 0, splits, accumulate, 0});
-      if (out_b) g_defer_jobs.push_back({part_b, out_b, n4_b, 0, splits, accumulate, 0});
-      return;
-    }
+  if (defer_reduce({part_a, out_a, n4_a, 0, splits, accumulate, 0})) {
+    if (out_b) defer_reduce({part_b, out_b, n4_b, 0, splits, accumulate, 0});
+    return;
   }
   const int ba = cdiv(n4_a, 32), bb = out_b ? cdiv(n4_b, 32) : 0;
   split_reduce4x8_kernel<<<ba + bb, 256, 0, st>>>(part_a, n4_a, out_a, ba, part_b, n4_b, out_b,
@@ -2079,41 +2083,36 @@ bool phase_ok(const cgConvGeom* g) {
 
 }  // namespace
 
+ReduceDeferScope::ReduceDeferScope(cgDeferCtx* ctx) : old_(t_defer) { t_defer = ctx; }
+ReduceDeferScope::~ReduceDeferScope() { t_defer = old_; }
 ReduceDeferSuspend::ReduceDeferSuspend(bool on) : on_(on) {
-  if (on_) {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    ++g_defer_suspend;
-  }
+  if (on_) ++t_defer_suspend;
 }
 ReduceDeferSuspend::~ReduceDeferSuspend() {
-  if (on_) {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    --g_defer_suspend;
-  }
+  if (on_) --t_defer_suspend;
 }
 
-extern "C" int cg_reduce_defer_begin(void) {
-  std::lock_guard<std::mutex> lk(g_defer_mu);
-  g_defer_on = true;
+extern "C" cgDeferCtx* cg_defer_create(void) { return new (std::nothrow) cgDeferCtx(); }
+extern "C" void cg_defer_destroy(cgDeferCtx* ctx) { delete ctx; }
+extern "C" int cg_defer_pending(cgDeferCtx* ctx) {
+  if (!ctx) return 0;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return (int)ctx->jobs.size();
+}
+extern "C" int cg_defer_abort(cgDeferCtx* ctx) {
+  if (!ctx) CG_FAIL(CG_ERR_BAD_ARG, "cg_defer_abort: null context");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->jobs.clear();
   return CG_OK;
 }
-extern "C" int cg_reduce_defer_pending(void) {
-  std::lock_guard<std::mutex> lk(g_defer_mu);
-  return (int)g_defer_jobs.size();
-}
-extern "C" int cg_reduce_defer_abort(void) {
-  std::lock_guard<std::mutex> lk(g_defer_mu);
-  g_defer_on = false;
-  g_defer_jobs.clear();
-  return CG_OK;
-}
-extern "C" int cg_reduce_defer_flush(cgStream stream) {
+extern "C" int cg_defer_flush(cgDeferCtx* ctx, cgStream stream) {
+  if (!ctx) CG_FAIL(CG_ERR_BAD_ARG, "cg_defer_flush: null context");
   std::vector<ReduceJob> jobs;
   {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    g_defer_on = false;
-    jobs.swap(g_defer_jobs);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    jobs.swap(ctx->jobs);
   }
+  if (jobs.empty()) return CG_OK;   // (no launch, no device needed)
   hipStream_t st = (hipStream_t)stream;
   for (int form = 0; form < 2; ++form) {   // 0: float4 kinds (0, 1), 1: strided
     ReduceChunk c;
@@ -2139,7 +2138,7 @@ extern "C" int cg_reduce_defer_flush(cgStream stream) {
     }
     launch();
   }
-  CG_CHECK_LAUNCH("cg_reduce_defer_flush");
+  CG_CHECK_LAUNCH("cg_defer_flush");
   return CG_OK;
 }
 

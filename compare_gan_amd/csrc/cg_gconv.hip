@@ -1167,6 +1167,23 @@ extern "C" int cg_gwgrad(const cgConvGeom* g, const void* in, const void* gate_i
 // Several weight gradients in one call (the deferred weight gradients of a backward pass,
 // compare_gan_amd/hip/functional.py): the small-map ones -- which cannot fill the chip one at a
 // time -- share launches of up to CG_SWGRAD_MAX_JOBS layers; the others run one by one.
+extern "C" int cg_gwgrad_deferred(const cgConvGeom* g, const void* in, const void* gate_in,
+                                  float slope_in, const void* dy, const void* gate_dy,
+                                  float slope_dy, float* dw, int accumulate, float* dbias, void* ws,
+                                  size_t ws_bytes, cgStream stream, cgDeferCtx* defer) {
+  ReduceDeferScope scope(defer);   // the launchers below record into the caller's context
+  return cg_gwgrad(g, in, gate_in, slope_in, dy, gate_dy, slope_dy, dw, accumulate, dbias, ws,
+                   ws_bytes, stream);
+}
+extern "C" int cg_gwgrad_pooled_deferred(const cgConvGeom* g, const void* in, const void* gate_in,
+                                         float slope_in, const void* dy_pooled, float* dw,
+                                         int accumulate, float* dbias, void* ws, size_t ws_bytes,
+                                         cgStream stream, cgDeferCtx* defer) {
+  ReduceDeferScope scope(defer);
+  return cg_gwgrad_pooled(g, in, gate_in, slope_in, dy_pooled, dw, accumulate, dbias, ws, ws_bytes,
+                          stream);
+}
+
 extern "C" int cg_gwgrad_groupable(const cgConvGeom* g) {
   if (!g || check_geom(g, "cg_gwgrad_groupable")) return 0;
   return cg_swgrad_supported(g, nullptr, nullptr, 0.f, nullptr, true) ? 1 : 0;

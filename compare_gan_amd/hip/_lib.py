@@ -82,19 +82,22 @@ SIGNATURES = {
     "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
     "cg_weight_prep_elems": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
-    "cg_reduce_defer_begin": (c_int, []),
-    "cg_reduce_defer_flush": (c_int, [vp]),
-    "cg_reduce_defer_abort": (c_int, []),
-    "cg_reduce_defer_pending": (c_int, []),
+    "cg_defer_create": (vp, []),
+    "cg_defer_destroy": (None, [vp]),
+    "cg_defer_pending": (c_int, [vp]),
+    "cg_defer_flush": (c_int, [vp, vp]),
+    "cg_defer_abort": (c_int, [vp]),
     "cg_gconv_fused_rows": (c_int, [GP]),
     "cg_gconv_fused_prologue_supported": (c_int, [GP]),
     "cg_gconv_fused_phases": (c_int, [GP]),
     "cg_gconv_fused": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp, vp]),
     "cg_gconv_pool_supported": (c_int, [GP]),
     "cg_gwgrad_pooled": (c_int, [GP, vp, vp, c_f32, vp, vp, c_int, vp, vp, c_sz, vp]),
+    "cg_gwgrad_pooled_deferred": (c_int, [GP, vp, vp, c_f32, vp, vp, c_int, vp, vp, c_sz, vp, vp]),
     "cg_bn_finalize": (c_int, [vp, c_int, c_int, c_i64, vp, vp, vp, vp, c_f32, vp]),
     "cg_gwgrad_workspace_bytes": (c_sz, [GP]),
     "cg_gwgrad": (c_int, [GP, vp, vp, c_f32, vp, vp, c_f32, vp, c_int, vp, vp, c_sz, vp]),
+    "cg_gwgrad_deferred": (c_int, [GP, vp, vp, c_f32, vp, vp, c_f32, vp, c_int, vp, vp, c_sz, vp, vp]),
     "cg_gwgrad_multi": (c_int, [ctypes.POINTER(WgradItem), c_int, vp, c_sz, vp]),
     "cg_gwgrad_groupable": (c_int, [GP]),
     "cg_spectral_norm_workspace_bytes": (c_sz, [c_int, c_int]),

@@ -111,9 +111,35 @@ def _wgrad_side_stream():
 # generator graphs without penalties only.
 # The weight gradients that do run at once inside the context (the large maps: one launch fills the
 # chip) still leave a small fixed-order reduction of their per-split partials behind; those are
-# recorded by the library (K.reduce_defer_begin) and run in ONE launch at the same flush points.
-_DEFER = {"on": False, "jobs": [], "wptrs": set()}
+# recorded in a K.DeferCtx -- a caller-owned cgDeferCtx, one per device, owned HERE and handed to
+# cg_gwgrad_deferred / cg_gwgrad_pooled_deferred with every call (the library keeps no deferral
+# state of its own) -- and run in ONE launch at the same flush points.
+_DEFER = {"on": False, "reduce": False, "jobs": [], "wptrs": set(), "ctx": {}}
 _DEFER_REDUCE = os.environ.get("CGAMD_DEFER_REDUCE", "1") != "0"   # A/B switch (read once)
+
+
+def _reduce_ctx(t):
+  """The DeferCtx that records the split reductions of a weight gradient on t's device, or None
+  when they run at once."""
+  if not (_DEFER["on"] and _DEFER["reduce"]) or not t.is_cuda:
+    return None
+  idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+  ctx = _DEFER["ctx"].get(idx)
+  if ctx is None:
+    ctx = _DEFER["ctx"][idx] = K.DeferCtx()
+  return ctx
+
+
+def _flush_reductions():
+  for idx, ctx in list(_DEFER["ctx"].items()):
+    if ctx.keep:
+      with torch.cuda.device(idx):
+        ctx.flush()
+
+
+def _abort_reductions():
+  for ctx in _DEFER["ctx"].values():
+    ctx.abort()
 
 
 class deferred_wgrads(object):
@@ -121,24 +147,23 @@ class deferred_wgrads(object):
     self._enabled = bool(enabled)
 
   def __enter__(self):
-    self._old = _DEFER["on"]
+    self._old = (_DEFER["on"], _DEFER["reduce"])
+    if self._old[0] and not self._enabled:
+      flush_wgrads()    # an inner scope that computes at once must not meet unwritten gradients
     _DEFER["on"] = self._enabled
     # (not together with the side-stream weight gradients: the recorded reductions are launched on
     # the stream that is current at the flush, the partials would be written on the side stream)
-    if self._enabled and _DEFER_REDUCE and not _WGRAD["enabled"]:
-      K.reduce_defer_begin()
+    _DEFER["reduce"] = self._enabled and _DEFER_REDUCE and not _WGRAD["enabled"]
     return self
 
   def __exit__(self, etype, *exc):
-    _DEFER["on"] = self._old
     if etype is None:
       flush_wgrads()
-      if self._old and _DEFER_REDUCE and not _WGRAD["enabled"]:
-        K.reduce_defer_begin()    # an enclosing context keeps recording
     else:
       del _DEFER["jobs"][:]
       _DEFER["wptrs"].clear()
-      K.reduce_defer_abort()
+      _abort_reductions()
+    _DEFER["on"], _DEFER["reduce"] = self._old
 
 
 def flush_wgrads():
@@ -148,10 +173,7 @@ def flush_wgrads():
     jobs, _DEFER["jobs"] = _DEFER["jobs"], []
     K.gwgrad_multi(jobs)
   _DEFER["wptrs"].clear()
-  if K.reduce_defer_active():
-    K.reduce_defer_flush()
-    if _DEFER["on"] and _DEFER_REDUCE and not _WGRAD["enabled"]:
-      K.reduce_defer_begin()
+  _flush_reductions()
 
 
 def join_wgrad_stream():
@@ -282,7 +304,7 @@ def _note_weight_contribution(w):
   (its split reduction is recorded, not run): a SECOND contribution to the same weight would be
   added by autograd to an unwritten tensor, so everything recorded is written first.
   The caller flushes again behind the second computation when this returns True."""
-  if _DEFER["on"] and K.reduce_defer_active():
+  if _DEFER["on"] and _DEFER["reduce"]:
     if w.data_ptr() in _DEFER["wptrs"]:
       flush_wgrads()
       return True
@@ -303,11 +325,11 @@ def _run_wgrad(spec, x, dy16, gate_in, gate_out, want_b):
   go = gate_out if spec.slope_out is not None else None
   if not spec.transpose:
     dw, db = K.gwgrad(g, x, dy16, gate_in=gi, slope_in=spec.slope_in or 0.0, gate_dy=go,
-                      slope_dy=spec.slope_out or 0.0, want_dbias=want_b)
+                      slope_dy=spec.slope_out or 0.0, want_dbias=want_b, defer=_reduce_ctx(x))
     return dw, db
   # y = F^T(x): dw = Wg_F(in = D(go) dy, "dy" = D(gi) x); dbias = colsum over y's pixels
   dw, _ = K.gwgrad(g, dy16, x, gate_in=go, slope_in=spec.slope_out or 0.0, gate_dy=gi,
-                   slope_dy=spec.slope_in or 0.0)
+                   slope_dy=spec.slope_in or 0.0, defer=_reduce_ctx(x))
   db = None
   if want_b:
     db = K.colsum(_gated(dy16, go, spec.slope_out).reshape(-1, dy16.shape[-1]))
@@ -407,7 +429,7 @@ class ConvPoolFn(torch.autograd.Function):
                      out_f32=ctx.dx_f32)
     if need_w or want_b:
       dup = _note_weight_contribution(w)
-      dw, db = K.gwgrad_pooled(g, x, dy16, gate_in=gi, want_dbias=want_b)
+      dw, db = K.gwgrad_pooled(g, x, dy16, gate_in=gi, want_dbias=want_b, defer=_reduce_ctx(x))
       if dup or not ctx.w_late:
         flush_wgrads()
       if not need_w:

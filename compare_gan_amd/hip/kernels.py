@@ -39,42 +39,45 @@ def _req(t, dtype, name, allow_none=False):
         raise ValueError("%s must be contiguous" % name)
 
 
-# workspaces of weight-gradient calls whose reductions are only recorded (reduce_defer_begin):
-# kept until reduce_defer_flush() has launched the reductions that read them
-_REDUCE_DEFER = {"on": False, "keep": []}
-
-
 def _ws(nbytes, like):
-    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
-    if _REDUCE_DEFER["on"]:
-        _REDUCE_DEFER["keep"].append(ws)
-    return ws
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
 
 
-def reduce_defer_begin():
-    """cg_reduce_defer_begin: the split reductions behind gwgrad / gwgrad_pooled are recorded, not
-    launched; their outputs are valid after reduce_defer_flush() (on the stream current there)."""
-    check(lib().cg_reduce_defer_begin(), "cg_reduce_defer_begin")
-    _REDUCE_DEFER["on"] = True
+class DeferCtx(object):
+    """A caller-owned cgDeferCtx (include/cgamd.h, "Deferred reductions") plus the workspaces whose
+    split partials its recorded reductions will read.  gwgrad / gwgrad_pooled called with
+    `defer=ctx` launch the partial-sum kernels and record the reduction; their outputs are valid
+    after ctx.flush() (on the stream current there).  One context per device / stream / backward
+    pass; the library itself holds no deferral state."""
 
+    def __init__(self):
+        self._lib = lib()
+        self.handle = self._lib.cg_defer_create()
+        if not self.handle:
+            raise MemoryError("cg_defer_create failed")
+        self.keep = []
 
-def reduce_defer_flush():
-    """Runs every recorded reduction in one launch per kernel form; recording is off afterwards."""
-    if not _REDUCE_DEFER["on"]:
-        return
-    _REDUCE_DEFER["on"] = False
-    check(lib().cg_reduce_defer_flush(_stream()), "cg_reduce_defer_flush")
-    del _REDUCE_DEFER["keep"][:]   # (stream-ordered: a later allocation reuses them after the launch)
+    def pending(self):
+        return int(self._lib.cg_defer_pending(self.handle))
 
+    def flush(self):
+        """Runs every recorded reduction in one launch per kernel form; the context is empty (and
+        reusable) afterwards."""
+        if self.keep or self.pending():
+            check(self._lib.cg_defer_flush(self.handle, _stream()), "cg_defer_flush")
+        del self.keep[:]   # (stream-ordered: a later allocation reuses them after the launch)
 
-def reduce_defer_active():
-    return _REDUCE_DEFER["on"]
+    def abort(self):
+        del self.keep[:]
+        self._lib.cg_defer_abort(self.handle)
 
-
-def reduce_defer_abort():
-    _REDUCE_DEFER["on"] = False
-    del _REDUCE_DEFER["keep"][:]
-    lib().cg_reduce_defer_abort()
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.cg_defer_destroy(self.handle)
+                self.handle = None
+        except Exception:  # pylint: disable=broad-except
+            pass
 
 
 # ------------------------------------------------------------------------------------------------
@@ -260,9 +263,10 @@ def gconv_fused(geom, x, bt, bias=None, residual=None, out_f32=False, bn=None, w
     return out, stats
 
 
-def gwgrad_pooled(geom, x, dy_pooled, gate_in=None, want_dbias=False):
+def gwgrad_pooled(geom, x, dy_pooled, gate_in=None, want_dbias=False, defer=None):
     """dw (+ dbias) of a convolution whose output was 2x2 average-pooled; dy_pooled is the
-    gradient w.r.t. the pooled output [N, Ho/2, Wo/2, Co]."""
+    gradient w.r.t. the pooled output [N, Ho/2, Wo/2, Co].  defer: a DeferCtx that records the
+    split reduction (outputs valid after its flush)."""
     _req(x, BF16, "x")
     _req(dy_pooled, BF16, "dy_pooled")
     if gate_in is not None and gate_in.data_ptr() != x.data_ptr():
@@ -272,6 +276,13 @@ def gwgrad_pooled(geom, x, dy_pooled, gate_in=None, want_dbias=False):
     dw = torch.empty((geom.kh, geom.kw, geom.Ci, geom.Co), dtype=F32, device=x.device)
     dbias = torch.empty((geom.Co,), dtype=F32, device=x.device) if want_dbias else None
     ws = _ws(lib().cg_gwgrad_workspace_bytes(ctypes.byref(geom)), x)
+    if defer is not None:
+        defer.keep.append(ws)
+        check(lib().cg_gwgrad_pooled_deferred(ctypes.byref(geom), _p(x), _p(gate_in), 0.0,
+                                              _p(dy_pooled), _p(dw), 0, _p(dbias), _p(ws),
+                                              ws.numel(), _stream(), defer.handle),
+              "cg_gwgrad_pooled_deferred")
+        return dw, dbias
     check(lib().cg_gwgrad_pooled(ctypes.byref(geom), _p(x), _p(gate_in), 0.0, _p(dy_pooled),
                                  _p(dw), 0, _p(dbias), _p(ws), ws.numel(), _stream()),
           "cg_gwgrad_pooled")
@@ -302,8 +313,9 @@ def bn_finalize(partials, count, moving_mean=None, moving_var=None, decay=0.0, g
 
 
 def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, want_dbias=False,
-           out=None, accumulate=False):
-    """dw fp32 [kh,kw,Ci,Co] (+ dbias [Co]) of the gather convolution `geom`."""
+           out=None, accumulate=False, defer=None):
+    """dw fp32 [kh,kw,Ci,Co] (+ dbias [Co]) of the gather convolution `geom`.  defer: a DeferCtx
+    that records the split reduction (outputs valid after its flush)."""
     _req(x, BF16, "x")
     _req(dy, BF16, "dy")
     _req(gate_in, BF16, "gate_in", True)
@@ -325,6 +337,13 @@ def gwgrad(geom, x, dy, gate_in=None, slope_in=0.0, gate_dy=None, slope_dy=0.0, 
     dbias = torch.empty((geom.Co,), dtype=F32, device=x.device) if want_dbias else None
     nbytes = lib().cg_gwgrad_workspace_bytes(ctypes.byref(geom))
     ws = _ws(nbytes, x)
+    if defer is not None:
+        defer.keep.append(ws)
+        check(lib().cg_gwgrad_deferred(ctypes.byref(geom), _p(x), _p(gate_in), float(slope_in),
+                                       _p(dy), _p(gate_dy), float(slope_dy), _p(dw),
+                                       int(accumulate), _p(dbias), _p(ws), ws.numel(), _stream(),
+                                       defer.handle), "cg_gwgrad_deferred")
+        return dw, dbias
     check(lib().cg_gwgrad(ctypes.byref(geom), _p(x), _p(gate_in), float(slope_in), _p(dy),
                           _p(gate_dy), float(slope_dy), _p(dw), int(accumulate), _p(dbias),
                           _p(ws), ws.numel(), _stream()), "cg_gwgrad")

@@ -170,22 +170,32 @@ int cg_gconv_pool_supported(const cgConvGeom* geom);
 int cg_gwgrad_pooled(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
                      const void* dy_pooled, float* dw, int accumulate, float* dbias, void* ws,
                      size_t ws_bytes, cgStream stream);
+/* The same with the split reductions recorded in `defer` (see "Deferred reductions" below; NULL =
+ * cg_gwgrad_pooled). */
+struct cgDeferCtx;
+int cg_gwgrad_pooled_deferred(const cgConvGeom* geom, const void* in, const void* gate_in,
+                              float slope_in, const void* dy_pooled, float* dw, int accumulate,
+                              float* dbias, void* ws, size_t ws_bytes, cgStream stream,
+                              struct cgDeferCtx* defer);
 
 /* Deferred reductions.  Weight-gradient kernels that split their pixels leave per-split partials in
  * the workspace and a small fixed-order reduction behind them (60 launches per ResNet-CIFAR train
- * step).  After cg_reduce_defer_begin(), cg_gwgrad / cg_gwgrad_pooled still launch the partial-sum
- * kernels but only RECORD those reductions; cg_reduce_defer_flush(stream) runs every recorded one in
- * one launch per kernel form (same summation order per output as the separate launches: results are
- * bit-identical) and switches recording off.  Until the flush the caller must keep every workspace
- * and output of the recorded calls alive, unread, and on `stream`.  The switch is process-wide
- * (autograd runs backward passes on its own thread).  cg_reduce_defer_abort() drops the recorded
- * reductions (error paths); cg_reduce_defer_pending() returns how many are recorded.
+ * step).  cg_gwgrad_deferred / cg_gwgrad_pooled_deferred (below) launch the partial-sum kernels but
+ * only RECORD those reductions in a CALLER-OWNED context; cg_defer_flush(ctx, stream) runs every
+ * recorded one in one launch per kernel form (same summation order per output as the separate
+ * launches: results are bit-identical) and leaves the context empty and reusable.  Until the flush
+ * the caller keeps every workspace and output of the recorded calls alive, unread, and on `stream`.
+ * The library holds no process-wide state: one context per stream / replica / backward pass, used
+ * by one thread at a time; contexts of different replicas never see each other's reductions.
+ * cg_defer_abort() drops the recorded reductions (error paths); cg_defer_pending() counts them.
  * tf.gradients hands the optimiser all kernel gradients at once (modular_gan.py:480-483,494-497):
  * nothing in the data-gradient chain reads them earlier. */
-int cg_reduce_defer_begin(void);
-int cg_reduce_defer_flush(cgStream stream);
-int cg_reduce_defer_abort(void);
-int cg_reduce_defer_pending(void);
+typedef struct cgDeferCtx cgDeferCtx;
+cgDeferCtx* cg_defer_create(void);              /* NULL when out of memory */
+void cg_defer_destroy(cgDeferCtx* ctx);         /* recorded reductions are dropped; NULL is fine */
+int cg_defer_pending(cgDeferCtx* ctx);
+int cg_defer_flush(cgDeferCtx* ctx, cgStream stream);
+int cg_defer_abort(cgDeferCtx* ctx);
 /* mean / var (and the moving averages, as cg_bn_stats) from `rows` rows of partial sums
  * [rows][2*C] over `count` values per channel. */
 int cg_bn_finalize(const float* partials, int rows, int C, int64_t count, float* mean, float* var,
@@ -209,6 +219,12 @@ size_t cg_gwgrad_workspace_bytes(const cgConvGeom* geom);
 int cg_gwgrad(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
               const void* dy, const void* gate_dy, float slope_dy, float* dw, int accumulate,
               float* dbias, void* ws, size_t ws_bytes, cgStream stream);
+/* The same with the split reductions recorded in `defer` (NULL = cg_gwgrad): dw / dbias are valid
+ * after cg_defer_flush(defer, stream); ws must stay alive until then. */
+int cg_gwgrad_deferred(const cgConvGeom* geom, const void* in, const void* gate_in, float slope_in,
+                       const void* dy, const void* gate_dy, float slope_dy, float* dw,
+                       int accumulate, float* dbias, void* ws, size_t ws_bytes, cgStream stream,
+                       cgDeferCtx* defer);
 /* Several weight gradients in one call: tf.gradients(loss, var_list) hands all kernel gradients
  * of a network to the optimiser at once (modular_gan.py:480-483,494-497), so they need not be
  * computed inside the data-gradient chain.  `items` is a HOST array (device pointers by value in

@@ -255,16 +255,23 @@ def test_library_argument_errors_without_gpu():
   assert rc == -2
 
 
-def test_deferred_reduction_switch_without_gpu():
-  """cg_reduce_defer_*: the recording switch is host state (no launch until a flush has something to
-  run): begin / pending / abort work without a device and leave the switch off."""
+def test_deferred_reduction_context_without_gpu():
+  """cgDeferCtx is caller-owned host state (no launch until a flush has something to run): create /
+  pending / abort / flush-of-nothing / destroy work without a device, contexts are independent
+  objects, and the NULL context is rejected where one is required."""
   from compare_gan_amd.hip import _lib
   lib = _lib.load()
-  assert lib.cg_reduce_defer_pending() == 0
-  assert lib.cg_reduce_defer_begin() == 0
-  assert lib.cg_reduce_defer_pending() == 0
-  assert lib.cg_reduce_defer_abort() == 0
-  assert lib.cg_reduce_defer_pending() == 0
+  a, b = lib.cg_defer_create(), lib.cg_defer_create()
+  assert a and b and a != b
+  assert lib.cg_defer_pending(a) == 0 and lib.cg_defer_pending(b) == 0
+  assert lib.cg_defer_abort(a) == 0
+  assert lib.cg_defer_flush(a, None) == 0           # nothing recorded: no launch
+  assert lib.cg_defer_flush(None, None) == -1 and b"cg_defer_flush" in lib.cg_last_error()
+  assert lib.cg_defer_abort(None) == -1
+  assert lib.cg_defer_pending(None) == 0
+  lib.cg_defer_destroy(a)
+  lib.cg_defer_destroy(b)
+  lib.cg_defer_destroy(None)
 
 
 def test_weight_gradient_consumers_are_classified():

@@ -414,13 +414,8 @@ def test_deferred_wgrads_with_a_torch_op_on_the_weight_path(K, dev):
         assert torch.equal(a, b)
 
 
-def test_deferred_reductions_are_bit_identical(K, dev):
-    """cg_reduce_defer_begin / _flush: the split reductions behind the weight-gradient kernels (halo:
-    float4 partials, 8 split lanes; RGB stem: strided partials; pooled-gradient forms; a layer with
-    the bias partials in the reused workspace, whose dw reduction must NOT be deferred), recorded and
-    run in one launch per form, give bit for bit the tensors of the separate launches -- and nothing
-    is written before the flush."""
-    g = _gen(23)
+def _deferred_reduction_ops(K, dev, seed=23):
+    g = _gen(seed)
     cases = [  # N, H, W, Ci, Co, relu, pooled
         (6, 32, 32, 128, 128, True, False), (4, 32, 32, 64, 64, False, True), (9, 32, 32, 3, 128, False, False),
         (5, 32, 32, 3, 64, False, True), (8, 16, 16, 128, 256, True, False), (3, 64, 64, 64, 64, True, False),
@@ -437,35 +432,80 @@ def test_deferred_reductions_are_bit_identical(K, dev):
         _, dyb = rand_bf16((N, geom.Ho // 2, geom.Wo // 2, Co) if pooled else (N, geom.Ho, geom.Wo, Co), g)
         ops.append((geom, xb.to(dev), dyb.to(dev), relu, pooled))
 
-    def run_all():
+    def run_all(defer=None, ops_=None):
         outs = []
-        for geom, x, dy, relu, pooled in ops:
+        for geom, x, dy, relu, pooled in (ops if ops_ is None else ops_):
             gi = x if relu else None
             if pooled:
-                outs.extend(K.gwgrad_pooled(geom, x, dy, gate_in=gi, want_dbias=True))
+                outs.extend(K.gwgrad_pooled(geom, x, dy, gate_in=gi, want_dbias=True, defer=defer))
             else:
-                outs.extend(K.gwgrad(geom, x, dy, gate_in=gi, slope_in=0.0, want_dbias=True))
+                outs.extend(K.gwgrad(geom, x, dy, gate_in=gi, slope_in=0.0, want_dbias=True, defer=defer))
         return outs
+    return cases, ops, run_all
 
+
+def test_deferred_reductions_are_bit_identical(K, dev):
+    """cgDeferCtx (cg_gwgrad_deferred / cg_gwgrad_pooled_deferred / cg_defer_flush): the split
+    reductions behind the weight-gradient kernels (halo: float4 partials, 8 split lanes; RGB stem:
+    strided partials; pooled-gradient forms; a layer with the bias partials in the reused workspace,
+    whose dw reduction must NOT be deferred), recorded in a caller-owned context and run in one launch
+    per form, give bit for bit the tensors of the separate launches."""
+    cases, ops, run_all = _deferred_reduction_ops(K, dev)
     ref = [t.clone() for t in run_all()]
-    K.reduce_defer_begin()
-    try:
-        outs = run_all()
-        pending = int(K.lib().cg_reduce_defer_pending())
-        K.reduce_defer_flush()
-    except Exception:
-        K.reduce_defer_abort()
-        raise
+    ctx = K.DeferCtx()
+    outs = run_all(ctx)
+    pending = ctx.pending()
+    ctx.flush()
     assert pending >= 8, pending          # (most of the layers above split their pixels)
-    assert int(K.lib().cg_reduce_defer_pending()) == 0 and not K.reduce_defer_active()
+    assert ctx.pending() == 0 and not ctx.keep
     for i, (a, b) in enumerate(zip(ref, outs)):
         assert torch.equal(a, b), "output %d of case %s" % (i % 2, cases[i // 2])
-    # an aborted recording leaves the switch off: the next call reduces at once
-    K.reduce_defer_begin()
-    K.reduce_defer_abort()
+    # an aborted recording leaves nothing behind: calls without a context reduce at once, and the
+    # context is reusable
+    run_all(ctx)
+    ctx.abort()
+    assert ctx.pending() == 0
     again = run_all()
     for a, b in zip(ref, again):
         assert torch.equal(a, b)
+    outs = run_all(ctx)
+    ctx.flush()
+    for a, b in zip(ref, outs):
+        assert torch.equal(a, b)
+
+
+def test_deferred_reductions_of_two_replicas_do_not_mix(K, dev):
+    """the C-ABI is re-entrant, no state besides what the caller owns.  Two replicas in
+    one process (two streams, two contexts, two sets of tensors) record their reductions
+    INTERLEAVED -- replica A's call, then B's, ... -- with a third party calling without a context in
+    between; each context flushes on its own stream and holds exactly its own reductions; all three
+    results are bit-identical to the immediate form.  (the process-wide switch
+    this replaces sent whatever was recorded to whichever stream flushed first.)"""
+    cases, ops_a, run_all = _deferred_reduction_ops(K, dev, seed=23)
+    _, ops_b, _ = _deferred_reduction_ops(K, dev, seed=29)
+    ref_a = [t.clone() for t in run_all(None, ops_a)]
+    ref_b = [t.clone() for t in run_all(None, ops_b)]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ca, cb = K.DeferCtx(), K.DeferCtx()
+    outs_a, outs_b, outs_c = [], [], []
+    for oa, ob in zip(ops_a, ops_b):
+        with torch.cuda.stream(sa):
+            outs_a.extend(run_all(ca, [oa]))
+        with torch.cuda.stream(sb):
+            outs_b.extend(run_all(cb, [ob]))
+        outs_c.extend(run_all(None, [oa]))        # no context: reduced at once, recorded nowhere
+    na, nb = ca.pending(), cb.pending()
+    assert na == nb and na >= 8
+    with torch.cuda.stream(sb):
+        cb.flush()
+    assert ca.pending() == na and cb.pending() == 0     # B's flush did not touch A's reductions
+    with torch.cuda.stream(sa):
+        ca.flush()
+    torch.cuda.synchronize()
+    for name, ref, outs in (("A", ref_a, outs_a), ("B", ref_b, outs_b), ("none", ref_a, outs_c)):
+        for i, (a, b) in enumerate(zip(ref, outs)):
+            assert torch.equal(a, b), "replica %s output %d of case %s" % (name, i % 2, cases[i // 2])
 
 
 FUSED_FULL_SIZE = [
