@@ -287,8 +287,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CGAMD_BENCH_DEVICE: every rank on ONE device (the dry run of the N > 1 entry point on a 1-GPU
+    # box, tests/test_data_parallel_gpu.py; two RCCL ranks cannot share a device, so that run also
+    # sets CGAMD_DIST_BACKEND=gloo and CGAMD_DP_GRAPH=0)
+    dev_index = int(os.environ.get("CGAMD_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_dp = os.environ.get("CGAMD_FORCE_DP", "") == "1"   # exercise the RCCL path on 1 GPU
     # one process per GPU: joins the RCCL group and switches batch norm to cross-replica
     # statistics (the reference's data-parallel semantics, arch_ops.py:258-263)

@@ -147,7 +147,19 @@ class _OptimizerState(object):
     """Call right before the backward pass whose gradients apply_gradients() will consume.  Data
     parallel with the overlap on: from now on each gradient reports in through a tensor hook, and a
     bucket whose gradients are all there is flattened and all-reduced on the communication stream
-    while the backward pass continues on the main stream.  Otherwise a no-op."""
+    while the backward pass continues on the main stream.  Otherwise a no-op.
+
+    Collective ordering across ranks (RCCL requires every rank to issue the collectives of one
+    communicator in the same order).  Two threads issue collectives: the main thread (cross-replica
+    batch norm in the forward passes, tpu_ops.SyncMoments) and autograd's device worker thread (the
+    batch norms' backward all-reduces and these bucket all-reduces).  They never issue concurrently:
+    the main thread sits inside torch.autograd.backward()/grad() for the whole backward pass, and the
+    worker issues nothing outside one.  Within a backward pass the engine runs ready nodes by
+    descending sequence number -- a pure function of the order in which the forward pass created them,
+    i.e. of the model code, identical on every rank -- so hooks fire, buckets fill (plan_buckets is a
+    function of the parameter sizes alone) and batch-norm backwards interleave in the same order
+    everywhere.  What would break it: rank-dependent control flow in a model (none in the
+    architectures here), or autograd's multi-device threading (one process drives one GPU)."""
     self._armed = None
     if not (tpu_ops.data_parallel() and tpu_ops.thread_state() is None and _DP_BUCKETS > 1):
       return
@@ -199,11 +211,8 @@ class _OptimizerState(object):
 
   def disarm(self):
     """Drops an armed state that apply_gradients() will not consume (the backward pass raised): the
-    gradient references go, and so does the in-flight mark of buckets that already left.
-    Collective ordering across ranks: the bucket all-reduces are issued from the autograd worker
-    thread and the cross-replica batch-norm collectives from the main thread; both orders are a
-    pure function of the (identical) graph on every rank, which is what keeps the ranks' sequences
-    of collectives aligned."""
+    gradient references go, and so does the in-flight mark of buckets that already left (the
+    ordering argument for the collectives is in arm())."""
     if self._armed is not None and self._armed["order"]:
       self.join()
     self._armed = None

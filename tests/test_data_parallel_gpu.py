@@ -55,6 +55,38 @@ def test_force_dp_one_rank_group_matches_single_replica(mode):
     assert p.returncode == 0 and "DP_FORCE_OK" in out, brief[-4000:]
 
 
+def test_bench_entry_point_with_two_ranks():
+    """`bench.py --gpus 2` exactly as the driver launches it for the scaling
+    curve (python -m torch.distributed.run --nproc-per-node 2 ...), dry-run on ONE GPU: both ranks on
+    cuda:0, host-side all-reduce (gloo; two RCCL ranks cannot share a device), eager launches.  What
+    this executes before an 8-GPU node ever does: RANK / LOCAL_RANK plumbing, per-rank data shards,
+    cross-replica batch norm + bucketed gradient all-reduce, the barrier-bracketed timed region with
+    MAX over ranks, the threaded communicator teardown, and rank 0 alone printing ONE JSON line whose
+    `value` counts the images of BOTH ranks."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CGAMD_FORCE_DP"):
+        env.pop(k, None)
+    env.update({"CGAMD_BENCH_DEVICE": "0", "CGAMD_DIST_BACKEND": "gloo", "CGAMD_DP_GRAPH": "0",
+                "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--preheat-s", "0", "--no-legs", "--no-fid",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    out, err = p.stdout.decode("utf-8", "replace"), p.stderr.decode("utf-8", "replace")
+    assert p.returncode == 0, (out[-2000:], err[-3000:])
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                      # rank 0 only, once
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["hip_graph"] is False
+    # whole-job throughput: both ranks' images over the slowest rank's time
+    assert abs(d["value"] - 2 * 64 * 6 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-3 * d["value"]
+    assert out.strip().splitlines()[-1] == lines[0]          # the JSON line is the LAST line
+
+
 def _batches(dataset, n, seed, steps):
     it = dataset.train_batches(n, seed=seed)
     return [next(it) for _ in range(steps)]
