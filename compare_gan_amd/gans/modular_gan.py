@@ -651,10 +651,22 @@ class ModularGAN(AbstractGAN):
       fs.append(f)
       ls.append(l)
     d_losses = []
+    # sub_step_hook (parity tests only, never under graph capture): called with ("d", i) before
+    # discriminator sub-step i and ("g", disc_iters) before the generator sub-step, every update
+    # enqueued so far joined -- tests take over the complete state there and compare each sub-step
+    # from identical states (tests/gan_util.py stepwise_parity: the free-running comparison of a
+    # whole step is chaotic, profiles/r05_gloss_spread.txt)
+    hook = getattr(self, "sub_step_hook", None)
     with ops.use_store(self.store):
       self._generate_for_disc(fs)
       for i in range(self._disc_iters):
+        if hook is not None:
+          self._join_updates()
+          hook("d", i)
         d_losses.append(self._disc_sub_step(fs[i], ls[i]))
+      if hook is not None:
+        self._join_updates()
+        hook("g", self._disc_iters)
       g_loss = self._train_generator(fs[-1], ls[-1])
     self._join_updates()
     return {"d_losses": d_losses, "g_loss": g_loss}

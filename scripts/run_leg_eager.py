@@ -10,6 +10,9 @@ LEGS = {
     "resnet128_dstep": ("resnet_lsun-bedroom128.gin", ("penalty.fn = @no_penalty",), 64, "dstep"),
     "resnet128_dstep_gp": ("resnet_lsun-bedroom128.gin", (), 64, "dstep"),
     "biggan128": ("biggan_imagenet128.gin", (), 64, "step"),
+    "biggan128_bs256": ("biggan_imagenet128.gin", (), 256, "step"),
+    "cifar": ("resnet_cifar10.gin", (), 64, "step"),
+    "sndcgan128": ("sndcgan_celebahq128.gin", (), 32, "step"),
 }
 key = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2

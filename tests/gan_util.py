@@ -135,3 +135,99 @@ def resync_oracle(gan, ora):
                 oopt.v[j].copy_(popt.v[idx[n]].detach().cpu().to(oopt.v[j].dtype))
     ora.g_opt.t = ora.global_step = int(gan.global_step.item())
     ora.d_opt.t = ora.global_step_disc = int(gan.global_step_disc.item())
+
+
+class stepwise_parity(object):
+    """One unrolled train_step() of the product against the oracle, sub-step by sub-step FROM
+    IDENTICAL STATES.
+
+    Why not the whole step against a free-running oracle: Adam's first updates are sign-like
+    (update = -lr * sign(g) whatever |g|), so the ~0.5 % of discriminator weights whose gradient is
+    rounding noise move by +-lr on either side after the FIRST sub-step, and the GAN dynamics
+    amplify that: over eight seeds the generator loss of the product and of the bf16-storage
+    oracle -- and of the bf16-storage and the exact oracle, two restatements of the reference
+    that differ in storage rounding alone -- end up 1e-4 ... 2e-1 (one seed: 2.3) apart
+    (profiles/r05_gloss_spread.txt), while every sub-step taken from identical states agrees to
+    3e-5 (D losses), 2.3e-4 (generator loss) and cosine >= 0.99 (updates)
+    (profiles/r05_gloss_stepwise.txt).
+
+    Usage: install as gan.sub_step_hook, call gan.train_step(images, labels), then finish(out).
+    Before every sub-step the oracle takes over the product's complete state (resync_oracle) and
+    runs the same sub-step (oracle/modular_gan.py train_step, taken apart); finish() compares:
+      d_losses / g_loss      relative tol_loss (default 2e-3; measured <= 3e-4)
+      every network's update of that sub-step  cosine >= cos_min (default 0.98; measured >= 0.9906)
+      and per element |update_p - update_o| <= 2.2 lr_t (a sign flip of a ~0 gradient)."""
+
+    def __init__(self, gan, ora, subs, lr_d, lr_g=None, tol_loss=2e-3, cos_min=0.98):
+        self.gan, self.ora, self.subs = gan, ora, subs
+        self.lr_d, self.lr_g = lr_d, lr_g if lr_g is not None else lr_d
+        self.tol_loss, self.cos_min = tol_loss, cos_min
+        self.d_o, self.g_o = [], None
+        self.pending = None      # (net, names, before, oracle_after) of the sub-step in flight
+        self.rows = []
+        self._joint = None
+
+    def _names(self, net):
+        return [n for n, _ in self.gan.store.trainable_variables(net)]
+
+    def _close(self):
+        if self.pending is None:
+            return
+        net, names, before, after_o, lr = self.pending
+        ups, uos = [], []
+        for n in names:
+            up = self.gan.store.vars[n].detach().cpu().double() - before[n]
+            uo = after_o[n] - before[n]
+            assert float((up - uo).abs().max()) <= 2.2 * lr * 1.6, (net, n, float((up - uo).abs().max()) / lr)
+            ups.append(up.reshape(-1))
+            uos.append(uo.reshape(-1))
+        c = cosine(torch.cat(ups), torch.cat(uos))
+        self.rows.append((net, c))
+        assert c >= self.cos_min, "update of the %s: cosine %.5f" % (net, c)
+        self.pending = None
+
+    def __call__(self, phase, index):
+        self._close()
+        gan, ora, s = self.gan, self.ora, self.subs[index]
+        resync_oracle(gan, ora)
+        ora._ensure_opts()   # pylint: disable=protected-access
+        sy = ora.one_hot(s["sampled_labels"]) if ora.conditional else None
+        if phase == "d":
+            names = self._names("discriminator")
+            before = {n: gan.store.vars[n].detach().cpu().double().clone() for n in names}
+            with torch.no_grad():
+                if ora.joint_gen_for_disc:
+                    if self._joint is None:
+                        z = torch.cat([t["z"] for t in self.subs[:ora.disc_iters]], dim=0)
+                        self._joint = torch.chunk(ora.G(z, None), ora.disc_iters, dim=0)
+                    generated = self._joint[index]
+                else:
+                    generated = ora.G(s["z"], sy)
+            d_loss, _, _ = ora.create_loss(s["images"], generated, s.get("labels"),
+                                           s.get("sampled_labels"), s.get("alpha"))
+            ora.d_opt.step(torch.autograd.grad(d_loss, ora.d_vars()))
+            ora.global_step_disc += 1
+            self.d_o.append(float(d_loss.detach()))
+            after = {n: ora.vs.vars[n].detach().double().clone() for n in names}
+            self.pending = ("discriminator", names, before, after, self.lr_d)
+        else:
+            names = self._names("generator")
+            before = {n: gan.store.vars[n].detach().cpu().double().clone() for n in names}
+            generated = ora.G(s["z"], sy)
+            _, g_loss, _ = ora.create_loss(s["images"], generated, s.get("labels"),
+                                           s.get("sampled_labels"), with_penalty=False)
+            ora.g_opt.step(torch.autograd.grad(g_loss, ora.g_vars()))
+            ora.global_step += 1
+            self.g_o = float(g_loss.detach())
+            after = {n: ora.vs.vars[n].detach().double().clone() for n in names}
+            self.pending = ("generator", names, before, after, self.lr_g)
+
+    def finish(self, out):
+        """out: what train_step() returned.  Returns (d_losses oracle, g_loss oracle)."""
+        self._close()
+        d_p = [float(x) for x in out["d_losses"]]
+        g_p = float(out["g_loss"])
+        for i, (a, b) in enumerate(zip(d_p, self.d_o)):
+            assert abs(a - b) <= self.tol_loss * max(1.0, abs(b)), ("d_loss", i, a, b)
+        assert abs(g_p - self.g_o) <= self.tol_loss * max(1.0, abs(self.g_o)), ("g_loss", g_p, self.g_o)
+        return self.d_o, self.g_o

@@ -208,7 +208,8 @@ def test_evaluate_gan_raises_on_nan(dev):
     from compare_gan_amd.metrics import fid_score
     gan, _, _ = U.build_product("resnet_cifar10.gin", 8, dev, seed=3)
     with torch.no_grad():
-        next(iter(gan.g_opt.params)).fill_(float("nan"))
+        for p in gan.g_opt.params:        # (a diverged generator: every weight, the last layer included)
+            p.fill_(float("nan"))
     with pytest.raises(eval_utils.NanFoundError):
         eval_gan_lib.evaluate_gan(gan, [fid_score.FIDScoreTask()], 1, num_test_examples=128)
 

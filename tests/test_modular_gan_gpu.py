@@ -199,59 +199,49 @@ def _forward_and_gradients(dev, config, bsz, emulate, bindings=(), oracle_overri
 
 @pytest.mark.parametrize("bsz", [8, 64])
 def test_train_steps_resnet_cifar(dev, bsz):
-    """Two full unrolled steps (5 D sub-steps + 1 G sub-step each) of resnet_cifar10.gin vs the
-    bf16-storage oracle, at a toy batch and at the batch bench.py measures (64: the dispatcher
-    picks the kernel variants of the benchmark there).  Both steps are held to the same tolerance:
-    after the first one the oracle takes over the product's complete state (U.resync_oracle), so
-    the second step -- non-zero Adam slots, advanced power-iteration vectors and moving averages --
-    is compared from identical states instead of through Adam's sign-like first update.  Step
-    counters follow the reference pin modular_gan_test.py:175-177."""
+    """Full unrolled steps (5 D sub-steps + 1 G sub-step each) of resnet_cifar10.gin through
+    train_step() vs the bf16-storage oracle, at a toy batch (two steps) and at the batch bench.py
+    measures (64: the dispatcher picks the kernel variants of the benchmark there).
+
+    Every sub-step is compared FROM IDENTICAL STATES (U.stepwise_parity, installed as the step's
+    sub_step_hook): losses within 2e-3, each network's update at cosine >= 0.98.  Round 4 compared
+    the whole step with a free-running oracle and had to widen the generator-loss band to 4e-2;
+    the round-5 sweeps show why that comparison cannot be tight -- it is chaotic (over eight seeds
+    product, bf16-storage oracle and exact oracle end up 1e-4 ... 2e-1 apart in the generator loss,
+    profiles/r05_gloss_spread.txt) -- while from identical states the sub-steps agree to 3e-4
+    (profiles/r05_gloss_stepwise.txt).  The free-running D losses of THIS seed are still reported
+    and held to the 2e-2 of round 1.  Step counters follow modular_gan_test.py:175-177."""
     config = "resnet_cifar10.gin"
     gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED)
-    vs = U.mirror_to_oracle(gan, emulate_bf16=True)
-    ora = U.build_oracle(config, vs)
+    ora = U.build_oracle(config, U.mirror_to_oracle(gan, emulate_bf16=True))
+    free = U.build_oracle(config, U.mirror_to_oracle(gan, emulate_bf16=True)) if bsz <= 8 else None
     nsub = options["disc_iters"] + 1
-    lr = 2e-4
     nsteps = 2 if bsz <= 8 else 1     # (the fp64 oracle needs ~20 s per step at batch 64)
     for step in range(nsteps):
-        before = {n: v.detach().clone() for n, v in gan.store.trainable_variables()}
         rng = np.random.RandomState(500 + step)
         images = rng.uniform(size=(nsub * bsz,) + dataset.image_shape).astype(np.float32)
         labels = np.ones((nsub * bsz,), dtype=np.int32)
-        out = gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
-        subs = []
-        for i in range(nsub):
-            subs.append({"images": torch.from_numpy(images[i * bsz:(i + 1) * bsz]).double(),
-                         "z": U.host_uniform((bsz, 128), "z/%d" % i, -1.0, 1.0, SEED, step).double()})
-        d_o, g_o = ora.train_step(subs)
+        subs = [{"images": torch.from_numpy(images[i * bsz:(i + 1) * bsz]).double(),
+                 "z": U.host_uniform((bsz, 128), "z/%d" % i, -1.0, 1.0, SEED, step).double()}
+                for i in range(nsub)]
+        check = U.stepwise_parity(gan, ora, subs, lr_d=2e-4)
+        gan.sub_step_hook = check
+        try:
+            out = gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+        finally:
+            gan.sub_step_hook = None
+        d_o, g_o = check.finish(out)
         d_p = [float(x) for x in out["d_losses"]]
-        print("step", step, "d", d_p, d_o, "g", float(out["g_loss"]), g_o)
-        for a, b in zip(d_p, d_o):
-            assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (step, a, b)
-        # the generator loss is taken AFTER the five sign-like Adam updates of D: weights whose gradient
-        # is rounding noise move by +-lr on either side in product and oracle, and D(G(z)) feels it.
-        # Measured on one box with two builds that differ only in the summation order of a few fp32
-        # reductions: step 0 -1.6 % with both, step 1 -0.3 % with one and -2.1 % with the other
-        # (-2.9 % with the batch-norm fusion off), while the D losses stay within 1.5e-3
-        assert abs(float(out["g_loss"]) - g_o) <= 4e-2 * max(1.0, abs(g_o)), step
-        # the step's weight UPDATE against the oracle's.  Adam's first updates are sign-like, so a
-        # weight whose gradient is ~0 (a bias in front of batch norm) moves by +-lr at random on
-        # either side: per element the two updates may differ by 2 lr per sub-step, and the
-        # direction is judged over each network as a whole (the exact and the bf16-storage oracle
-        # agree to cosine 0.93 / 0.945 there at batch 8 -- measured on the CPU)
-        for net in ("generator", "discriminator"):
-            ups, uos = [], []
-            for name, v in gan.store.trainable_variables(net):
-                up = v.detach().double().cpu() - before[name].double().cpu()
-                uo = vs.vars[name].detach().double() - before[name].double().cpu()
-                assert float((up - uo).abs().max()) <= 12 * lr, (step, name)
-                assert float(up.abs().max()) > 0.0, "%s did not move" % name
-                ups.append(up.reshape(-1))
-                uos.append(uo.reshape(-1))
-            c = U.cosine(torch.cat(ups), torch.cat(uos))
-            print("step", step, net, "update cosine", c)
-            assert c >= 0.90, (step, net, c)
-        U.resync_oracle(gan, ora)
+        print("step", step, "d", d_p, d_o, "g", float(out["g_loss"]), g_o, "update cosines", check.rows)
+        assert len(check.rows) == nsub
+        for name, v in gan.store.trainable_variables():
+            assert float(v.detach().abs().max()) > 0.0
+        if free is not None and step == 0:
+            # the same step free-running (the comparison of rounds 1-4): D losses at their old band
+            d_f, g_f = free.train_step(subs)
+            print("free-running oracle d", d_f, "g", g_f)
+            for a, b in zip(d_p, d_f):
+                assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (a, b)
     assert int(gan.global_step.item()) == nsteps
     assert int(gan.global_step_disc.item()) == nsteps * options["disc_iters"]
 
@@ -534,6 +524,22 @@ def test_biggan_at_the_benchmark_batch(dev):
         fwd_tol=(0.03, 2e-3), d_tol=(0.999, 0.06), g_tol=(0.999, 0.06))
 
 
+def test_biggan_d_substep_at_the_c5_batch(dev):
+    """BASELINE.json configs[4] / bench.py's `biggan128_bs256` leg: biggan_imagenet128.gin at 256 per
+    GPU (global 2048 on 8 GPUs, example_configs/biggan_imagenet128.gin:15) -- the dispatcher's
+    choices change with the batch (tile sizes, pixel splits of the weight gradients, grouped
+    launches), and the tests stopped at 64 (VERDICT r04 missing 4).  Generator forward (256
+    samples) and the D sub-step on 512 images -- loss, every gradient -- against the bf16-storage
+    oracle resident on the device; the G sub-step's shapes are the generator's at the same batch
+    and the discriminator's at half of it, both covered here.  Tolerances of the batch-64 test."""
+    torch.cuda.empty_cache()
+    _biggan_family_forward_and_gradients(
+        dev, "biggan-ch96-bs256", [], dict(hierarchical_z=True, embed_y=True, ch=96),
+        dict(project_y=True, ch=96), bsz=256, oracle_device=dev, g_step=False,
+        fwd_tol=(0.03, 2e-3), d_tol=(0.999, 0.06))
+    torch.cuda.empty_cache()
+
+
 def test_biggan_256px(dev):
     """resnet_biggan at 256x256 (resnet_biggan.py:205-221,344-361: seven blocks, attention at 64x64
     in G after B4 and at 128x128 in D after B1 -- 16,384 queries x 4,096 keys), width ch = 32 (the
@@ -765,19 +771,20 @@ def test_joint_gen_for_disc_step_against_oracle(dev):
     rng = np.random.RandomState(500)
     images = rng.uniform(size=(nsub * bsz,) + dataset.image_shape).astype(np.float32)
     labels = np.ones((nsub * bsz,), dtype=np.int32)
-    out = gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
     subs = [{"images": torch.from_numpy(images[i * bsz:(i + 1) * bsz]).double(),
              "z": U.host_uniform((bsz, 128), "z/%d" % i, -1.0, 1.0, SEED, 0).double()}
             for i in range(nsub)]
-    d_o, g_o = ora.train_step(subs)
+    # sub-step by sub-step from identical states (see test_train_steps_resnet_cifar)
+    check = U.stepwise_parity(gan, ora, subs, lr_d=2e-4)
+    gan.sub_step_hook = check
+    try:
+        out = gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+    finally:
+        gan.sub_step_hook = None
+    d_o, g_o = check.finish(out)
     d_s, _ = ora_sep.train_step(subs)
     d_p = [float(x) for x in out["d_losses"]]
     print("joint: product", d_p, "oracle", d_o, "oracle with separate calls", d_s)
-    for a, b in zip(d_p, d_o):
-        assert abs(a - b) <= 2e-2 * max(1.0, abs(b))
-    # (generator loss after five sign-like Adam updates of D: the 4e-2 band of
-    # test_train_steps_resnet_cifar, where the measured spread is written down)
-    assert abs(float(out["g_loss"]) - g_o) <= 4e-2 * max(1.0, abs(g_o))
     # the option is not a no-op: joint statistics move the first loss away from the separate calls'
     assert abs(d_o[0] - d_s[0]) > 1e-6
 
@@ -808,7 +815,8 @@ def test_not_unrolled_step_against_oracle(dev):
         d_p, g_p = float(out["d_losses"][0]), float(out["g_loss"])
         print("call", call, "d", d_p, d_o, "g", g_p, g_o)
         assert abs(d_p - d_o) <= 2e-2 * max(1.0, abs(d_o))
-        assert abs(g_p - g_o) <= 4e-2 * max(1.0, abs(g_o))   # (see test_train_steps_resnet_cifar)
+        # (ONE discriminator update from identical states lies between the resync and this loss)
+        assert abs(g_p - g_o) <= 2e-2 * max(1.0, abs(g_o))
         moved = any(not torch.equal(v, g_before[n])
                     for n, v in gan.store.trainable_variables("generator"))
         assert moved == (call >= 1), "generator update on the wrong call (%d)" % call
