@@ -21,6 +21,11 @@ def _bf16(t):
   if t is None:
     return None
   if t.dtype == F32:
+    if torch.is_grad_enabled() and t.requires_grad:
+      # inside a create_graph=True backward (gradient penalties) the gradient is itself part of a
+      # graph: the raw cast kernel has no autograd node and would cut the second-order path through
+      # it silently -- CastFn is the same kernel with a straight-through gradient
+      return CastFn.apply(t)
     return K.cast_f32_to_bf16(t.contiguous())
   return t.contiguous()
 

@@ -179,16 +179,29 @@ TFDS = {
 }
 
 
+def _version_key(path):
+  """Sort key of a shard directory: its dotted version component (…/3.0.10 > …/3.0.9) as a tuple of
+  ints, other path components as text."""
+  key = []
+  for part in path.split(os.sep):
+    nums = part.split(".")
+    if len(nums) >= 2 and all(n.isdigit() for n in nums):
+      key.append((1, tuple(int(n) for n in nums), ""))
+    else:
+      key.append((0, (), part))
+  return key
+
+
 def shard_files(data_dir, tfds_name, split):
   """The split's shards under <data_dir>/<tfds name>: ONE directory -- with several installed
-  versions / configs (…/3.0.0, …/3.0.1) the last one in sorted order, as TFDS picks the highest
-  version -- never their concatenation."""
+  versions / configs (…/3.0.9, …/3.0.10) the highest VERSION (compared as integer tuples, not as
+  strings), as TFDS picks it -- never their concatenation."""
   root = os.path.join(data_dir, *tfds_name.split("/"))
   files = sorted(glob.glob(os.path.join(root, "**", "*-%s.tfrecord*" % split), recursive=True))
   files = [f for f in files if not f.endswith(".json")]
   if not files:
     return files
-  last_dir = sorted(set(os.path.dirname(f) for f in files))[-1]
+  last_dir = sorted(set(os.path.dirname(f) for f in files), key=_version_key)[-1]
   return [f for f in files if os.path.dirname(f) == last_dir]
 
 
@@ -206,12 +219,16 @@ def load_split(data_dir, name, training, max_examples=None, verify_payload=False
   if not files:
     raise ValueError("no TFRecord shards of %s (%s) under %s" % (name, tname, data_dir))
   images, labels = [], []
+  seen = 0     # records of the earlier shards: the legacy mask does NOT restart at a shard boundary
   for path in files:
     # records are streamed (nothing but the decoded examples that are kept stays in memory).  The
-    # legacy `subsplit([99, 1])` is a repeating 100-record mask per shard: record i of a shard
-    # belongs to the first part iff i % 100 < 99
+    # legacy `subsplit([99, 1])` is a repeating 100-entry mask carried ACROSS the shards: shard s
+    # starts at offset (records of shards 0..s-1) % 100 (TFDS compute_mask_offsets / _build_mask_ds),
+    # so record i of shard s belongs to the first part iff (offset_s + i) % 100 < 99
+    first = seen
     for i, data in enumerate(read_records(path, verify_payload)):
-      if pct is not None and ((i % 100) < pct[0]) != bool(training):
+      seen = first + i + 1
+      if pct is not None and (((first + i) % 100) < pct[0]) != bool(training):
         continue
       ex = parse_example(data)
       if "image" not in ex:

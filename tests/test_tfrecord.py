@@ -123,3 +123,27 @@ def test_lsun_subsplit_mask_repeats_every_100_records_and_one_version_is_read(tm
     # max_examples stops the decoding early (the evaluation only takes the first N)
     few, _ = tfrecord.load_split(str(root), "lsun-bedroom", True, max_examples=5)
     assert len(few) == 5 and [int(im[0, 0, 0]) for im in few] == [0, 1, 2, 3, 4]
+
+
+def test_lsun_subsplit_mask_is_carried_across_shards_and_versions_sort_numerically(tmp_path):
+    """legacy TFDS carries the 100-entry `subsplit([99, 1])` mask across shard
+    boundaries -- shard s starts at offset (records of the earlier shards) % 100
+    (compute_mask_offsets / _build_mask_ds) -- so with shards of 130 and 90 records the evaluation
+    part is the GLOBAL records 99 and 199 (local index 69 of the second shard), not local index 99
+    of each shard.  Version directories compare as integer tuples: 3.0.10 is newer than 3.0.9."""
+    root = tmp_path / "tfds"
+    for version, sizes in (("3.0.9", (40,)), ("3.0.10", (130, 90))):
+        d = root / "lsun" / "bedroom" / version
+        d.mkdir(parents=True)
+        g = 0
+        for s, n in enumerate(sizes):
+            ims = [np.full((8, 8, 3), (g + i) % 256, dtype=np.uint8) for i in range(n)]
+            g += n
+            tfrecord.write_records(str(d / ("lsun-train.tfrecord-%05d-of-%05d" % (s, len(sizes)))),
+                                   [tfrecord.make_example({"image": _png(im)}) for im in ims])
+    files = tfrecord.shard_files(str(root), "lsun/bedroom", "train")
+    assert len(files) == 2 and all("3.0.10" in f for f in files)
+    tr, _ = tfrecord.load_split(str(root), "lsun-bedroom", True)
+    ev, _ = tfrecord.load_split(str(root), "lsun-bedroom", False)
+    assert len(tr) == 218 and [int(im[0, 0, 0]) for im in ev] == [99, 199]
+    assert 99 not in [int(im[0, 0, 0]) for im in tr] and 199 not in [int(im[0, 0, 0]) for im in tr]
