@@ -68,6 +68,37 @@ void cg_prof_end(int family, hipStream_t st) {
   if (p.ev.size() >= 2) hipEventRecord(p.ev.back(), st);
 }
 
+// CRC32C (Castagnoli, reflected 0x82F63B78), slice-by-8 on the host: the checksum of TFRecord
+// payloads (datasets.py:430-532 reads TFDS shards) and of tensor-bundle blocks / tensors
+// (compare_gan_amd/tf_checkpoint.py).  Plain host code: no device, no stream.
+extern "C" uint32_t cg_host_crc32c(const void* data, size_t n, uint32_t seed) {
+  static uint32_t T[8][256];
+  static bool ready = [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+    return true;
+  }();
+  (void)ready;
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = ~seed;
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = T[7][w & 0xFF] ^ T[6][(w >> 8) & 0xFF] ^ T[5][(w >> 16) & 0xFF] ^ T[4][(w >> 24) & 0xFF] ^
+        T[3][(w >> 32) & 0xFF] ^ T[2][(w >> 40) & 0xFF] ^ T[1][(w >> 48) & 0xFF] ^ T[0][w >> 56];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return ~c;
+}
+
 extern "C" int cg_prof_family_count(void) { return CG_PROF_COUNT; }
 extern "C" const char* cg_prof_family_name(int family) {
   return (family >= 0 && family < CG_PROF_COUNT) ? g_prof_names[family] : "";

@@ -112,6 +112,7 @@ SIGNATURES = {
     "cg_flatten_multi": (c_int, [vp, vp, c_int, vp, vp]),
     "cg_scale_f32": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
     "cg_scale_count_nan_f32": (c_int, [vp, c_f32, vp, c_i64, vp, vp]),
+    "cg_host_crc32c": (ctypes.c_uint32, [vp, c_sz, ctypes.c_uint32]),
     "cg_bn_finalize_groups": (c_int, [vp, c_int, c_int, c_i64, c_int, c_int, vp, vp, vp, vp, c_f32,
                                      vp]),
     "cg_bn_stats_groups_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),

@@ -171,6 +171,13 @@ def latest_checkpoint(model_dir):
   return path if os.path.isfile(path) else None
 
 
+def _latest_tf_checkpoint(model_dir):
+  if not model_dir or not os.path.isdir(model_dir):
+    return None
+  from compare_gan_amd import tf_checkpoint
+  return tf_checkpoint.latest_checkpoint(model_dir)
+
+
 def _barrier():
   import torch.distributed as dist
   if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -250,6 +257,15 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
   if ckpt is not None:                              # README.md:93-94 resume
     gan.load_state_dict(torch.load(ckpt, map_location=device))
     start = int(gan.global_step.item())
+  else:
+    # a model_dir written by the REFERENCE (TF-1 tensor bundles `model.ckpt-<step>.index` +
+    # `.data-*`, same variable names: SURVEY App. D): continue from its newest checkpoint
+    tf_ckpt = _broadcast_from_rank0(_latest_tf_checkpoint(run_config.model_dir)
+                                    if tpu_ops.replica_id() == 0 else None)
+    if tf_ckpt is not None:
+      from compare_gan_amd import tf_checkpoint
+      tf_checkpoint.import_tf_checkpoint(gan, tf_ckpt)
+      start = int(gan.global_step.item())
   num_sub = options.get("disc_iters", 1) + 1
   batches = dataset.train_batches(bsz * num_sub, seed=dataset._seed + tpu_ops.replica_id())  # pylint: disable=protected-access
   if start == 0 and tpu_ops.replica_id() == 0:

@@ -44,11 +44,33 @@ def _crc_table():
 _TABLE = _crc_table()
 
 
-def crc32c(data):
+_NATIVE = [None]
+
+
+def _native_crc32c():
+  """cg_host_crc32c of libcgamd.so (slice-by-8, ~1 GB/s) when the library is there; False otherwise."""
+  if _NATIVE[0] is None:
+    try:
+      from compare_gan_amd.hip import _lib
+      _NATIVE[0] = _lib.load().cg_host_crc32c
+    except Exception:  # pylint: disable=broad-except
+      _NATIVE[0] = False
+  return _NATIVE[0]
+
+
+def crc32c_py(data):
   c = 0xFFFFFFFF
   for b in bytes(data):
     c = _TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
   return c ^ 0xFFFFFFFF
+
+
+def crc32c(data):
+  fn = _native_crc32c()
+  if fn:
+    data = bytes(data)
+    return int(fn(data, len(data), 0))
+  return crc32c_py(data)
 
 
 def masked_crc32c(data):

@@ -399,6 +399,10 @@ int cg_axpby(const void* a, float alpha, const void* b, float beta, void* out, i
  * d_loss += lambda * penalty, modular_gan.py:670).  b may be NULL. */
 int cg_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, int64_t n,
                  cgStream stream);
+/* HOST utility (no device work): CRC32C (Castagnoli) of n bytes, continuing from `seed` (0 for a
+ * fresh checksum) -- TFRecord payloads of the TFDS shards (datasets.py:430-532) and the blocks /
+ * tensors of TF-1 tensor bundles (modular_gan.py:266-285 restores them). */
+uint32_t cg_host_crc32c(const void* data, size_t n, uint32_t seed);
 /* out = x * scale on fp32 and *nan_count += (number of NaNs in x): the sampled images of an
  * evaluation set are scaled to [0, 255] and tested with np.isnan (eval_utils.py:144-162) -- one
  * pass per generator batch, written straight into the batch's slot of the set.  nan_count: int32 on
