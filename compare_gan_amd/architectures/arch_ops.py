@@ -781,6 +781,46 @@ def reduce_spatial(inputs, mean):
   return Fn.SpatialReduceFn.apply(x, gate, (1.0 / hw) if mean else 1.0)
 
 
+_DOUBLE_BWD = [False]
+_FUSED_HEAD = _os.environ.get("CGAMD_FUSED_HEAD", "1") != "0"    # A/B switch (read once)
+
+
+class twice_differentiable(object):
+  """Context for network calls whose gradient will itself be differentiated (the discriminator call
+  of a gradient penalty, penalty_lib.py:59-82): fused ops without a second derivative fall back
+  to their separate, twice differentiable launches."""
+
+  def __enter__(self):
+    self._old = _DOUBLE_BWD[0]
+    _DOUBLE_BWD[0] = True
+
+  def __exit__(self, *exc):
+    _DOUBLE_BWD[0] = self._old
+
+
+def pooled_linear_head(inputs, mean, scope, use_sn=False):
+  """relu -> reduce_mean / reduce_sum over [1, 2] -> linear(C -> 1): the tail of every ResNet
+  discriminator (resnet_cifar.py:154-157, resnet5.py:141-145, resnet_stl.py, resnet_biggan.py:404-407).
+  inputs: ops.relu(net).  Returns (out_logit [N,1] fp32, h [N,C] bf16), both differentiable.
+  One fused launch per direction where it exists (Fn.PooledHeadFn); the reference's two ops
+  otherwise (gradient penalties, leaky gates, channel counts that are not multiples of 8)."""
+  x, slope = _split_act(inputs)
+  n, c = x.shape[0], x.shape[-1]
+  hw = x.numel() // max(1, n * c)
+  if (x.is_meta or not _FUSED_HEAD or _DOUBLE_BWD[0] or slope != 0.0 or x.dtype != BF16 or
+      not K.pooled_head_supported(hw, c)):
+    h = reduce_spatial(inputs, mean=mean)
+    return linear(h, 1, scope=scope, use_sn=use_sn, out_f32=True), h
+  with variable_scope(scope):
+    kernel = get_variable("kernel", [c, 1], weight_initializer(stddev=0.02))
+    if use_sn:
+      kernel = spectral_norm(kernel)
+    bias = get_variable("bias", [1], constant(0.0))
+    store = current_store()
+    store.bt_ready.pop(store.full_name("kernel"), None)   # (prepare_module()'s operand image is not needed)
+    return Fn.PooledHeadFn.apply(x, kernel, bias, (1.0 / hw) if mean else 1.0)
+
+
 def output_head(pre_activation, kind):
   """sigmoid (kind 0) or (tanh + 1) / 2 (kind 1) on the fp32 pre-activation."""
   if pre_activation.is_meta:

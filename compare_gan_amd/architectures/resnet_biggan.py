@@ -153,8 +153,9 @@ class Discriminator(abstract_arch.AbstractDiscriminator):
       net = block(net, z=None, y=y, is_training=is_training)
       if name in self._blocks_with_attention:
         net = ops.non_local_block(net, "non_local_block", use_sn=self._spectral_norm)
-    h = ops.reduce_spatial(ops.relu(net), mean=False)   # relu + reduce_sum over [1, 2]
-    out_logit = ops.linear(h, 1, scope="final_fc", use_sn=self._spectral_norm, out_f32=True)
+    # relu + reduce_sum over [1, 2] + linear(C -> 1); h also feeds the projection term below
+    out_logit, h = ops.pooled_linear_head(ops.relu(net), mean=False, scope="final_fc",
+                                          use_sn=self._spectral_norm)
     if self._project_y:
       if y is None:
         raise ValueError("You must provide class information y to project.")

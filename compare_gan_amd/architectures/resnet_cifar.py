@@ -74,8 +74,9 @@ class Discriminator(resnet_ops.ResNetDiscriminator):
                                  in_channels=colors if block_idx == 0 else 128,
                                  out_channels=128, scale="down" if block_idx <= 1 else "none")
       output = block(output, z=None, y=y, is_training=is_training)
-    h = ops.reduce_spatial(ops.relu(output), mean=True)   # relu + reduce_mean over [1, 2]
-    out_logit = ops.linear(h, 1, scope="disc_final_fc", use_sn=self._spectral_norm, out_f32=True)
+    # relu + reduce_mean over [1, 2] + linear(128 -> 1)
+    out_logit, h = ops.pooled_linear_head(ops.relu(output), mean=True, scope="disc_final_fc",
+                                          use_sn=self._spectral_norm)
     if self._project_y:
       if y is None:
         raise ValueError("You must provide class information y to project.")

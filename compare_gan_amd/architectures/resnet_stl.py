@@ -45,7 +45,6 @@ class Discriminator(resnet_ops.ResNetDiscriminator):
                                  out_channels=ch * magic[block_idx][1],
                                  scale="down" if block_idx < 3 else "none")
       output = block(output, z=None, y=y, is_training=is_training)
-    pre_logits = ops.reduce_spatial(ops.relu(output), mean=True)
-    out_logit = ops.linear(pre_logits, 1, scope="disc_final_fc", use_sn=self._spectral_norm,
-                           out_f32=True)
+    out_logit, pre_logits = ops.pooled_linear_head(ops.relu(output), mean=True, scope="disc_final_fc",
+                                                   use_sn=self._spectral_norm)
     return ops.output_head(out_logit, 0), out_logit, pre_logits

@@ -22,7 +22,8 @@ def _gradient_norm_penalty(discriminator, x_in, y, is_training, input_scale=1.0)
   [0,1] image): d logits / d x = a * d logits / d x_in, hence `input_scale` = a.  The inner backward
   runs with create_graph=True so the penalty is differentiable w.r.t. D's weights; every op on that
   path is a HIP kernel."""
-  logits = discriminator(x_in, y=y, is_training=is_training, reuse=True)[1]
+  with ops.twice_differentiable():     # this call's backward is differentiated again below
+    logits = discriminator(x_in, y=y, is_training=is_training, reuse=True)[1]
   ones = torch.ones_like(logits)   # d(sum logits)/d logits: a constant fill, not arithmetic
   with Fn.only_input_grads():
     gradients, = torch.autograd.grad(logits, [x_in], grad_outputs=ones, create_graph=True)

@@ -146,6 +146,11 @@ SIGNATURES = {
     "cg_maxpool2_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_spatial_reduce": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),
     "cg_spatial_reduce_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),
+    "cg_pooled_head_supported": (c_int, [c_int, c_int]),
+    "cg_pooled_head_fwd": (c_int, [vp, c_int, c_int, c_int, c_f32, vp, vp, vp, vp, vp]),
+    "cg_pooled_head_bwd_workspace_bytes": (c_sz, [c_int, c_int]),
+    "cg_pooled_head_bwd": (c_int, [vp, c_int, c_int, c_int, c_f32, vp, vp, vp, vp, vp, vp, vp, vp,
+                                   c_sz, vp]),
     "cg_head": (c_int, [vp, c_int, vp, c_i64, vp]),
     "cg_head_bwd": (c_int, [vp, c_int, vp, c_int, vp, c_i64, vp]),
     "cg_cast_f32_to_bf16": (c_int, [vp, vp, c_i64, vp]),

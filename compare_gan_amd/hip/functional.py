@@ -760,6 +760,46 @@ class SpatialReduceBwdFn(torch.autograd.Function):
     return SpatialReduceFn.apply(_bf16(ddx), gate, ctx.scale), None, None, None
 
 
+class PooledHeadFn(torch.autograd.Function):
+  """(logit [N,1] fp32, pooled [N,C] bf16) = head(x [N,...,C] bf16, w [C,1] fp32, bias [1] fp32):
+  relu -> scale * sum over the spatial axes -> linear(C -> 1), one launch forward, one (+ a small
+  reduction) backward (cg_pooled_head_*; resnet_cifar.py:154-157, arch_ops.py:538-556).  `pooled`
+  is differentiable too (projection discriminators and the self-supervised heads read it).  Not
+  twice differentiable: gradient penalties call the discriminator inside ops.twice_differentiable(),
+  where the separate (differentiable) launches run instead."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, scale):
+    n, c = x.shape[0], x.shape[-1]
+    x3 = x.contiguous().reshape(n, -1, c)
+    wv = w.contiguous().reshape(-1)
+    logit, pooled = K.pooled_head_fwd(x3, wv, bias, scale)
+    ctx.scale, ctx.shape = scale, x.shape
+    ctx.save_for_backward(x3, wv, pooled)
+    ctx.w_shape = w.shape
+    ctx.has_bias = bias is not None
+    ctx.set_materialize_grads(False)
+    ctx.mark_non_differentiable()
+    return logit, pooled
+
+  @staticmethod
+  def backward(ctx, dlogit, dpooled):
+    if torch.is_grad_enabled():
+      raise RuntimeError("PooledHeadFn is not twice differentiable: call the discriminator inside "
+                         "ops.twice_differentiable() when its gradient will be differentiated again")
+    x3, wv, pooled = ctx.saved_tensors
+    if dlogit is None and dpooled is None:
+      return None, None, None, None
+    dl = dlogit.contiguous().reshape(-1).float() if dlogit is not None else None
+    dp = _bf16(dpooled) if dpooled is not None else None
+    need_w = ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS[0]
+    need_b = ctx.has_bias and ctx.needs_input_grad[2] and not _SKIP_PARAM_GRADS[0]
+    dx, dw, db = K.pooled_head_bwd(x3, wv, ctx.scale, pooled, dlogit=dl, dpooled=dp,
+                                   want_dw=need_w, want_dbias=need_b)
+    return (dx.reshape(ctx.shape) if ctx.needs_input_grad[0] else None,
+            dw.reshape(ctx.w_shape) if dw is not None else None, db, None)
+
+
 def avg_pool2(x):
   return AvgPool2Fn.apply(x)
 

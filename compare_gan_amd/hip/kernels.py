@@ -806,6 +806,46 @@ def spatial_reduce(x, gate, scale):
     return out
 
 
+def pooled_head_supported(HW, C):
+    return bool(lib().cg_pooled_head_supported(int(HW), int(C)))
+
+
+def pooled_head_fwd(x3, w, bias, scale):
+    """x3 [N,HW,C] bf16, w [C] fp32, bias [1] fp32 or None -> (logit [N,1] fp32, pooled [N,C] bf16):
+    relu -> scale * sum over HW -> linear(C -> 1) in one launch (cg_pooled_head_fwd)."""
+    _req(x3, BF16, "x")
+    _req(w, F32, "w")
+    _req(bias, F32, "bias", True)
+    N, HW, C = x3.shape
+    if w.numel() != C:
+        raise ValueError("w must have %d elements" % C)
+    pooled = torch.empty((N, C), dtype=BF16, device=x3.device)
+    logit = torch.empty((N, 1), dtype=F32, device=x3.device)
+    check(lib().cg_pooled_head_fwd(_p(x3), N, HW, C, float(scale), _p(w), _p(bias), _p(pooled),
+                                   _p(logit), _stream()), "cg_pooled_head_fwd")
+    return logit, pooled
+
+
+def pooled_head_bwd(x3, w, scale, pooled, dlogit=None, dpooled=None, want_dw=True, want_dbias=True):
+    """-> (dx [N,HW,C] bf16, dw [C] fp32 or None, dbias [1] fp32 or None)."""
+    _req(x3, BF16, "x")
+    _req(w, F32, "w")
+    _req(pooled, BF16, "pooled")
+    _req(dlogit, F32, "dlogit", True)
+    _req(dpooled, BF16, "dpooled", True)
+    N, HW, C = x3.shape
+    want_dw = bool(want_dw and dlogit is not None)
+    want_dbias = bool(want_dbias and dlogit is not None)
+    dx = torch.empty_like(x3)
+    dw = torch.empty((C,), dtype=F32, device=x3.device) if want_dw else None
+    db = torch.empty((1,), dtype=F32, device=x3.device) if want_dbias else None
+    ws = _ws(lib().cg_pooled_head_bwd_workspace_bytes(N, C), x3)
+    check(lib().cg_pooled_head_bwd(_p(x3), N, HW, C, float(scale), _p(w), _p(dlogit), _p(dpooled),
+                                   _p(pooled), _p(dx), _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+          "cg_pooled_head_bwd")
+    return dx, dw, db
+
+
 def spatial_reduce_bwd(gate, dout, shape, scale):
     _req(dout, BF16, "dout")
     _req(gate, BF16, "gate", True)

@@ -438,6 +438,24 @@ int cg_maxpool2_bwd(const void* x, const void* dy, int N, int H, int W, int C, v
 int cg_spatial_reduce(const void* x, const void* gate, int N, int HW, int C, float scale,
                       void* out, cgStream stream);
 /* dx[n,hw,c] = scale * dout[n,c] * (gate ? gate>0 : 1) */
+/* The discriminator's output head, one launch per direction (resnet_cifar.py:154-157,
+ * resnet5.py:141-145, resnet_biggan.py:404-407: relu -> reduce_mean / reduce_sum over [1, 2] ->
+ * linear(C -> 1), arch_ops.py:538-556):
+ *   pooled[n,c] = bf16(scale * sum_hw relu(x[n,hw,c]))     x [N,HW,C] bf16, pooled [N,C] bf16
+ *   logit[n]    = sum_c pooled[n,c] * bf16(w[c]) + bias[0]  w [C] fp32 (the [C,1] kernel, after
+ *                                                           spectral norm), bias [1] fp32 or NULL
+ * Backward: dlogit [N] fp32 (NULL = no gradient through the logits), dpooled_ext [N,C] bf16 or NULL
+ * (a gradient arriving through `pooled` itself: projection discriminators read it,
+ * resnet_biggan.py:408-415), both added; dx [N,HW,C] bf16; dw [C] / dbias [1] fp32 or NULL.  The
+ * bf16 rounding points are those of the separate launches (pooled, d pooled, dx).
+ * C % 8 == 0 (cg_pooled_head_supported).  ws >= cg_pooled_head_bwd_workspace_bytes(N, C) when dw. */
+int cg_pooled_head_supported(int HW, int C);
+int cg_pooled_head_fwd(const void* x, int N, int HW, int C, float scale, const float* w,
+                       const float* bias, void* pooled, float* logit, cgStream stream);
+size_t cg_pooled_head_bwd_workspace_bytes(int N, int C);
+int cg_pooled_head_bwd(const void* x, int N, int HW, int C, float scale, const float* w,
+                       const float* dlogit, const void* dpooled_ext, const void* pooled, void* dx,
+                       float* dw, float* dbias, void* ws, size_t ws_bytes, cgStream stream);
 int cg_spatial_reduce_bwd(const void* gate, const void* dout, int N, int HW, int C, float scale,
                           void* dx, cgStream stream);
 /* Output heads (resnet_cifar.py:112 sigmoid; resnet_biggan.py:301 / sndcgan.py:74-78

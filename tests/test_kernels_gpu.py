@@ -1334,3 +1334,78 @@ def test_unpool_standalone(K, dev, shape):
     gx, gr = torch.autograd.grad(out, [xd, rd], grad_outputs=dy.to(dev))
     assert torch.equal(gx.cpu().double(), dy_ref[:, ::2, ::2, :])
     assert torch.equal(gr.cpu().double(), dy_ref)
+
+
+def _bf(t):
+    return t.float().to(torch.bfloat16).double()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,HW,C,mean", [(128, 64, 128, True), (16, 16, 512, True), (6, 16, 1536, False),
+                                         (3, 5, 24, False), (2, 4, 2056, True)],
+                         ids=["cifar", "resnet5", "biggan", "small_ragged", "wide"])
+def test_pooled_head(K, dev, N, HW, C, mean):
+    """cg_pooled_head_fwd / _bwd (relu -> reduce_mean / reduce_sum over [1, 2] -> linear(C -> 1),
+    resnet_cifar.py:154-157 + arch_ops.py:538-556, in one launch per direction) against the fp64
+    restatement with the bf16 rounding points of the separate launches: pooled, d pooled and dx are
+    bf16 tensors; an extra gradient through `pooled` (projection discriminators) is added; then the
+    autograd Function against the separate Functions it replaces (same roundings: bf16 noise only)."""
+    from compare_gan_amd.hip import functional as Fn
+    g = _gen(N + C)
+    x64, x = rand_bf16((N, HW, C), g)
+    w = (torch.randn(C, generator=g) * 0.1).float()
+    b = torch.randn(1, generator=g).float()
+    dl = torch.randn(N, generator=g).float()
+    _, ext = rand_bf16((N, C), g, scale=0.05)
+    scale = 1.0 / HW if mean else 1.0
+    pooled_ref = _bf(scale * torch.relu(x64).sum(1))
+    w16 = _bf(w)
+    logit_ref = pooled_ref @ w16 + b.double()
+    logit, pooled = K.pooled_head_fwd(x.to(dev), w.to(dev), b.to(dev), scale)
+    # pooled: one bf16 rounding of an fp32 sum -> at most one ulp from the fp64 reference's rounding
+    assert_close_bf16(pooled, pooled_ref, "pooled", ulps=1.01, abs_rms=1e-6)
+    p_dev = pooled.cpu().double()
+    assert_close_f32(logit, (p_dev @ w16 + b.double()).reshape(N, 1), "logit", 1e-5, 1e-5)
+    for use_ext in (False, True):
+        dl16 = _bf(dl)
+        dp = _bf(dl16[:, None] * w16[None, :])
+        if use_ext:
+            dp = _bf(dp + ext.double())
+        dx_ref = torch.where(x64 > 0, _bf(scale * dp)[:, None, :].expand(N, HW, C), torch.zeros((), dtype=torch.float64))
+        dw_ref = (p_dev * dl16[:, None]).sum(0)
+        db_ref = dl16.sum().reshape(1)
+        dx, dw, db = K.pooled_head_bwd(x.to(dev), w.to(dev), scale, pooled, dlogit=dl.to(dev),
+                                       dpooled=ext.to(dev) if use_ext else None)
+        assert torch.equal(dx.cpu().double(), dx_ref), "dx (ext %s)" % use_ext
+        assert_close_f32(dw, dw_ref, "dw", 1e-5, 1e-6)
+        assert_close_f32(db, db_ref, "dbias", 1e-5, 1e-6)
+    # only through pooled (no logit gradient), no parameter gradients
+    dx, dw, db = K.pooled_head_bwd(x.to(dev), w.to(dev), scale, pooled, dlogit=None, dpooled=ext.to(dev))
+    assert dw is None and db is None
+    dx_ref = torch.where(x64 > 0, _bf(scale * ext.double())[:, None, :].expand(N, HW, C), torch.zeros((), dtype=torch.float64))
+    assert torch.equal(dx.cpu().double(), dx_ref)
+    # the autograd Function against the separate Functions
+    side = int(round(math.sqrt(HW)))
+    shape = (N, side, side, C) if side * side == HW else (N, HW, 1, C)
+    xs = [x.to(dev).reshape(shape).clone().requires_grad_(True) for _ in range(2)]
+    ws = [w.to(dev).reshape(C, 1).clone().requires_grad_(True) for _ in range(2)]
+    bs = [b.to(dev).clone().requires_grad_(True) for _ in range(2)]
+    lo_f, po_f = Fn.PooledHeadFn.apply(xs[0], ws[0], bs[0], scale)
+    po_u = Fn.SpatialReduceFn.apply(xs[1], xs[1].detach(), scale)
+    geom = K.make_geom(N, 1, 1, C, 1, 1, 1, 1, 1)
+    lo_u = Fn.gconv(po_u.reshape(N, 1, 1, C), ws[1].reshape(1, 1, C, 1), bs[1], None, None, None,
+                    Fn.ConvSpec(geom, transpose=False, slope_in=None, out_f32=True), False, None).reshape(N, 1)
+    assert torch.equal(po_f, po_u) or float((po_f.float() - po_u.float()).abs().max()) <= 2.0 ** -7 * float(po_u.float().abs().max())
+    assert_close_f32(lo_f, lo_u.double().cpu(), "logit vs separate", 2e-3, 2e-3)
+    gl = dl.to(dev).reshape(N, 1)
+    gp = ext.to(dev)
+    torch.autograd.backward([lo_f, po_f], [gl, gp])
+    torch.autograd.backward([lo_u, po_u], [gl, gp])
+    assert U_cos(xs[0].grad, xs[1].grad) >= 0.9999
+    assert_close_f32(ws[0].grad, ws[1].grad.double().cpu(), "dw vs separate", 2e-2, 2e-3)
+    assert_close_f32(bs[0].grad, bs[1].grad.double().cpu(), "db vs separate", 1e-3, 1e-4)
+
+
+def U_cos(a, b):
+    a, b = a.double().reshape(-1).cpu(), b.double().reshape(-1).cpu()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
