@@ -122,12 +122,15 @@ def cpu_baseline(config, batch, budget_s=20.0, mode="step", no_penalty=False):
                           what, config, batch, dt, t_first)}
 
 
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r04_pmc_traffic.json")
+_PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+PMC_TRAFFIC_FILE = next((p for p in (os.path.join(_PROFILES, "r05_pmc_traffic.json"),
+                                     os.path.join(_PROFILES, "r04_pmc_traffic.json"))
+                         if os.path.exists(p)), os.path.join(_PROFILES, "r05_pmc_traffic.json"))
 PMC_TRAFFIC_NOTE = ("HBM bytes per launch of this kernel family = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                     "from two rocprofv3 --pmc passes of this workload (scripts/pmc_traffic.py -> "
-                    "profiles/r04_pmc_traffic.json, one table per workload); null when that summary "
-                    "is absent")
+                    "profiles/%s, one table per workload; counters cannot be read from inside the "
+                    "timed process, so this is the committed summary of those passes, not a property "
+                    "of this run); null when that summary is absent" % os.path.basename(PMC_TRAFFIC_FILE))
 
 
 def pmc_traffic(family, workload="cifar"):
