@@ -467,7 +467,7 @@ def conv_pool_supported(inputs, output_dim, k_h, k_w):
 
 def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", use_sn=False,
            use_bias=True, upsample=False, residual=None, out_f32=False, dx_f32=False, pool=False,
-           pad_out_to=None, logical_in=None):
+           pad_out_to=None, logical_in=None, kernel_scale=None):
   """2-D convolution, TF 'SAME' padding (arch_ops.py:559-573).
 
   Extensions that keep the reference semantics but fuse its neighbours into the kernel:
@@ -495,6 +495,11 @@ def conv2d(inputs, output_dim, k_h, k_w, d_h, d_w, stddev=0.02, name="conv2d", u
     if use_sn:
       w = spectral_norm(w, build_only=x.is_meta)
     bias = get_variable("bias", [output_dim], constant(0.0)) if use_bias else None
+    if kernel_scale is not None and not x.is_meta:
+      # a trainable scalar in front of the convolution (`x + sigma * conv(...)`) folded into the
+      # kernel: Fn.ScaleWeightFn; the operand images prepare_module() made are of the unscaled kernel
+      w = Fn.ScaleWeightFn.apply(w, kernel_scale)
+      resized = True
     if padded:
       if bias is not None and co_run != output_dim:
         bias = torch.nn.functional.pad(bias, (0, co_run - output_dim))
@@ -781,6 +786,7 @@ def reduce_spatial(inputs, mean):
   return Fn.SpatialReduceFn.apply(x, gate, (1.0 / hw) if mean else 1.0)
 
 
+_FOLD_SIGMA = _os.environ.get("CGAMD_FOLD_SIGMA", "1") != "0"    # A/B switch (read once)
 _DOUBLE_BWD = [False]
 _FUSED_HEAD = _os.environ.get("CGAMD_FUSED_HEAD", "1") != "0"    # A/B switch (read once)
 
@@ -853,8 +859,14 @@ def non_local_block(x, name, use_sn):
       attn_g = Fn.AttentionFn.apply(theta.reshape(n, h * w, cap), phi.reshape(n, h * w // 4, cap),
                                     g.reshape(n, h * w // 4, cgp)).reshape(n, h, w, cgp)
     sigma = get_variable("sigma", [], constant(0.0))
-    attn_g = conv1x1(attn_g, c, name="conv2d_attn_g", use_sn=use_sn, use_bias=False,
-                     logical_in=cg)
-    if x.is_meta:
-      return x
-    return Fn.ScaledResidualFn.apply(x, attn_g, sigma.reshape(1))
+    if x.is_meta or not _FOLD_SIGMA:
+      attn_g = conv1x1(attn_g, c, name="conv2d_attn_g", use_sn=use_sn, use_bias=False,
+                       logical_in=cg)
+      if x.is_meta:
+        return x
+      return Fn.ScaledResidualFn.apply(x, attn_g, sigma.reshape(1))
+    # x + sigma * conv(attn_g, w) as ONE convolution: sigma folded into the kernel, x the residual of
+    # its epilogue (three passes over the [N, 64, 64, C] map less per call: the scaled add, its
+    # gradient sigma * dy, and the dot product for d sigma)
+    return conv1x1(attn_g, c, name="conv2d_attn_g", use_sn=use_sn, use_bias=False, logical_in=cg,
+                   kernel_scale=sigma, residual=x.contiguous())

@@ -146,6 +146,25 @@ __global__ __launch_bounds__(HB) void pooled_head_reduce_kernel(const float* __r
   }
 }
 
+// out[0] = sum_i a[i] * b[i] on fp32 (fixed order: 1024 strided lanes, then a tree): the gradient of
+// a scalar that multiplies a weight tensor
+__global__ __launch_bounds__(1024) void dot_f32_kernel(const float* __restrict__ a,
+                                                       const float* __restrict__ b, int64_t n,
+                                                       float* __restrict__ out) {
+  __shared__ float sm[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    out[0] = t;
+  }
+}
+
 size_t head_lds_bytes(int C) {
   const int G = C >> 3, R = G <= HB ? HB / G : 1;
   return ((size_t)R * C + 4) * sizeof(float);
@@ -166,6 +185,13 @@ extern "C" int cg_pooled_head_fwd(const void* x, int N, int HW, int C, float sca
   pooled_head_fwd_kernel<<<N, HB, head_lds_bytes(C), (hipStream_t)stream>>>(
       (const bf16_t*)x, HW, C, scale, w, bias, (bf16_t*)pooled, logit);
   CG_CHECK_LAUNCH("cg_pooled_head_fwd");
+  return CG_OK;
+}
+
+extern "C" int cg_dot_f32(const float* a, const float* b, int64_t n, float* out, cgStream stream) {
+  if (!a || !b || !out || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_dot_f32: bad argument");
+  dot_f32_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a, b, n, out);
+  CG_CHECK_LAUNCH("cg_dot_f32");
   return CG_OK;
 }
 

@@ -146,6 +146,7 @@ SIGNATURES = {
     "cg_maxpool2_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_spatial_reduce": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),
     "cg_spatial_reduce_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_f32, vp, vp]),
+    "cg_dot_f32": (c_int, [vp, vp, c_i64, vp, vp]),
     "cg_pooled_head_supported": (c_int, [c_int, c_int]),
     "cg_pooled_head_fwd": (c_int, [vp, c_int, c_int, c_int, c_f32, vp, vp, vp, vp, vp]),
     "cg_pooled_head_bwd_workspace_bytes": (c_sz, [c_int, c_int]),

@@ -1007,6 +1007,28 @@ class AttentionFn(torch.autograd.Function):
     return K.attention_bwd(theta, phi, g, out, lse, _bf16(dout))
 
 
+class ScaleWeightFn(torch.autograd.Function):
+  """w_eff = sigma * w for a trainable device scalar sigma: `x + sigma * conv(a, w)`
+  (arch_ops.py:755-758) runs as conv(a, sigma * w) with x as the convolution's residual -- no pass
+  over the activations for the scaled add, none for its gradients: d w = sigma * d w_eff,
+  d sigma = <d w_eff, w> (a dot over the weight, not over the feature map)."""
+
+  @staticmethod
+  def forward(ctx, w, sigma):
+    w = w.contiguous()
+    ctx.save_for_backward(w, sigma)
+    return K.scale_f32(w, sigma.reshape(1).contiguous())
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, dweff):
+    w, sigma = ctx.saved_tensors
+    dweff = dweff.contiguous()
+    dw = K.scale_f32(dweff, sigma.reshape(1).contiguous()) if ctx.needs_input_grad[0] else None
+    dsig = K.dot_f32(dweff, w).reshape(sigma.shape) if ctx.needs_input_grad[1] else None
+    return dw, dsig
+
+
 class ScaledResidualFn(torch.autograd.Function):
   """x + sigma * o with a trainable scalar sigma (arch_ops.py:755-758)."""
 

@@ -806,6 +806,17 @@ def spatial_reduce(x, gate, scale):
     return out
 
 
+def dot_f32(a, b):
+    """sum(a * b) of two fp32 tensors of one shape -> fp32 [1] (one workgroup: weight-sized inputs)."""
+    _req(a, F32, "a")
+    _req(b, F32, "b")
+    if a.numel() != b.numel():
+        raise ValueError("dot_f32: operands differ in size")
+    out = torch.empty((1,), dtype=F32, device=a.device)
+    check(lib().cg_dot_f32(_p(a), _p(b), a.numel(), _p(out), _stream()), "cg_dot_f32")
+    return out
+
+
 def pooled_head_supported(HW, C):
     return bool(lib().cg_pooled_head_supported(int(HW), int(C)))
 

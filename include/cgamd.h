@@ -449,6 +449,11 @@ int cg_spatial_reduce(const void* x, const void* gate, int N, int HW, int C, flo
  * resnet_biggan.py:408-415), both added; dx [N,HW,C] bf16; dw [C] / dbias [1] fp32 or NULL.  The
  * bf16 rounding points are those of the separate launches (pooled, d pooled, dx).
  * C % 8 == 0 (cg_pooled_head_supported).  ws >= cg_pooled_head_bwd_workspace_bytes(N, C) when dw. */
+/* out[0] = sum_i a[i] * b[i] on fp32, one workgroup, fixed summation order: d(loss)/d(sigma) of a
+ * scalar folded into a weight tensor (w_eff = sigma * w: d sigma = <d w_eff, w>; the self-attention
+ * block's `x + sigma * conv(attn_g, w)`, arch_ops.py:755-758, runs as conv(attn_g, sigma * w) with
+ * x as the convolution's residual).  Meant for weight-sized n. */
+int cg_dot_f32(const float* a, const float* b, int64_t n, float* out, cgStream stream);
 int cg_pooled_head_supported(int HW, int C);
 int cg_pooled_head_fwd(const void* x, int N, int HW, int C, float scale, const float* w,
                        const float* bias, void* pooled, float* logit, cgStream stream);

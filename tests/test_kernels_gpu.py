@@ -1409,3 +1409,53 @@ def test_pooled_head(K, dev, N, HW, C, mean):
 def U_cos(a, b):
     a, b = a.double().reshape(-1).cpu(), b.double().reshape(-1).cpu()
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.gpu
+def test_sigma_folded_into_the_attention_projection(K, dev):
+    """arch_ops.py:755-758 `x + sigma * conv1x1(attn_g, w)` as ONE convolution (sigma folded into the
+    kernel by Fn.ScaleWeightFn, x as the epilogue's residual) against the separate form
+    (convolution, then Fn.ScaledResidualFn): outputs and the gradients w.r.t. x, attn_g, w and sigma,
+    at sigma = 0 (the initial value: the output must be x exactly) and at sigma != 0.  The two forms
+    round at different points (sigma * w to bf16 vs the convolution's output to bf16): bf16 noise."""
+    from compare_gan_amd.hip import functional as Fn
+    g = _gen(77)
+    N, H, W, Cg, C = 3, 16, 16, 32, 64
+    _, x = rand_bf16((N, H, W, C), g)
+    _, a = rand_bf16((N, H, W, Cg), g)
+    w0 = (torch.randn(1, 1, Cg, C, generator=g) * 0.2).float()
+    _, dy = rand_bf16((N, H, W, C), g)
+    geom = K.geom_conv_same(N, H, W, Cg, C, 1, 1, 1, 1)
+    spec = Fn.ConvSpec(geom, transpose=False, slope_in=None, out_f32=False)
+    # ScaleWeightFn on its own: w_eff = sigma * w, d w = sigma * g, d sigma = <g, w>
+    wv = w0.to(dev).clone().requires_grad_(True)
+    sv = torch.tensor(0.37, device=dev, requires_grad=True)
+    weff = Fn.ScaleWeightFn.apply(wv, sv)
+    gw = torch.randn(w0.shape, generator=g).float().to(dev)
+    weff.backward(gw)
+    assert_close_f32(weff, (w0.double() * 0.37), "w_eff", 1e-6, 1e-7)
+    assert_close_f32(wv.grad, gw.double().cpu() * 0.37, "d w", 1e-6, 1e-7)
+    assert_close_f32(sv.grad.reshape(1), (gw.double().cpu() * w0.double()).sum().reshape(1), "d sigma", 1e-5, 1e-6)
+    for sigma in (0.0, 0.6):
+        outs = []
+        for folded in (True, False):
+            xs = x.to(dev).clone().requires_grad_(True)
+            as_ = a.to(dev).clone().requires_grad_(True)
+            ws = w0.to(dev).clone().requires_grad_(True)
+            ss = torch.tensor(sigma, device=dev, requires_grad=True)
+            if folded:
+                y = Fn.gconv(as_, Fn.ScaleWeightFn.apply(ws, ss), None, xs, None, None, spec, False, None)
+            else:
+                o = Fn.gconv(as_, ws, None, None, None, None, spec, False, None)
+                y = Fn.ScaledResidualFn.apply(xs, o, ss.reshape(1))
+            y.backward(dy.to(dev))
+            outs.append((y.detach(), xs.grad, as_.grad, ws.grad, ss.grad))
+        (yf, dxf, daf, dwf, dsf), (yu, dxu, dau, dwu, dsu) = outs
+        if sigma == 0.0:
+            assert torch.equal(yf, x.to(dev)) and torch.equal(yu, x.to(dev))
+            assert float(daf.float().abs().max()) == 0.0 and float(dwf.abs().max()) == 0.0
+        assert U_cos(yf, yu) >= 0.99999 and float((yf.float() - yu.float()).abs().max()) <= 0.05
+        assert torch.equal(dxf, dxu)                       # dy passes through both forms unchanged
+        if sigma != 0.0:
+            assert U_cos(daf, dau) >= 0.9999 and U_cos(dwf, dwu) >= 0.9999
+        assert abs(float(dsf) - float(dsu)) <= 5e-3 * max(1.0, abs(float(dsu))), (float(dsf), float(dsu))

@@ -56,7 +56,8 @@ def test_pmc_traffic_summary(tmp_path):
 
 def test_bench_reads_the_committed_traffic_summary():
     bench = _load(os.path.join(ROOT, "bench.py"), "bench_module")
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))["workloads"]
+    summary = json.load(open(bench.PMC_TRAFFIC_FILE))["workloads"]
+    assert os.path.basename(bench.PMC_TRAFFIC_FILE) == "r05_pmc_traffic.json"
     for family in ("hconv_kernel<128, *>", "hwgrad_kernel<*>", "sconv_kernel<*>", "swgrad_kernel<*>"):
         assert bench.pmc_traffic(family) == \
             summary["cifar"]["families"][family]["hbm_bytes_per_launch"] > 0
