@@ -779,7 +779,6 @@ class PooledHeadFn(torch.autograd.Function):
     ctx.w_shape = w.shape
     ctx.has_bias = bias is not None
     ctx.set_materialize_grads(False)
-    ctx.mark_non_differentiable()
     return logit, pooled
 
   @staticmethod
