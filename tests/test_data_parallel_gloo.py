@@ -184,7 +184,55 @@ def _body_per_replica_streams(rank):
   assert not torch.equal(parts[0], parts[1])
 
 
+def _body_reference_goldens(rank):
+  """The literal vectors the reference's own two-core tests hold, on two gloo ranks:
+  tpu/tpu_ops_test.py:44-65 (cross_replica_concat), :73-101 (cross_replica_mean, group_size None /
+  0 / 2), :103-128 (group_size 1 = identity), and architectures/arch_ops_tpu_test.py:30-52,112-133
+  (batch norm over 4 images split across two cores with cross-replica moments == the golden array)."""
+  import numpy as np
+  from compare_gan_amd.tpu import tpu_ops
+  from oracle import arch_ops as oops
+  # batch_parallel splits axis 0 over the cores: core r sees row r
+  x = torch.tensor([[3, 4], [1, 5]], dtype=torch.float32)[rank:rank + 1]
+  cat = tpu_ops.cross_replica_concat(x, rank, WORLD)
+  assert cat.tolist() == [[3.0, 4.0], [1.0, 5.0]]          # (the test concatenates both cores' copies)
+  inputs = torch.tensor([[0.55, 0.70, -1.29, 0.502], [0.57, 0.90, 1.290, 0.202]], dtype=torch.float32)
+  want = torch.tensor([0.56, 0.8, 0.0, 0.352], dtype=torch.float32)
+  for group_size in (None, 0, 2):
+    got = tpu_ops.cross_replica_mean(inputs[rank:rank + 1], group_size=group_size)
+    assert torch.allclose(got[0], want, rtol=1e-6, atol=1e-6), (group_size, got)
+  got = tpu_ops.cross_replica_mean(inputs[rank:rank + 1], group_size=1)
+  assert torch.equal(got, inputs[rank:rank + 1])
+  # arch_ops_tpu_test.py: 4 images of 2x1x3, two per core
+  x1 = [[[5, 7, 2]], [[5, 8, 8]]]
+  x2 = [[[1, 2, 0]], [[4, 0, 4]]]
+  x3 = [[[6, 2, 6]], [[5, 0, 5]]]
+  x4 = [[[2, 4, 2]], [[6, 4, 1]]]
+  images = torch.tensor([x1, x2, x3, x4], dtype=torch.float64)
+  expected = torch.tensor(
+      [[[[0.4375205, 1.30336881, -0.58830315]], [[0.4375205, 1.66291881, 1.76490951]]],
+       [[[-1.89592218, -0.49438119, -1.37270737]], [[-0.14584017, -1.21348119, 0.19610107]]],
+       [[[1.02088118, -0.49438119, 0.98050523]], [[0.4375205, -1.21348119, 0.58830321]]],
+       [[[-1.31256151, 0.22471881, -0.58830315]], [[1.02088118, 0.22471881, -0.98050523]]]],
+      dtype=torch.float64)
+
+  def sync(mean, mean_sq):
+    return tpu_ops.cross_replica_mean(mean), tpu_ops.cross_replica_mean(mean_sq)
+
+  vs = oops.VarStore()
+  mine = images[rank * 2:(rank + 1) * 2]
+  # (tf.layers' default epsilon in that test is 1e-3: arch_ops_tpu_test.py:117-121 calls
+  # standardize_batch with its default epsilon)
+  y = oops.standardize_batch(vs, mine, True, "", oops.BNConfig(0.999, 1e-3, cross_replica=sync))
+  assert torch.allclose(y, expected[rank * 2:(rank + 1) * 2], rtol=1e-5, atol=1e-5), (rank, y)
+  del np
+
+
 # ---- tests -----------------------------------------------------------------------------------------
+def test_reference_goldens_world2():
+  _run("_body_reference_goldens")
+
+
 def test_collectives_world2():
   _run("_body_collectives")
 
