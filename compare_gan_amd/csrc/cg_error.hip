@@ -14,7 +14,7 @@ void cg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int cg_abi_version(void) { return 1; }
+extern "C" int cg_abi_version(void) { return 5; }   // round 5: cgDeferCtx replaces cg_reduce_defer_*
 extern "C" const char* cg_last_error(void) { return g_err; }
 
 // ---- optional per-kernel-family timing with HIP events (bench.py's roofline leg) -------------

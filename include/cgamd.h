@@ -8,6 +8,10 @@
  *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*), re-entrant,
  *     allocation-free and synchronisation-free (hipGraph-capturable); scratch memory is supplied
  *     by the caller (`ws`, sized by the matching *_workspace_bytes query).
+ *   - state: none between calls.  What the library keeps is (a) the last error text per thread,
+ *     (b) the opt-in cg_prof_* instrumentation of bench.py (process-wide, off by default),
+ *     (c) dispatch switches read once from the environment (scripts/README.md).  Deferred
+ *     reductions live in a CALLER-owned cgDeferCtx that travels with every call that records.
  *   - return value: 0 = ok; negative = error (never throws, never aborts):
  *       CG_ERR_BAD_ARG (-1) null pointer / non-positive dim / inconsistent geometry,
  *       CG_ERR_UNSUPPORTED (-2) shape class the kernel family does not cover,
@@ -36,7 +40,7 @@ extern "C" {
 
 typedef void* cgStream; /* hipStream_t */
 
-/* Library/ABI version (bumped when a signature changes). */
+/* Library/ABI version (bumped when a signature changes; 5 = round 5). */
 int cg_abi_version(void);
 /* Human-readable description of the last error on this thread ("" if none). */
 const char* cg_last_error(void);
