@@ -20,7 +20,7 @@
 #                                   lib/libcgamd.so through CGAMD_LIB_PATH, alternating twice: bench.py --legs LEGS
 #   dp [TAG]                        CGAMD_FORCE_DP=1: the data-parallel path on a one-rank RCCL group
 #                                   (bucket, all-reduce captured in the hipGraph, bucketed overlap on / off)
-#   final [TAG]                     full + bench (all legs) + stats cifar / resnet128_dstep / fid + dp
+#   final [TAG]                     scripts/visit_final.sh: bench (all legs) FIRST, rocprofv3 stats, PMC passes, dp, suite LAST
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
 mkdir -p gpurun_out
@@ -116,10 +116,6 @@ case $task in
     echo "# shape $SHAPE kinds $KINDS settings $*" > gpurun_out/${TAG}_sq.txt
     python scripts/pmc_one.py agg /tmp/sq_$TAG >> gpurun_out/${TAG}_sq.txt; cat gpurun_out/${TAG}_sq.txt ;;
   dp) run_dp ${1:-dp} ;;
-  final) TAG=${1:-final}; run_full $TAG
-    timeout 1500 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-    leg_summary gpurun_out/${TAG}_bench.json resnet128_dstep
-    for w in cifar resnet128_dstep fid; do run_stats $w $TAG > /dev/null; done
-    run_dp $TAG ;;
+  final) exec bash "$R/scripts/visit_final.sh" "${1:-final}" ;;   # bench first, profiles, suite last
   *) echo "unknown task '$task' (see the header of scripts/gpu.sh)"; exit 2 ;;
 esac
