@@ -83,3 +83,26 @@ def test_gpu_launcher_is_valid_shell_and_documents_its_tasks():
     readme = open(os.path.join(ROOT, "scripts", "README.md")).read()
     for t in tasks:
         assert "`%s" % t in readme, t
+
+
+def test_graph_timeline_on_a_fabricated_trace(tmp_path):
+    """scripts/graph_timeline.py (the source of profiles/r05_cifar_graph_timeline.txt): a serial chain
+    with one gap and one overlapping pair -- span, sum of durations, union of busy intervals and idle
+    time come out as constructed; kernels behind the first calibration launch are ignored."""
+    import subprocess
+    rows = [("k_a", 1000, 2000), ("k_b", 2000, 3500), ("k_c", 3000, 4000),     # b and c overlap by 500
+            ("counter_add_kernel(long*, long)", 6000, 6500),                   # 2000 ns idle before it
+            ("calib_mfma_kernel(int, float*)", 9000, 99000), ("k_late", 99000, 99500)]
+    path = str(tmp_path / "trace.csv")
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        for name, s, e in rows:
+            w.writerow(["KERNEL_DISPATCH", name, s, e])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "graph_timeline.py"), path, "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    head = r.stdout.splitlines()[0]
+    assert "kernels 4 " in head and "span 5.5 us" in head and "sum of durations 4.0 us" in head
+    assert "union busy 3.5 us" in head and "idle 2.0 us" in head and "(1 gaps" in head
+    assert "calib" not in r.stdout and "k_late" not in r.stdout
