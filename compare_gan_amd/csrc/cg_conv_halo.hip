@@ -2193,12 +2193,13 @@ HWgradPlan hwgrad_plan(const cgConvGeom* g) {
   p.tiles_y = g->Ho / TH;
   p.nslices = g->N * p.tiles_y * p.tiles_x;
   p.tiles = cdiv(g->Ci, 64) * cdiv(g->Co, 64);
-  // one workgroup per CU: every split costs a K x Co fp32 partial.  Two per CU when each workgroup
-  // still walks >= 96 slices (BigGAN at 256 per GPU: 128^2 x 96 ... 16^2 x 768 on 512 images): the
-  // second resident workgroup hides the other's window staging and its partial-sum burst -- hwgrad
-  // 29.5 -> 23.6 ms per step there (603 -> 770 TFLOP/s), step 194.9 -> 188.7 ms; with fewer slices
-  // per workgroup the extra partials cost more than that buys (cifar 6.67 -> 7.15 ms, ResNet5
-  // D-step 5.12 -> 5.29 ms at 512 everywhere: profiles/r05_hwgrad_blocks_ab.txt).
+  // one workgroup per CU (150 KB of LDS each): every split costs a K x Co fp32 partial.  512
+  // workgroups -- two rounds of half-size work items -- when each still walks >= 96 slices (BigGAN at
+  // 256 per GPU: 128^2 x 96 ... 16^2 x 768 on 512 images): measured, hwgrad 29.5 -> 23.6 ms per step
+  // there (603 -> 770 TFLOP/s), step 194.9 -> 188.7 ms -- finer items even out the tail of a launch
+  // whose (ci, co) tiles are unevenly filled (96 = 64 + 32 channels); with fewer slices per workgroup
+  // the extra partials cost more than that buys (cifar 6.67 -> 7.15 ms, ResNet5 D-step 5.12 ->
+  // 5.29 ms at 512 everywhere: profiles/r05_hwgrad_blocks_ab.txt).
   // CGAMD_HWGRAD_BLOCKS > 0 fixes the target.
   static const int forced = hc_env("CGAMD_HWGRAD_BLOCKS", 0);
   const int target = forced > 0 ? forced : ((int64_t)p.nslices * p.tiles >= 512 * 96 ? 512 : 256);

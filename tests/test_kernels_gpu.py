@@ -1289,8 +1289,8 @@ CONV_VARIANT_ENVS = [
     # small-map kernels (cg_conv_small.hip) wherever their geometry fits / nowhere
     ("small_all", {"CGAMD_SCONV": "2", "CGAMD_SWGRAD": "2"}),
     ("no_small", {"CGAMD_SCONV": "0", "CGAMD_SWGRAD": "0"}),
-    # two weight-gradient workgroups per CU (the policy of the large-batch layers: hwgrad_plan)
-    ("hwgrad_two_per_cu", {"CGAMD_HWGRAD_BLOCKS": "512", "CGAMD_HWGRAD_MIN": "1"}),
+    # 512 weight-gradient workgroups (the policy of the large-batch layers: hwgrad_plan)
+    ("hwgrad_512_blocks", {"CGAMD_HWGRAD_BLOCKS": "512", "CGAMD_HWGRAD_MIN": "1"}),
 ]
 
 
