@@ -304,6 +304,41 @@ def test_weight_gradient_consumers_are_classified():
   assert Fn.SpectralNormBatchFn.__name__.startswith("SpectralNorm")
 
 
+def test_deferred_wgrads_scopes_on_the_host():
+  """Fn.deferred_wgrads (host state machine only, no device): scopes nest and restore their flags,
+  reductions are recorded only while the scope says so, an inner non-deferring scope flushes first,
+  an exception drops what was recorded, CPU tensors never get a context, the scaled-weight Function
+  of the attention block is classified as a reader of its weight gradient inside the backward pass,
+  and ops.twice_differentiable() nests."""
+  from compare_gan_amd.architectures import arch_ops as ops
+  from compare_gan_amd.hip import functional as Fn
+  D = Fn._DEFER   # pylint: disable=protected-access
+  assert (D["on"], D["reduce"]) == (False, False)
+  t = torch.zeros(2)
+  with Fn.deferred_wgrads(True):
+    assert D["on"] and D["reduce"] == (Fn._DEFER_REDUCE and not Fn._WGRAD["enabled"])   # pylint: disable=protected-access
+    assert Fn._reduce_ctx(t) is None                      # CPU tensor: no context
+    with Fn.deferred_wgrads(False):
+      assert (D["on"], D["reduce"]) == (False, False)
+    assert D["on"]                                        # restored
+    D["wptrs"].add(123)
+  assert (D["on"], D["reduce"]) == (False, False) and not D["wptrs"] and not D["jobs"]
+  with pytest.raises(RuntimeError):
+    with Fn.deferred_wgrads(True):
+      D["jobs"].append("never run")
+      raise RuntimeError("backward failed")
+  assert (D["on"], D["reduce"]) == (False, False) and not D["jobs"]
+  w = torch.randn(1, 1, 8, 4, requires_grad=True)
+  assert not Fn._weight_grad_read_late(w * torch.tensor(0.5))   # what ScaleWeightFn's output looks like
+  assert not ops._DOUBLE_BWD[0]                                 # pylint: disable=protected-access
+  with ops.twice_differentiable():
+    assert ops._DOUBLE_BWD[0]
+    with ops.twice_differentiable():
+      assert ops._DOUBLE_BWD[0]
+    assert ops._DOUBLE_BWD[0]
+  assert not ops._DOUBLE_BWD[0]
+
+
 def test_product_refuses_cpu_tensors():
   from compare_gan_amd.hip import kernels as K
   with pytest.raises(ValueError, match="no CPU fallback"):
