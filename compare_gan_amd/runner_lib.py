@@ -99,19 +99,40 @@ class TaskManager(object):
     with open(path) as f:
       return set(r["checkpoint_path"] for r in csv.DictReader(f))
 
-  def unevaluated_checkpoints(self, timeout=0, eval_every_steps=None):
-    """Checkpoints in model_dir without a scores.csv row (runner_lib.py:137-180)."""
-    del timeout
-    done = self.get_checkpoints_with_results()
-    ckpts = sorted((p for p in os.listdir(self.model_dir)
-                    if p.startswith("model.ckpt-") and p.endswith(".pt")), key=_step_of)
-    for name in ckpts:
-      path = os.path.join(self.model_dir, name)
-      if path in done:
+  def _checkpoints(self):
+    """Every checkpoint of model_dir, ascending by step: this package's `model.ckpt-<step>.pt` and
+    the reference's TF-1 bundles `model.ckpt-<step>` (`.index` + `.data-*`), the native file first
+    when both exist for a step."""
+    found = {}
+    for p in os.listdir(self.model_dir):
+      if not p.startswith("model.ckpt-"):
         continue
-      if eval_every_steps and _step_of(path) % eval_every_steps:
+      if p.endswith(".pt"):
+        found[_step_of(p)] = os.path.join(self.model_dir, p)
+      elif p.endswith(".index"):
+        found.setdefault(_step_of(p[:-len(".index")]), os.path.join(self.model_dir, p[:-len(".index")]))
+    return [found[k] for k in sorted(found)]
+
+  def unevaluated_checkpoints(self, timeout=0, eval_every_steps=None, poll_seconds=60):
+    """Generator for checkpoints without evaluation results (runner_lib.py:137-180): ascending by
+    step; with eval_every_steps only steps > 0 divisible by it; with timeout > 0 it keeps polling
+    the directory (every poll_seconds) until no new checkpoint has appeared for `timeout` seconds or
+    training is marked done -- the continuous-evaluation schedule."""
+    evaluated = set(self.get_checkpoints_with_results())
+    last_eval = time.time()
+    while True:
+      todo = [p for p in self._checkpoints() if p not in evaluated]
+      if eval_every_steps:
+        todo = [p for p in todo if _step_of(p) > 0 and _step_of(p) % eval_every_steps == 0]
+      for path in todo:
+        yield path
+      if todo:
+        evaluated |= set(todo)
+        last_eval = time.time()
         continue
-      yield path
+      if time.time() - last_eval > timeout or self.is_training_done():
+        break
+      time.sleep(poll_seconds)
 
 
 class TaskManagerWithCsvResults(TaskManager):
@@ -124,6 +145,10 @@ class TaskManagerWithCsvResults(TaskManager):
 
   def _score_path(self):
     return self._score_file
+
+
+_CONTINUOUS_EVAL_TIMEOUT_S = 24 * 3600    # runner_lib.py:341-343
+_CONTINUOUS_EVAL_POLL_S = 60              # runner_lib.py:179
 
 
 def _step_of(checkpoint_path):
@@ -202,8 +227,11 @@ def _run_eval(gan, checkpoint_path, task_manager, options, num_averaging_runs, d
   from compare_gan_amd.metrics import inception_score as inception_score_lib
   del options
   eval_tasks = [inception_score_lib.InceptionScoreTask(), fid_score_lib.FIDScoreTask()]
-  sd = torch.load(checkpoint_path, map_location=device)
-  gan.load_state_dict(sd)
+  if checkpoint_path.endswith(".pt"):
+    gan.load_state_dict(torch.load(checkpoint_path, map_location=device))
+  else:     # a TF-1 bundle prefix written by the reference (modular_gan.py:266-285 restores those)
+    from compare_gan_amd import tf_checkpoint
+    tf_checkpoint.import_tf_checkpoint(gan, checkpoint_path)
   from compare_gan_amd.tpu import tpu_ops
   in_context = tpu_ops._STATE["enabled"]  # pylint: disable=protected-access
   # no collectives INSIDE the networks (each rank runs different evaluation batches on the same
@@ -233,9 +261,6 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
   del use_tpu
   if schedule not in {"train", "eval_after_train", "continuous_eval"}:
     raise ValueError("Schedule {} not supported.".format(schedule))
-  if schedule == "continuous_eval":
-    raise NotImplementedError("continuous_eval polls a checkpoint directory written by another "
-                              "job; run eval_after_train or call _run_eval per checkpoint.")
   seed = run_config.tf_random_seed if run_config.tf_random_seed is not None else 0
   np.random.seed(seed)                                            # runner_lib.py:303-305
   dataset = datasets.get_dataset()
@@ -249,55 +274,63 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
         options["batch_size"], world))
   bsz = options["batch_size"] // world              # runner_lib.py:84-85
   gan.build(batch_size=bsz, device=device, seed=seed)
-  start = 0
-  # rank 0 decides where to resume and tells the others: ranks looking at the directory on their own
-  # could disagree while rank 0 writes checkpoint 0
-  ckpt = _broadcast_from_rank0(
-      latest_checkpoint(run_config.model_dir) if tpu_ops.replica_id() == 0 else None)
-  if ckpt is not None:                              # README.md:93-94 resume
-    gan.load_state_dict(torch.load(ckpt, map_location=device))
-    start = int(gan.global_step.item())
-  else:
-    # a model_dir written by the REFERENCE (TF-1 tensor bundles `model.ckpt-<step>.index` +
-    # `.data-*`, same variable names: SURVEY App. D): continue from its newest checkpoint
-    tf_ckpt = _broadcast_from_rank0(_latest_tf_checkpoint(run_config.model_dir)
-                                    if tpu_ops.replica_id() == 0 else None)
-    if tf_ckpt is not None:
-      from compare_gan_amd import tf_checkpoint
-      tf_checkpoint.import_tf_checkpoint(gan, tf_ckpt)
+  if schedule in {"train", "eval_after_train"}:
+    start = 0
+    # rank 0 decides where to resume and tells the others: ranks looking at the directory on their own
+    # could disagree while rank 0 writes checkpoint 0
+    ckpt = _broadcast_from_rank0(
+        latest_checkpoint(run_config.model_dir) if tpu_ops.replica_id() == 0 else None)
+    if ckpt is not None:                              # README.md:93-94 resume
+      gan.load_state_dict(torch.load(ckpt, map_location=device))
       start = int(gan.global_step.item())
-  num_sub = options.get("disc_iters", 1) + 1
-  batches = dataset.train_batches(bsz * num_sub, seed=dataset._seed + tpu_ops.replica_id())  # pylint: disable=protected-access
-  if start == 0 and tpu_ops.replica_id() == 0:
-    save_checkpoint(gan, run_config.model_dir, 0)
-  _barrier()
-  t0, last = time.time(), start
-  for step in range(start, options["training_steps"]):
-    images, labels = next(batches)
-    out = gan.train_step(torch.from_numpy(images).to(gan.device),
-                         torch.from_numpy(labels).to(gan.device))
-    done = step + 1
-    if log_every and done % log_every == 0:
-      torch.cuda.synchronize()
-      dt = time.time() - t0
-      print("%.1f%% @%d, %.2f steps/s, %.1f img/s, d_loss %.4f g_loss %.4f" % (
-          100.0 * done / options["training_steps"], done, (done - last) / dt,
-          (done - last) * bsz * num_sub * world / dt, float(out["d_losses"][0]),
-          float(out["g_loss"])))
-      t0, last = time.time(), done
-    if tpu_ops.replica_id() == 0 and (done % run_config.save_checkpoints_steps == 0 or
-                                      done == options["training_steps"]):
-      save_checkpoint(gan, run_config.model_dir, done)
-  if tpu_ops.replica_id() == 0:
-    task_manager.mark_training_done()
-  if schedule == "eval_after_train":
+    else:
+      # a model_dir written by the REFERENCE (TF-1 tensor bundles `model.ckpt-<step>.index` +
+      # `.data-*`, same variable names: SURVEY App. D): continue from its newest checkpoint
+      tf_ckpt = _broadcast_from_rank0(_latest_tf_checkpoint(run_config.model_dir)
+                                      if tpu_ops.replica_id() == 0 else None)
+      if tf_ckpt is not None:
+        from compare_gan_amd import tf_checkpoint
+        tf_checkpoint.import_tf_checkpoint(gan, tf_ckpt)
+        start = int(gan.global_step.item())
+    num_sub = options.get("disc_iters", 1) + 1
+    batches = dataset.train_batches(bsz * num_sub, seed=dataset._seed + tpu_ops.replica_id())  # pylint: disable=protected-access
+    if start == 0 and tpu_ops.replica_id() == 0:
+      save_checkpoint(gan, run_config.model_dir, 0)
+    _barrier()
+    t0, last = time.time(), start
+    for step in range(start, options["training_steps"]):
+      images, labels = next(batches)
+      out = gan.train_step(torch.from_numpy(images).to(gan.device),
+                           torch.from_numpy(labels).to(gan.device))
+      done = step + 1
+      if log_every and done % log_every == 0:
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        print("%.1f%% @%d, %.2f steps/s, %.1f img/s, d_loss %.4f g_loss %.4f" % (
+            100.0 * done / options["training_steps"], done, (done - last) / dt,
+            (done - last) * bsz * num_sub * world / dt, float(out["d_losses"][0]),
+            float(out["g_loss"])))
+        t0, last = time.time(), done
+      if tpu_ops.replica_id() == 0 and (done % run_config.save_checkpoints_steps == 0 or
+                                        done == options["training_steps"]):
+        save_checkpoint(gan, run_config.model_dir, done)
+    if tpu_ops.replica_id() == 0:
+      task_manager.mark_training_done()
+  if schedule in {"eval_after_train", "continuous_eval"}:
     _barrier()  # the last checkpoint and the training-done marker are on disk
-    # rank 0 picks the checkpoints; every rank evaluates its share of each one's batches
-    todo = _broadcast_from_rank0(
-        list(task_manager.unevaluated_checkpoints(
-            eval_every_steps=eval_every_steps if eval_every_steps > 0 else None))
-        if tpu_ops.replica_id() == 0 else None)
-    for checkpoint_path in todo:
+    # rank 0 looks at the directory (continuous_eval: keeps polling it, up to 24 hours between
+    # checkpoints, runner_lib.py:340-343) and hands every rank the next checkpoint; every rank
+    # evaluates its share of that checkpoint's batches (eval_shard.py)
+    every = eval_every_steps if eval_every_steps and eval_every_steps > 0 else None
+    pending = None
+    if tpu_ops.replica_id() == 0:
+      pending = iter(task_manager.unevaluated_checkpoints(
+          timeout=_CONTINUOUS_EVAL_TIMEOUT_S if schedule == "continuous_eval" else 0,
+          eval_every_steps=every, poll_seconds=_CONTINUOUS_EVAL_POLL_S))
+    while True:
+      checkpoint_path = _broadcast_from_rank0(next(pending, None) if pending is not None else None)
+      if checkpoint_path is None:
+        break
       _run_eval(gan, checkpoint_path, task_manager, options, num_eval_averaging_runs, device)
   _barrier()    # nobody tears the process group down while another rank still works
   return gan
