@@ -26,7 +26,38 @@ def parse_args(argv=None):
   p.add_argument("--num_eval_averaging_runs", type=int, default=3)
   p.add_argument("--eval_every_steps", type=int, default=5000)
   p.add_argument("--log_every", type=int, default=100)
+  # the reference's data flags (datasets.py:46-63) and --use_tpu (main.py:66), so that its command
+  # lines run unchanged
+  p.add_argument("--tfds_data_dir", default=None,
+                 help="TFDS data directory (record shards) or <dir>/<dataset>/{train,test}.npz; "
+                      "default: CGAMD_DATA_DIR, else synthetic data.")
+  p.add_argument("--data_fake_dataset", type=_flag_bool, nargs="?", const=True, default=None,
+                 help="True: synthetic data even if a data directory is given (the default here "
+                      "when no directory is set: there is no network to fetch datasets).")
+  p.add_argument("--data_shuffle_buffer_size", type=int, default=10000)
+  p.add_argument("--data_reading_num_threads", type=int, default=64, help="accepted, unused")
+  p.add_argument("--use_tpu", type=_flag_bool, nargs="?", const=True, default=None,
+                 help="accepted, ignored: the accelerator path (unrolled steps) is always taken")
   return p.parse_args(argv)
+
+
+def _flag_bool(text):
+  """absl's boolean flag syntax: --flag, --flag=true / false / 1 / 0."""
+  if text.lower() in ("1", "true", "t", "yes", "y"):
+    return True
+  if text.lower() in ("0", "false", "f", "no", "n"):
+    return False
+  raise argparse.ArgumentTypeError("not a boolean: %r" % text)
+
+
+def configure_data(args):
+  """--tfds_data_dir / --data_fake_dataset / --data_shuffle_buffer_size -> datasets.use_data_dir."""
+  from compare_gan_amd import datasets
+  path = args.tfds_data_dir or os.environ.get("CGAMD_DATA_DIR") or None
+  if args.data_fake_dataset:
+    path = None
+  datasets.use_data_dir(path, shuffle_buffer_size=args.data_shuffle_buffer_size)
+  return path
 
 
 def main(argv=None):
@@ -39,6 +70,7 @@ def main(argv=None):
   from compare_gan_amd.tpu import tpu_ops
   tpu_ops.init_replicas(device)
   gin.parse_config_files_and_bindings(args.gin_config, args.gin_bindings)
+  configure_data(args)
   run_config = runner_lib.RunConfig(model_dir=args.model_dir)
   task_manager = runner_lib.TaskManagerWithCsvResults(
       model_dir=args.model_dir, score_file=os.path.join(args.model_dir, args.score_filename))

@@ -224,3 +224,27 @@ def test_continuous_eval_schedule(dev, tmp_path, monkeypatch):
                                  eval_every_steps=1, log_every=0)
     with open(os.path.join(d, "scores.csv")) as f:
         assert len(list(csv.DictReader(f))) == 3
+
+
+def test_main_accepts_the_reference_flags():
+    """compare_gan/main.py:45-66 and datasets.py:46-63: the reference's command lines parse
+    unchanged -- absl boolean syntax included -- and the data flags select the data source."""
+    from compare_gan_amd import datasets, main
+    a = main.parse_args(["--model_dir", "/tmp/x", "--schedule", "continuous_eval",
+                         "--gin_config", "a.gin", "--gin_config", "b.gin",
+                         "--gin_bindings", "options.z_dim = 64", "--score_filename", "s.csv",
+                         "--num_eval_averaging_runs", "1", "--eval_every_steps", "2500",
+                         "--tfds_data_dir", "/data", "--data_fake_dataset=false", "--use_tpu",
+                         "--data_shuffle_buffer_size", "7", "--data_reading_num_threads", "8"])
+    assert a.gin_config == ["a.gin", "b.gin"] and a.schedule == "continuous_eval"
+    assert a.data_fake_dataset is False and a.use_tpu is True and a.eval_every_steps == 2500
+    saved = dict(datasets._SOURCE)     # pylint: disable=protected-access
+    try:
+        assert main.configure_data(a) == "/data"
+        assert datasets._SOURCE == {"dir": "/data", "shuffle_buffer": 7}     # pylint: disable=protected-access
+        b = main.parse_args(["--model_dir", "/tmp/x", "--tfds_data_dir", "/data", "--data_fake_dataset"])
+        assert main.configure_data(b) is None and datasets._SOURCE["dir"] is None   # pylint: disable=protected-access
+    finally:
+        datasets._SOURCE.update(saved)     # pylint: disable=protected-access
+    with pytest.raises(SystemExit):
+        main.parse_args(["--model_dir", "/tmp/x", "--use_tpu=maybe"])
