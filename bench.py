@@ -396,6 +396,12 @@ def main():
         result["calibration"] = {
             "mfma_bf16_tflops": round(calib["mfma_bf16_tflops"], 1),
             "hbm_copy_gbs": round(calib["hbm_copy_gbs"], 1),
+            # DERIVED, not read: 1024 SIMDs x 1024 FLOP per cycle (one 32x32x16 MFMA per 32 cycles
+            # and SIMD) -> the shader clock at which back-to-back MFMA issue gives this rate.  The
+            # 2.5 PFLOP/s datasheet peak is that arithmetic at 2.4 GHz; the sysfs clock table of the
+            # pool's boxes does not follow the load (it reads 105-157 MHz throughout), so the
+            # sustained clock cannot be read directly
+            "mfma_equivalent_clock_mhz": round(calib["mfma_bf16_tflops"] * 1e12 / (1024 * 1024) / 1e6, 0),
             "how": "pure v_mfma_f32_32x32x16_bf16 loop on random operands for %.0f ms (2048 "
                    "workgroups of 4 waves, 8 independent accumulators) and a float4 copy of %d MiB "
                    "(read + write bytes), HIP events, same process" % (calib["mfma_ms"], calib["copy_mb"]),
