@@ -130,7 +130,11 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  // waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically): they are the two
+  // CHANNEL halves of one pixel quarter, so that a channel half with fewer real output channels
+  // (Co = 96, 192: half of every second 64-channel group is empty) halves the matrix work of EVERY
+  // SIMD instead of idling two of the four
+  const int wm = wave & 3, wn = wave >> 2;
   const int frow = lane & 31, half = lane >> 5;
   HC_STAMP(0);
 #ifdef CG_CONV_TIMING
@@ -337,6 +341,10 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     bko[kk] = ((NARROW ? 0 : wn * (BN / 2)) + frow) * 128 +
               ((((NARROW ? 2 * wn + kk : kk) * 2 + half) ^ ((frow >> 1) & 7)) << 4);
 
+  // 32-channel tiles of this wave with real output channels (wave-uniform; Co % 8 == 0)
+  const int cleft = a.Co - n0 - wn * (BN / 2);
+  const int jn = NARROW ? 1 : (cleft <= 0 ? 0 : (cleft >= 32 * TN ? TN : (cleft + 31) >> 5));
+
   f32x16_t acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -348,7 +356,12 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
   // ---- main loop: K-slice = (channel block, tap); the halo is staged once per channel block ----
   HC_STAMP(1);
   int tap = 0, cb = 0, ri = 0, si = 0;
-  for (int it = 0; it < nk; ++it) {
+  // one K-slice.  JN: 32-channel MFMA tiles of this wave that hold real output channels; NKQ:
+  // 16-channel k-steps of the slice that hold real input channels (2 in the ragged last block of
+  // Ci % 64 == 32).  Both are chosen OUTSIDE the loop (run_slices below): a wave-uniform branch
+  // around the MFMAs inside it makes hipcc copy the accumulator tuples at the merge points and
+  // spill (measured: 10-20x slower).
+  auto slice = [&](int it, auto jn_c, auto nkq_c) {
     // this wave's pieces of slice `it` (and of the halo, on a block's first tap) have landed; after
     // the barrier so have everybody's, and every wave is done with the weight slot restaged below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,24 +408,29 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       aswz[i] = MI ? ((((hx0[i] + si) >> 1) & 3) | (((hy0[i] + ri) & 1) << 2))
                    : (((hx0[i] + si) >> 1) & 7);
     }
+    {
+      constexpr int JN = decltype(jn_c)::value, NKQ = decltype(nkq_c)::value;
 #pragma unroll
-    for (int kq = 0; kq < (NARROW ? 2 : 4); ++kq) {
-      const int kk = kq;                             // index of bko[]
-      const int ka = NARROW ? 2 * wn + kq : kq;      // 16-channel step within the slice
-      bf16x8_t af[2], bfr[TN];
+      for (int kq = 0; kq < NKQ; ++kq) {
+        const int kk = kq;                             // index of bko[]
+        const int ka = NARROW ? 2 * wn + kq : kq;      // 16-channel step within the slice
+        bf16x8_t af[2], bfr[JN > 0 ? JN : 1];
+        if constexpr (JN > 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(smem + abase[i] +
-                                                   (((ka * 2 + half) ^ aswz[i]) << 4));
+          for (int i = 0; i < 2; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8_t*>(smem + abase[i] +
+                                                       (((ka * 2 + half) ^ aswz[i]) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < JN; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk] + j * 32 * 128);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk] + j * 32 * 128);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (ntap == 0 && ncb < a.cblocks) {
       // channel block finished: every wave is done with the halo image before it is overwritten
@@ -424,7 +442,26 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     cb = ncb;
     ri = nri;
     si = nsi;
-  }
+  };
+  using HI0 = std::integral_constant<int, 0>;
+  using HI1 = std::integral_constant<int, 1>;
+  using HI2 = std::integral_constant<int, 2>;
+  using HI4 = std::integral_constant<int, 4>;
+  using HITN = std::integral_constant<int, TN>;
+  // the slices of the ragged last channel block (if any) are the last `ntaps` ones
+  const int nk_full = (!NARROW && ragged_ci) ? nk - ntaps : nk;
+  auto run_slices = [&](auto jn_c) {
+    int it = 0;
+    if constexpr (NARROW) {
+      for (; it < nk; ++it) slice(it, HI1(), HI2());
+    } else {
+      for (; it < nk_full; ++it) slice(it, jn_c, HI4());
+      for (; it < nk; ++it) slice(it, jn_c, HI2());
+    }
+  };
+  if (jn == TN) run_slices(HITN());
+  else if (TN == 2 && jn == 1) run_slices(HI1());
+  else run_slices(HI0());
 
   HC_STAMP(3);
   // ---- epilogue: every wave stages its own 64-pixel x WCO-channel accumulator tile through a
@@ -647,8 +684,8 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     if (lane < G8) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        sreg[(wave * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
-        sreg[(wave * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
+        sreg[((wm * 2 + wn) * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
+        sreg[((wm * 2 + wn) * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
       }
     }
     __syncthreads();
@@ -1077,8 +1114,14 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[ph][j][v] = 0.f;
 
+  const bool have_j1 = a.Co - n0 > 32;   // workgroup-uniform
   int slot = 0;
-  for (int cb = 0; cb < a.cblocks; ++cb) {
+  // one channel block (nine taps).  J1: the tile's second 32 output channels exist (Co = 96: not in
+  // the second tile); NKK: k-steps with real input channels (2 in the ragged last block of
+  // Ci % 64 == 32); both chosen outside the loop (no branch around the MFMAs inside it)
+  auto block = [&](int cb, auto j1_c, auto nkk_c) {
+    constexpr bool J1 = decltype(j1_c)::value != 0;
+    constexpr int NKK = decltype(nkk_c)::value;
     const unsigned char* Hb = smem + (cb & 1) * HU_HB;
     const bool next_cb = cb + 1 < a.cblocks;
 #pragma unroll
@@ -1110,18 +1153,28 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
       const int dy = tr == 2 ? 1 : 0, dx = ts == 2 ? 1 : 0;
       const unsigned char* Bs = smem + 2 * HU_HB + slot * HU_SLAB;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < NKK; ++kk) {
         bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Hb + aoff[dy][dx] +
                                                          (((kk * 2 + half) ^ aswz[dx]) << 4));
         if (RELU) af = hc_relu(af);
         const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk]);
-        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk] + 32 * 128);
         acc[ph][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, af, acc[ph][0], 0, 0, 0);
-        acc[ph][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, af, acc[ph][1], 0, 0, 0);
+        if constexpr (J1) {
+          const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + bko[kk] + 32 * 128);
+          acc[ph][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, af, acc[ph][1], 0, 0, 0);
+        }
       }
       slot = slot + 1 == HU_RING ? 0 : slot + 1;
     }
-  }
+  };
+  auto run_blocks = [&](auto j1_c) {
+    const int nfull = ragged_ci ? a.cblocks - 1 : a.cblocks;
+    int cb = 0;
+    for (; cb < nfull; ++cb) block(cb, j1_c, std::integral_constant<int, 4>());
+    for (; cb < a.cblocks; ++cb) block(cb, j1_c, std::integral_constant<int, 2>());
+  };
+  if (have_j1) run_blocks(std::integral_constant<int, 1>());
+  else run_blocks(std::integral_constant<int, 0>());
 
   // ---- epilogue: per-wave staging (32 pixels x 64 channels fp32), 8 lanes finish one pixel's 64
   // channels: 128-byte rows ----
@@ -1283,10 +1336,24 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tg = wave >> 2, wk = (wave >> 1) & 1, wn = wave & 1;
   const int cb = (int)fdiv((uint32_t)blockIdx.x, a.dNt);
   const int nt = blockIdx.x - cb * a.ntiles;
   const int c0 = nt * 64;
+  // wave roles: tap group tg, channel half wk, out-channel half wn.  Waves w and w + 4 share a SIMD
+  // (cyclic placement), so the role bit that is EMPTY in this workgroup -- the second channel half of
+  // a ragged last channel block (Ci = 96: 64 + 32), the second out-channel half of a ragged last
+  // out-channel tile -- is taken from wave >> 2: every SIMD then carries one working and one idle
+  // wave and the block's matrix work halves, instead of two SIMDs idling beside two full ones
+  const bool ragged_k = cb * 64 + 32 >= a.Ci, ragged_n = c0 + 32 >= a.Co;   // workgroup-uniform
+  int tg, wk, wn;
+  if (ragged_k) {
+    wk = wave >> 2; tg = (wave >> 1) & 1; wn = wave & 1;
+  } else if (ragged_n) {
+    wn = wave >> 2; tg = (wave >> 1) & 1; wk = wave & 1;
+  } else {
+    tg = wave >> 2; wk = (wave >> 1) & 1; wn = wave & 1;
+  }
+  const bool idle = (ragged_k && wk == 1) || (ragged_n && wn == 1);   // wave-uniform
 
   // ---- staging descriptors (relative to the tile's origin; the origin goes into the descriptor
   // base).  Halo piece p = wave + 8 j: row 8 p + (lane >> 3); 16-byte chunk c of row r lives at chunk
@@ -1411,7 +1478,10 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
   if (sbeg < send) stage(0, sbeg);
 
   hc_lds_ptr lds = (hc_lds_ptr)smem;
-  for (int sl = sbeg; sl < send; ++sl) {
+  // one 256-pixel slice; ROLE 0 / 1: tap group of a working wave, 2: idle wave (stages only).  The
+  // role is chosen outside the loop: a branch around the MFMAs inside it costs accumulator copies
+  auto slice = [&](int sl, auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
     const int buf = (sl - sbeg) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (RELU) {
@@ -1462,8 +1532,23 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(HWgradArgs a) {
         }
       }
     };
-    if (tg == 0) compute(std::integral_constant<int, 0>());
-    else compute(std::integral_constant<int, 1>());
+    if constexpr (ROLE == 2) {   // no operand of this wave's tiles is real: it only stages its share
+      if constexpr (ASMDMA) {
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < NPIECE; ++i) stage_piece(nctx, i);
+        }
+      }
+    } else {
+      compute(role_c);
+    }
+  };
+  if (idle) {
+    for (int sl = sbeg; sl < send; ++sl) slice(sl, std::integral_constant<int, 2>());
+  } else if (tg == 0) {
+    for (int sl = sbeg; sl < send; ++sl) slice(sl, std::integral_constant<int, 0>());
+  } else {
+    for (int sl = sbeg; sl < send; ++sl) slice(sl, std::integral_constant<int, 1>());
   }
 
   // ---- write-out: acc[tt][v] = dw[tap][ci = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)][co = lane & 31]

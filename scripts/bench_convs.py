@@ -1,5 +1,6 @@
 """GPU-bound timing of individual convolution launches (hipGraph of R repeats, so host launch cost
-is excluded).  usage: python scripts/bench_convs.py [cifar|resnet128]"""
+is excluded).  usage: python scripts/bench_convs.py [cifar|resnet128|...|"N,H,W,Ci,Co,k,s,up,relu;..."]
+BENCH_KINDS=fwd,dgrad,wgrad selects the columns."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -62,7 +63,9 @@ SHAPES = {
         (64, 32, 32, 256, 128, 3, 1, 2, 0), (64, 128, 128, 64, 64, 3, 1, 1, 0),
         (128, 128, 128, 3, 64, 3, 1, 1, 1), (64, 128, 128, 64, 3, 3, 1, 1, 0),
     ],
-}[which]
+}.get(which)
+if SHAPES is None:   # literal list: "N,H,W,Ci,Co,k,s,up,relu;N,H,..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in which.split(";") if t]
 R = 20
 
 
@@ -94,9 +97,10 @@ for (N, H, W, Ci, Co, k, s, up, relu) in SHAPES:
     bt_f, bt_b = K.weight_prep(w, want_fwd=True, want_bwd=True)
     fl = 2.0 * N * geom.Ho * geom.Wo * k * k * Ci * Co / (up * up)
     gi = x if relu else None
-    t_f = timed(lambda: K.gconv(geom, x, bt_f, bias=bias, gate_in=gi, slope_in=0.0))
-    t_d = timed(lambda: K.gconv(K.geom_adjoint(geom), dy, bt_b, gate_out=gi, slope_out=0.0))
-    t_w = 0.0 if os.environ.get("BENCH_NO_WGRAD") else timed(
+    kinds = os.environ.get("BENCH_KINDS", "fwd,dgrad,wgrad").split(",")
+    t_f = timed(lambda: K.gconv(geom, x, bt_f, bias=bias, gate_in=gi, slope_in=0.0)) if "fwd" in kinds else 1e-9
+    t_d = timed(lambda: K.gconv(K.geom_adjoint(geom), dy, bt_b, gate_out=gi, slope_out=0.0)) if "dgrad" in kinds else 1e-9
+    t_w = 1e-9 if (os.environ.get("BENCH_NO_WGRAD") or "wgrad" not in kinds) else timed(
         lambda: K.gwgrad(geom, x, dy, gate_in=gi, slope_in=0.0, want_dbias=True))
     print("%-44s %6.1f|%4.0f %6.1f|%4.0f %6.1f|%4.0f" % (
         ",".join(map(str, (N, H, W, Ci, Co, k, s, up, relu))), t_f, fl / t_f / 1e6, t_d, fl / t_d / 1e6,

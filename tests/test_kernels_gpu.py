@@ -207,6 +207,13 @@ FULL_SIZE_CASES = [
     ("mi_ragged_n98", 98, 8, 8, 256, 512),
     ("cifar_G_rgb_out", 64, 32, 32, 256, 3),
     ("resnet128_G_rgb_out", 32, 128, 128, 64, 3),
+    # BigGAN at ch = 96 (resnet_biggan.py:99-151, 344-425): channel counts of 64 k + 32 -- the second
+    # channel half of the last 64-channel group is empty and its waves skip their matrix work
+    # (hconv_kernel's jn / half_k, hwgrad_kernel's idle roles)
+    ("biggan_128x128_c96", 24, 128, 128, 96, 96),
+    ("biggan_64x64_c96_c192", 24, 64, 64, 96, 192),
+    ("biggan_64x64_c192", 24, 64, 64, 192, 192),
+    ("biggan_32x32_c192_c96", 40, 32, 32, 192, 96),
 ]
 
 
