@@ -57,6 +57,13 @@ __device__ __forceinline__ void unpack8_bf16(uint4 q, float* v) {
   v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
 }
 
+typedef __attribute__((ext_vector_type(4))) float cg_f32x4_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 cg_bf16x4_t;
+__device__ __forceinline__ uint2 pack4_bf16(const float* v) {
+  const cg_f32x4_t f = {v[0], v[1], v[2], v[3]};
+  return __builtin_bit_cast(uint2, __builtin_convertvector(f, cg_bf16x4_t));
+}
+
 struct __attribute__((aligned(16))) bf16x8_raw {
   bf16_t v[8];
 };

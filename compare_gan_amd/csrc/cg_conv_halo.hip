@@ -90,9 +90,28 @@ __device__ __forceinline__ int hc_xcd_remap(int b, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// 4-byte LDS-DMA from a per-lane global address: lane l lands at lds_wave_base + 4 l
+__device__ __forceinline__ void hc_glds4(const float* gptr, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (lds_void_t*)lds_wave_base, 4, 0, 0);
+}
+
 __device__ __forceinline__ void hc_dma16(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff,
                                          unsigned char* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// x of the lane `r` positions to the left within its 16-lane row (DPP row_ror:r, r compile-time)
+__device__ __forceinline__ float hc_row_ror(float x, int r) {
+  const int xi = __builtin_bit_cast(int, x);
+  int y;
+  switch (r) {
+    case 1: y = __builtin_amdgcn_update_dpp(xi, xi, 0x121, 0xf, 0xf, false); break;
+    case 2: y = __builtin_amdgcn_update_dpp(xi, xi, 0x122, 0xf, 0xf, false); break;
+    case 4: y = __builtin_amdgcn_update_dpp(xi, xi, 0x124, 0xf, 0xf, false); break;
+    default: y = __builtin_amdgcn_update_dpp(xi, xi, 0x128, 0xf, 0xf, false); break;
+  }
+  return __builtin_bit_cast(float, y);
 }
 
 __device__ __forceinline__ bf16x8_t hc_relu(bf16x8_t v) {
@@ -240,18 +259,27 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
 
   // fused batch-norm prologue: per channel block, the coefficients of its 64 channels go to LDS ...
   const bool bnp = (FUSE == 1 || FUSE == 3) && a.bn_mean != nullptr;   // wave-uniform
-  auto load_bn_table = [&](int cb) {
-    if (bnp && tid < 64) {
+  // the block's coefficient rows go to LDS by 4-byte LDS-DMAs of wave 0 (mean | variance | gamma |
+  // beta, 64 floats each): with VGPR-destination loads hipcc waits vmcnt(0) where the values are used,
+  // i.e. for the whole window DMA issued around them (r06: +3 k cycles per channel block); absent
+  // gamma / beta rows are written once as 1 / 0
+  auto fetch_bn_table = [&](int cb) {
+    if (bnp && wave == 0) {
       float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
-      const int ch = min(cb * 64 + tid, a.Ci - 1);   // (a ragged last block only uses its first half)
+      const int ch = min(cb * 64 + lane, a.Ci - 1);   // (a ragged last block only uses its first half)
       const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
       const int64_t sidx = a.bn_stat_group > 0 ? (int64_t)(n / a.bn_stat_group) * a.Ci + ch : ch;
-      tab[tid] = a.bn_mean[sidx];
-      tab[64 + tid] = rsqrtf(a.bn_var[sidx] + a.bn_eps);
-      tab[128 + tid] = a.bn_gamma ? a.bn_gamma[pidx] : 1.f;
-      tab[192 + tid] = a.bn_beta ? a.bn_beta[pidx] : 0.f;
+      hc_glds4(a.bn_mean + sidx, tab);
+      hc_glds4(a.bn_var + sidx, tab + 64);
+      if (a.bn_gamma) hc_glds4(a.bn_gamma + pidx, tab + 128);
+      if (a.bn_beta) hc_glds4(a.bn_beta + pidx, tab + 192);
     }
   };
+  if (bnp && tid < 64) {
+    float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
+    if (!a.bn_gamma) tab[128 + tid] = 1.f;
+    if (!a.bn_beta) tab[192 + tid] = 0.f;
+  }
   // ... and the staged window is normalised in place (same operation order as cg_bn_apply,
   // arch_ops.py:306-312); padding pixels stay zero: the padding applies to the BN output
   auto bn_transform = [&](int cb) {
@@ -268,60 +296,96 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         cm[e] = tab[c8 + e];
-        cr[e] = tab[64 + c8 + e];
+        cr[e] = rsqrtf(tab[64 + c8 + e] + a.bn_eps);
         cg[e] = tab[128 + c8 + e];
         cbt[e] = tab[192 + c8 + e];
       }
-      for (int row = tid >> 3; row < npieces * 8; row += 64) {
-        const int hy = row / PITCH, hx = row - hy * PITCH;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (!(hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win))
-          continue;
-        uint4* p = reinterpret_cast<uint4*>(smem + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16);
-        float v[8];
-        unpack8_bf16(*p, v);
+      // batches of three rows: all LDS reads of a batch are in flight before the first is used (one
+      // row per iteration left a read -> 40 VALU -> write chain of ~400 cycles per row exposed)
+      constexpr int NIT = (HALO_PIECES * 8 + 63) / 64, NB = 3;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = (v[e] - cm[e]) * cr[e];
-          t = t * cg[e] + cbt[e];
-          v[e] = fmaxf(t, 0.f);
+      for (int b0 = 0; b0 < NIT; b0 += NB) {
+        uint4* pp[NB];
+        uint4 raw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int row = (tid >> 3) + 64 * (b0 + b);
+          const int hy = row / PITCH, hx = row - hy * PITCH;
+          const int iy = iy0 + hy, ix = ix0 + hx;
+          const bool ok = b0 + b < NIT && row < npieces * 8 && hy < HH && hx < HWID &&
+                          (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          pp[b] = ok ? reinterpret_cast<uint4*>(smem + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16)
+                     : nullptr;
+          if (pp[b]) raw[b] = *pp[b];
         }
-        *p = pack8_bf16(v);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (!pp[b]) continue;
+          float v[8];
+          unpack8_bf16(raw[b], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = (v[e] - cm[e]) * cr[e];
+            t = t * cg[e] + cbt[e];
+            v[e] = fmaxf(t, 0.f);
+          }
+          *pp[b] = pack8_bf16(v);
+        }
       }
       return;
     }
-    for (int i = tid; i < npieces * 64; i += 512) {
-      const int row = i >> 3;
-      const int hy = row / PITCH, hx = row - hy * PITCH;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      if (!(hy < HH && hx < HWID && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win))
-        continue;
-      const int c8 = ((i & 7) ^ ((hx >> 1) & 7)) * 8;
-      if (c8 >= crem) continue;   // zero-filled half of a ragged last channel block
-      uint4* p = reinterpret_cast<uint4*>(smem + i * 16);
-      float v[8];
-      unpack8_bf16(*p, v);
-      // the chunk's 4 x 8 coefficients as eight 16-byte LDS reads (element-wise reads were 32 of the
-      // ~36 LDS operations a chunk cost, and this pass is not overlapped with the MFMA loop); four
-      // channels at a time: the 128-channel kernel has no registers to spare
-      const float4* t4 = reinterpret_cast<const float4*>(tab + c8);
+    // 128-channel tile: the same thread -> (8-channel group, rows) map, in two passes of FOUR channels
+    // (16 coefficient registers; the accumulators leave no room for 32) with 8-byte LDS accesses; the
+    // round-5 form read the 4 x 8 coefficients of every chunk from the LDS table (8 of its 10 LDS
+    // operations per chunk)
+    const int c8 = (tid & 7) * 8;
+    if (c8 >= crem) return;   // zero-filled half of a ragged last channel block
+    constexpr int NIT = (HALO_PIECES * 8 + 63) / 64, NB = 2;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      float cm[4], cr[4], cg[4], cbt[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4 m = t4[h], r = t4[16 + h], g = t4[32 + h], b = t4[48 + h];
-        float t;
-        t = (v[4 * h + 0] - m.x) * r.x; t = t * g.x + b.x; v[4 * h + 0] = fmaxf(t, 0.f);
-        t = (v[4 * h + 1] - m.y) * r.y; t = t * g.y + b.y; v[4 * h + 1] = fmaxf(t, 0.f);
-        t = (v[4 * h + 2] - m.z) * r.z; t = t * g.z + b.z; v[4 * h + 2] = fmaxf(t, 0.f);
-        t = (v[4 * h + 3] - m.w) * r.w; t = t * g.w + b.w; v[4 * h + 3] = fmaxf(t, 0.f);
+      for (int e = 0; e < 4; ++e) {
+        cm[e] = tab[c8 + 4 * h + e];
+        cr[e] = rsqrtf(tab[64 + c8 + 4 * h + e] + a.bn_eps);
+        cg[e] = tab[128 + c8 + 4 * h + e];
+        cbt[e] = tab[192 + c8 + 4 * h + e];
       }
-      *p = pack8_bf16(v);
+#pragma unroll
+      for (int b0 = 0; b0 < NIT; b0 += NB) {
+        int pp[NB];   // LDS byte offset of the row's half chunk (-1: padding / outside)
+        uint2 raw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int row = (tid >> 3) + 64 * (b0 + b);
+          const int hy = row / PITCH, hx = row - hy * PITCH;
+          const int iy = iy0 + hy, ix = ix0 + hx;
+          const bool ok = b0 + b < NIT && row < npieces * 8 && hy < HH && hx < HWID &&
+                          (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          pp[b] = ok ? (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16 + 8 * h : -1;
+          if (pp[b] >= 0) raw[b] = *reinterpret_cast<const uint2*>(smem + pp[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (pp[b] < 0) continue;
+          float v[4] = {__uint_as_float(raw[b].x << 16), __uint_as_float(raw[b].x & 0xffff0000u),
+                        __uint_as_float(raw[b].y << 16), __uint_as_float(raw[b].y & 0xffff0000u)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = (v[e] - cm[e]) * cr[e];
+            t = t * cg[e] + cbt[e];
+            v[e] = fmaxf(t, 0.f);
+          }
+          *reinterpret_cast<uint2*>(smem + pp[b]) = pack4_bf16(v);
+        }
+      }
     }
   };
 
   // the first loads leave before the rest of the set-up (their latency is the longest pole)
   issue_halo(0);
   issue_b(0, ((r0 * a.kw) + s0) * a.Ci);
-  load_bn_table(0);
+  fetch_bn_table(0);
 
   // ---- fragment addressing ----
   // pixel p = wm*64 + i*32 + frow of the tile -> (y, x); halo row of its tap-(0,0) input pixel
@@ -436,7 +500,7 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       // channel block finished: every wave is done with the halo image before it is overwritten
       asm volatile("s_barrier" ::: "memory");
       issue_halo(ncb);
-      load_bn_table(ncb);
+      fetch_bn_table(ncb);
     }
     tap = ntap;
     cb = ncb;
@@ -608,8 +672,33 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     HC_STAMP(4);
     return;
   }
+  // row `rl + RPI k` of pass i: output offset of this lane's 8 channels (-1: nothing to store)
+  constexpr int NKR = 32 / RPI;
+  auto row_off = [&](int i, int k) -> int64_t {
+    const int row = rl + RPI * k;
+    const int p = wm * 64 + i * 32 + row;
+    const int y = MI ? (p >> 3) & 7 : p >> TWL, x = p & (TW - 1);
+    const int oy = (ty * TH + y) * a.U + ph, ox = (tx * TW + x) * a.U + pw;
+    const int ni = MI ? n * 4 + (p >> 6) : n;
+    if (!co_ok || (MI && ni >= a.N)) return -1;   // (ragged last image group)
+    return ((int64_t)(ni * a.Ho + oy) * a.Wo + ox) * a.Co + co;
+  };
+  // the gate tensor (data gradients: every launch of a backward pass) or the residual of a pass's rows
+  // is requested BEFORE the accumulators of the pass go through LDS: a load issued where its value is
+  // used costs its whole latency per row, four to eight times per workgroup (r06_hconv_timeline.txt:
+  // epilogue 3.0 k -> 8.5 k cycles with a residual).  One buffer: with both tensors present the gate is
+  // prefetched and the residual read late.
+  const bf16_t* pf = a.gate_out ? a.gate_out : a.residual;   // workgroup-uniform
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    uint4 pre[NKR];
+    if (pf) {
+#pragma unroll
+      for (int k = 0; k < NKR; ++k) {
+        const int64_t o = row_off(i, k);
+        pre[k] = *reinterpret_cast<const uint4*>(pf + (o < 0 ? 0 : o));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -619,17 +708,12 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
                         acc[i][j][q * 4 + 3]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 32 / RPI; ++k) {
+    for (int k = 0; k < NKR; ++k) {
       const int row = rl + RPI * k;
       const float4 lo = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32);
       const float4 hi = *reinterpret_cast<const float4*>(Sw + row * SP + g8 * 32 + 16);
-      if (!co_ok) continue;
-      const int p = wm * 64 + i * 32 + row;
-      const int y = MI ? (p >> 3) & 7 : p >> TWL, x = p & (TW - 1);
-      const int oy = (ty * TH + y) * a.U + ph, ox = (tx * TW + x) * a.U + pw;
-      const int ni = MI ? n * 4 + (p >> 6) : n;
-      if (MI && ni >= a.N) continue;   // ragged last image group
-      const int64_t o = ((int64_t)(ni * a.Ho + oy) * a.Wo + ox) * a.Co + co;
+      const int64_t o = row_off(i, k);
+      if (o < 0) continue;
       float v[8] = {lo.x * osc + bv[0], lo.y * osc + bv[1], lo.z * osc + bv[2], lo.w * osc + bv[3],
                     hi.x * osc + bv[4], hi.y * osc + bv[5], hi.z * osc + bv[6], hi.w * osc + bv[7]};
       if (a.self_gate) {
@@ -639,14 +723,14 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       }
       if (a.gate_out) {
         float gv[8];
-        unpack8_bf16(*reinterpret_cast<const uint4*>(a.gate_out + o), gv);
+        unpack8_bf16(pre[k], gv);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (!(gv[e] > 0.f)) v[e] *= a.slope_out;
       }
       if (a.residual) {
         float rv[8];
-        unpack8_bf16(*reinterpret_cast<const uint4*>(a.residual + o), rv);
+        unpack8_bf16(a.gate_out ? *reinterpret_cast<const uint4*>(a.residual + o) : pre[k], rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
@@ -670,22 +754,26 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   if (FUSE == 1 && a.stats) {   // wave-uniform
-    // lanes with the same g8 hold partial sums of the same 8 channels: butterfly over the others,
-    // then the 4 pixel-waves of a channel half are combined through LDS in a fixed order
+    // lane = rl * G8 + g8: the lanes of one 16-lane DPP row with the same g8 (16 / G8 of them) are
+    // summed by row rotations (one VALU instruction each, no LDS round trip: the round-5 butterfly was
+    // 64 ds_bpermute per wave); the 4 rows of a wave and the 4 pixel-waves of a channel half are then
+    // combined through LDS in a fixed order.  A wave's partials go into its OWN staging rows (its
+    // LDS operations complete in order).
 #pragma unroll
-    for (int m = G8; m < 64; m <<= 1) {
+    for (int r = G8; r < 16; r <<= 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s1[e] += __shfl_xor(s1[e], m, 64);
-        s2[e] += __shfl_xor(s2[e], m, 64);
+        s1[e] += hc_row_ror(s1[e], r);
+        s2[e] += hc_row_ror(s2[e], r);
       }
     }
-    float* sreg = reinterpret_cast<float*>(smem + 8 * 32 * SP);   // [8 waves][2][WCO]
-    if (lane < G8) {
+    float* sreg = reinterpret_cast<float*>(Sw);   // [4 DPP rows][2][WCO]
+    if ((lane & 15) < G8) {
+      const int dr = lane >> 4;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        sreg[((wm * 2 + wn) * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
-        sreg[((wm * 2 + wn) * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
+        sreg[(dr * 2 + 0) * WCO + g8 * 8 + e] = s1[e];
+        sreg[(dr * 2 + 1) * WCO + g8 * 8 + e] = s2[e];
       }
     }
     __syncthreads();
@@ -694,8 +782,12 @@ __global__ __launch_bounds__(512, 4) void hconv_kernel(HConvArgs a) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) {
-        t1 += sreg[((m4 * 2 + cw) * 2 + 0) * WCO + cc];
-        t2 += sreg[((m4 * 2 + cw) * 2 + 1) * WCO + cc];
+        const float* sw = reinterpret_cast<const float*>(smem + (cw * 4 + m4) * (32 * SP));   // wave (wm = m4, wn = cw)
+#pragma unroll
+        for (int dr = 0; dr < 4; ++dr) {
+          t1 += sw[(dr * 2 + 0) * WCO + cc];
+          t2 += sw[(dr * 2 + 1) * WCO + cc];
+        }
       }
       const int cch = n0 + tid;
       if (cch < a.Co) {
@@ -815,9 +907,16 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
 
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
   int t = blockIdx.x;
+#ifdef CG_CONV_TIMING
+  unsigned long long tq_wait = 0, tq_mma = 0, tq_epi = 0, tq_t0 = __builtin_amdgcn_s_memtime(), tq_a, tq_b;
+#define RW_T(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define RW_T(x) do {} while (0)
+#endif
   if (t < ntiles) stage(0, t);
   for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
     const int buf = it & 1;
+    RW_T(tq_a);
     // the window DMA of this tile was issued BEFORE the previous tile's output stores; vmcnt counts
     // stores too and retires in order, so leaving exactly those stores outstanding (4 bf16 / 8 fp32
     // store instructions per wave and tile) waits for the window without draining the stores
@@ -842,6 +941,9 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
     }
     if (t + (int)gridDim.x < ntiles) stage(buf ^ 1, t + gridDim.x);
     const unsigned char* Hb = smem + buf * RW_HB + hb0;
+#ifdef CG_CONV_TIMING
+    RW_T(tq_b); tq_wait += tq_b - tq_a;
+#endif
 
     f32x16_t acc[2];
 #pragma unroll
@@ -864,6 +966,9 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
       // fragment reads are not hoisted across taps: 144 of the 256 registers hold the weights
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef CG_CONV_TIMING
+    RW_T(tq_a); tq_mma += tq_a - tq_b;
+#endif
     // ---- epilogue of this tile (wave-private staging: no workgroup barrier) ----
     const int q = (int)fdiv((uint32_t)t, a.dTx);
     const int tx = t - q * a.tiles_x;
@@ -905,6 +1010,9 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + o) = pack8_bf16(v);
       }
       __builtin_amdgcn_wave_barrier();
+#ifdef CG_CONV_TIMING
+      RW_T(tq_b); tq_epi += tq_b - tq_a;
+#endif
       continue;
     }
     const float osc = a.out_scale;
@@ -953,7 +1061,17 @@ __global__ __launch_bounds__(256, 2) void hconv_rw_kernel(HConvArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+#ifdef CG_CONV_TIMING
+    RW_T(tq_b); tq_epi += tq_b - tq_a;
+#endif
   }
+#ifdef CG_CONV_TIMING
+  if (a.tdbg && tid == 0) {   // per workgroup: total, wait (window + barrier), MFMA loop, epilogue cycles
+    unsigned long long* d = a.tdbg + (size_t)blockIdx.x * 8;
+    d[0] = __builtin_amdgcn_s_memtime() - tq_t0; d[1] = tq_wait; d[2] = tq_mma; d[3] = tq_epi;
+  }
+#endif
+#undef RW_T
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1045,18 +1163,24 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
       hc_dma16(rs_bt, bvoff[j], (uint32_t)((tap * a.Ci + cb * 64) * 2), bs + (wave * 2 + j) * 1024);
   };
   const bool bnp = FUSE == 1 && a.bn_mean != nullptr;
-  auto load_bn_table = [&](int cb) {
-    if (bnp && tid < 64) {
+  // the block's coefficient rows by 4-byte LDS-DMAs of wave 0 (hconv_kernel)
+  auto fetch_bn_table = [&](int cb) {
+    if (bnp && wave == 0) {
       float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
-      const int ch = min(cb * 64 + tid, a.Ci - 1);
+      const int ch = min(cb * 64 + lane, a.Ci - 1);
       const int64_t pidx = a.bn_per_sample ? (int64_t)n * a.Ci + ch : ch;
       const int64_t sidx = a.bn_stat_group > 0 ? (int64_t)(n / a.bn_stat_group) * a.Ci + ch : ch;
-      tab[tid] = a.bn_mean[sidx];
-      tab[64 + tid] = rsqrtf(a.bn_var[sidx] + a.bn_eps);
-      tab[128 + tid] = a.bn_gamma ? a.bn_gamma[pidx] : 1.f;
-      tab[192 + tid] = a.bn_beta ? a.bn_beta[pidx] : 0.f;
+      hc_glds4(a.bn_mean + sidx, tab);
+      hc_glds4(a.bn_var + sidx, tab + 64);
+      if (a.bn_gamma) hc_glds4(a.bn_gamma + pidx, tab + 128);
+      if (a.bn_beta) hc_glds4(a.bn_beta + pidx, tab + 192);
     }
   };
+  if (bnp && tid < 64) {
+    float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
+    if (!a.bn_gamma) tab[128 + tid] = 1.f;
+    if (!a.bn_beta) tab[192 + tid] = 0.f;
+  }
   auto bn_transform = [&](int cb) {   // as hconv_kernel: in place, padding pixels stay zero
     const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
     const int crem = a.Ci - cb * 64;
@@ -1067,30 +1191,45 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       cm[e] = tab[c8 + e];
-      cr[e] = tab[64 + c8 + e];
+      cr[e] = rsqrtf(tab[64 + c8 + e] + a.bn_eps);
       cg[e] = tab[128 + c8 + e];
       cbt[e] = tab[192 + c8 + e];
     }
-    for (int row = tid >> 3; row < HU_ROWS; row += 32) {
-      const int hy = row / HU_PITCH, hx = row - hy * HU_PITCH;
-      if (!(hx <= HU_TW && iy0 + hy < a.Hin && ix0 + hx < a.Win)) continue;
-      uint4* p = reinterpret_cast<uint4*>(hbuf + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16);
-      float v[8];
-      unpack8_bf16(*p, v);
+    constexpr int NIT = (HU_ROWS + 31) / 32, NB = 3;   // batches of three rows (hconv_kernel)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (v[e] - cm[e]) * cr[e];
-        t = t * cg[e] + cbt[e];
-        v[e] = fmaxf(t, 0.f);
+    for (int b0 = 0; b0 < NIT; b0 += NB) {
+      uint4* pp[NB];
+      uint4 raw[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int row = (tid >> 3) + 32 * (b0 + b);
+        const int hy = row / HU_PITCH, hx = row - hy * HU_PITCH;
+        const bool ok = b0 + b < NIT && row < HU_ROWS && hx <= HU_TW && iy0 + hy < a.Hin &&
+                        ix0 + hx < a.Win;
+        pp[b] = ok ? reinterpret_cast<uint4*>(hbuf + (row * 8 + ((tid & 7) ^ ((hx >> 1) & 7))) * 16)
+                   : nullptr;
+        if (pp[b]) raw[b] = *pp[b];
       }
-      *p = pack8_bf16(v);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!pp[b]) continue;
+        float v[8];
+        unpack8_bf16(raw[b], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = (v[e] - cm[e]) * cr[e];
+          t = t * cg[e] + cbt[e];
+          v[e] = fmaxf(t, 0.f);
+        }
+        *pp[b] = pack8_bf16(v);
+      }
     }
   };
 
+  fetch_bn_table(0);   // (first: the counted waits below leave the LATEST DMAs in flight)
   issue_halo(0);
   issue_b(0);
   if (nk > 1) issue_b(1);
-  load_bn_table(0);
 
   // ---- fragment addressing: pixel p = wave * 32 + frow -> (y, x) of the 8 x 16 tile ----
   const int py = (wave * 32 + frow) >> 4, px = frow & 15;
@@ -1143,7 +1282,7 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
       if (tap == 0 && next_cb) {   // the other window buffer was last read a whole block ago
         // (the table is read by bn_transform(cb + 1), nine barriers from here; its loads go first:
         // the compiler waits for them before the LDS stores, and vmcnt retires in order)
-        load_bn_table(cb + 1);
+        fetch_bn_table(cb + 1);
         issue_halo(cb + 1);
       }
       if (s + 2 < nk) issue_b(s + 2);   // into the slot every wave finished before this barrier
@@ -1254,28 +1393,28 @@ __global__ __launch_bounds__(256, 2) void hup_kernel(HConvArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   if (FUSE == 1 && a.stats) {   // wave-uniform
+    // lane = rl * 8 + g8: the two lanes of a 16-lane DPP row with the same g8 by one row rotation, the
+    // four rows of a wave and the four waves through LDS in a fixed order (as hconv_kernel)
 #pragma unroll
-    for (int m = 8; m < 64; m <<= 1) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s1[e] += __shfl_xor(s1[e], m, 64);
-        s2[e] += __shfl_xor(s2[e], m, 64);
-      }
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += hc_row_ror(s1[e], 8);
+      s2[e] += hc_row_ror(s2[e], 8);
     }
     __syncthreads();   // every wave is done with its staging rows
-    float* sreg = reinterpret_cast<float*>(smem);   // [4 waves][2][64]
-    if (lane < 8) {
+    float* sreg = reinterpret_cast<float*>(smem);   // [4 waves][4 DPP rows][2][64]
+    if ((lane & 15) < 8) {
+      const int dr = lane >> 4;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        sreg[(wave * 2 + 0) * 64 + g8 * 8 + e] = s1[e];
-        sreg[(wave * 2 + 1) * 64 + g8 * 8 + e] = s2[e];
+        sreg[((wave * 4 + dr) * 2 + 0) * 64 + g8 * 8 + e] = s1[e];
+        sreg[((wave * 4 + dr) * 2 + 1) * 64 + g8 * 8 + e] = s2[e];
       }
     }
     __syncthreads();
     if (tid < 64 && n0 + tid < a.Co) {
       float t1s = 0.f, t2s = 0.f;
 #pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) {
+      for (int w4 = 0; w4 < 16; ++w4) {
         t1s += sreg[(w4 * 2 + 0) * 64 + tid];
         t2s += sreg[(w4 * 2 + 1) * 64 + tid];
       }
@@ -2550,6 +2689,9 @@ static void hconv_rw_launch_ex(const cgConvGeom* g, const void* in, const void* 
   a.dTy = make_fastdiv(a.tiles_y);
   const int ntiles = g->N * a.tiles_y * a.tiles_x;
   const int grid = ntiles < 512 ? ntiles : 512;
+#ifdef CG_CONV_TIMING
+  a.tdbg = g_hconv_tdbg;
+#endif
   CgProfScope prof(CG_PROF_HCONV_64, g, st);
   if (pool) {
     if (gate_in) hconv_rw_kernel<true, true><<<grid, 256, 0, st>>>(a);

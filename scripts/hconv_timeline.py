@@ -24,6 +24,16 @@ w = torch.randn(k, k, Ci, Co, device=dev) * 0.05
 bias = torch.zeros(Co, device=dev)
 bt_f, _ = K.weight_prep(w, want_fwd=True, want_bwd=False)
 gi = x if relu else None
+# optional 3rd argument: fused forms of the no-gradient generator forward: any of "bn", "stats", "res"
+forms = sys.argv[2].split("+") if len(sys.argv) > 2 else []
+if forms:
+    mean, var = torch.zeros(Ci, device=dev), torch.ones(Ci, device=dev)
+    gamma, beta = torch.ones(Ci, device=dev), torch.zeros(Ci, device=dev)
+    bn = (mean, var, gamma, beta, 1e-5, False) if "bn" in forms else None
+    res = torch.randn(N, geom.Ho, geom.Wo, Co, device=dev).to(BF16) if "res" in forms else None
+    _plain = K.gconv
+    K.gconv = lambda geom, x, bt_f, bias=None, gate_in=None, slope_in=0.0: K.gconv_fused(
+        geom, x, bt_f, bias=bias, bn=bn, want_stats="stats" in forms, residual=res)
 nwg_max = 1 << 16
 buf = torch.zeros(nwg_max * 8, dtype=torch.int64, device=dev)
 for _ in range(3):
