@@ -655,6 +655,10 @@ def test_gconv_gates_residual(K, dev, slope, size):
 @pytest.mark.parametrize("case", [
     # name, N, H, W, Ci, Co, k, up, per_sample, residual
     ("bn_c64", 2, 32, 32, 64, 64, 3, 1, False, False),
+    # 64 -> 64 channels on whole 128 x 128 maps (one channel block, 8 x 32 tiles), plain and per-sample
+    # coefficients
+    ("bn_c64_128_res", 3, 128, 128, 64, 64, 3, 1, False, True),
+    ("cbn_c64_128", 2, 128, 128, 64, 64, 3, 1, True, False),
     ("bn_c128_res", 3, 16, 16, 128, 192, 3, 1, False, True),
     ("cbn_up", 2, 16, 16, 128, 64, 3, 2, True, False),
     ("cbn_1x1", 2, 32, 32, 64, 128, 1, 1, True, True),
