@@ -11,6 +11,39 @@ union V8 {
   bf16_t h[8];
 };
 
+// Thread -> (channel vector, row lane) of the vector kernels.  A block covers the channel vectors
+// [32 bx, 32 bx + LW), LW = min(32, CV - 32 bx), with RL = 256 / LW row lanes: every lane of the block
+// works for any channel count (round 5 fixed LW = 32: C = 64 left 24 of every 32 lanes idle, C = 96 20
+// -- bn_stats 1.1-1.5 TB/s, bn_apply 2.7 TB/s on the 128 x 128 layers, profiles/r06_stream_rates.txt).
+struct BnLane {
+  int lw, rl_n, cg, rl;
+  bool on;
+};
+__device__ __forceinline__ BnLane bn_lane(int CV, int bx, int tid) {
+  BnLane m;
+  m.lw = min(32, CV - bx * 32);
+  m.rl_n = 256 / m.lw;
+  m.rl = tid / m.lw;
+  m.cg = tid - m.rl * m.lw;
+  m.on = m.rl < m.rl_n;
+  return m;
+}
+// sum of the block's row lanes per (channel vector, element): sm[tid][0:16] -> 256 threads as (cg2 =
+// tid >> 3, e2 = tid & 7), fixed order
+__device__ __forceinline__ void bn_block_reduce(const float (*sm)[17], const BnLane& m, int tid,
+                                                float& a, float& b, int& cg2, int& e2) {
+  cg2 = tid >> 3;
+  e2 = tid & 7;
+  a = 0.f;
+  b = 0.f;
+  if (cg2 < m.lw) {
+    for (int r = 0; r < m.rl_n; ++r) {
+      a += sm[r * m.lw + cg2][e2];
+      b += sm[r * m.lw + cg2][8 + e2];
+    }
+  }
+}
+
 // ---- statistics ------------------------------------------------------------------------------
 // grid (ceil(CV/32), splits); thread (cg = tid%32, rl = tid/32) accumulates rows rl, rl+8, ...
 // Statistics groups (cg_bn_stats_groups): the rows form `groups` consecutive blocks of group_rows
@@ -20,20 +53,40 @@ __global__ __launch_bounds__(256) void bn_stats_part_kernel(const bf16_t* __rest
                                                             int64_t group_rows, int spg, int C,
                                                             int64_t rows_per_split,
                                                             float* __restrict__ part) {
-  __shared__ float sm[8][32][17];
-  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int cv = blockIdx.x * 32 + cg;
+  __shared__ float sm[256][17];
   const int CV = C / 8;
+  const BnLane m = bn_lane(CV, blockIdx.x, threadIdx.x);
+  const int cv = blockIdx.x * 32 + m.cg;
   const int grp = blockIdx.y / spg, sl = blockIdx.y - grp * spg;
   const int64_t r0 = grp * group_rows + (int64_t)sl * rows_per_split;
   const int64_t r1 = min((grp + 1) * group_rows, r0 + rows_per_split);
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-  if (cv < CV) {
-    for (int64_t r = r0 + rl; r < r1; r += 8) {
+  if (m.on) {
+    const bf16_t* xp = x + (int64_t)cv * 8;
+    int64_t r = r0 + m.rl;
+    // two rows in flight per lane
+    for (; r + m.rl_n < r1; r += 2 * m.rl_n) {
+      V8 v0, v1;
+      v0.q = *reinterpret_cast<const uint4*>(xp + r * C);
+      v1.q = *reinterpret_cast<const uint4*>(xp + (r + m.rl_n) * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(v0.h[e]);
+        s[e] += f;
+        q[e] += f * f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(v1.h[e]);
+        s[e] += f;
+        q[e] += f * f;
+      }
+    }
+    for (; r < r1; r += m.rl_n) {
       V8 v;
-      v.q = *reinterpret_cast<const uint4*>(x + r * C + (int64_t)cv * 8);
+      v.q = *reinterpret_cast<const uint4*>(xp + r * C);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float f = bf2f(v.h[e]);
@@ -44,20 +97,15 @@ __global__ __launch_bounds__(256) void bn_stats_part_kernel(const bf16_t* __rest
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    sm[rl][cg][e] = s[e];
-    sm[rl][cg][8 + e] = q[e];
+    sm[threadIdx.x][e] = s[e];
+    sm[threadIdx.x][8 + e] = q[e];
   }
   __syncthreads();
-  // 256 threads: 32 channel groups x 8 elements -> sum over the 8 row lanes
-  const int cg2 = threadIdx.x >> 3, e2 = threadIdx.x & 7;
-  const int cv2 = blockIdx.x * 32 + cg2;
-  if (cv2 < CV) {
-    float ss = 0.f, qq = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      ss += sm[r][cg2][e2];
-      qq += sm[r][cg2][8 + e2];
-    }
+  float ss, qq;
+  int cg2, e2;
+  bn_block_reduce(sm, m, threadIdx.x, ss, qq, cg2, e2);
+  if (cg2 < m.lw) {
+    const int cv2 = blockIdx.x * 32 + cg2;
     float* p = part + (int64_t)blockIdx.y * 2 * C;
     p[cv2 * 8 + e2] = ss;
     p[C + cv2 * 8 + e2] = qq;
@@ -220,9 +268,10 @@ __global__ __launch_bounds__(256) void bn_apply_vec_kernel(
     const float* __restrict__ var, float eps, const float* __restrict__ gamma,
     const float* __restrict__ beta, int per_sample, int stat_group, int relu,
     bf16_t* __restrict__ y) {
-  const int cv = blockIdx.x * 32 + (threadIdx.x & 31);
-  if (cv * 8 >= C) return;
-  const int rl = threadIdx.x >> 5;
+  const BnLane m = bn_lane(C / 8, blockIdx.x, threadIdx.x);
+  if (!m.on) return;
+  const int cv = blockIdx.x * 32 + m.cg;
+  const int rl = m.rl, RL = m.rl_n;
   const int n = blockIdx.z;
   const int c0 = cv * 8;
   // stat_group > 0: mean / var are [N / stat_group][C], one set per stat_group consecutive samples
@@ -241,7 +290,26 @@ __global__ __launch_bounds__(256) void bn_apply_vec_kernel(
   const int h0 = blockIdx.y * hw_per_chunk, h1 = min(HW, h0 + hw_per_chunk);
   const bf16_t* xp = x + (int64_t)n * HW * C + c0;
   bf16_t* yp = y + (int64_t)n * HW * C + c0;
-  for (int p = h0 + rl; p < h1; p += 8) {
+  int p = h0 + rl;
+  for (; p + RL < h1; p += 2 * RL) {   // two rows in flight per lane
+    V8 v0, v1, o0, o1;
+    v0.q = *reinterpret_cast<const uint4*>(xp + (int64_t)p * C);
+    v1.q = *reinterpret_cast<const uint4*>(xp + (int64_t)(p + RL) * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (bf2f(v0.h[e]) - mu[e]) * rs[e];
+      t = t * gm[e] + bt[e];
+      if (relu) t = fmaxf(t, 0.f);
+      o0.h[e] = f2bf(t);
+      float u = (bf2f(v1.h[e]) - mu[e]) * rs[e];
+      u = u * gm[e] + bt[e];
+      if (relu) u = fmaxf(u, 0.f);
+      o1.h[e] = f2bf(u);
+    }
+    *reinterpret_cast<uint4*>(yp + (int64_t)p * C) = o0.q;
+    *reinterpret_cast<uint4*>(yp + (int64_t)(p + RL) * C) = o1.q;
+  }
+  for (; p < h1; p += RL) {
     V8 v, o;
     v.q = *reinterpret_cast<const uint4*>(xp + (int64_t)p * C);
 #pragma unroll
@@ -283,15 +351,16 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_vec_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
     int HW, int C, int hw_per_split, const float* __restrict__ mean,
     const float* __restrict__ var, float eps, int relu, float* __restrict__ part) {
-  __shared__ float sm[8][32][17];
-  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int cv = blockIdx.x * 32 + cg;
+  __shared__ float sm[256][17];
+  const BnLane m = bn_lane(C / 8, blockIdx.x, threadIdx.x);
+  const int cv = blockIdx.x * 32 + m.cg;
+  const int rl = m.rl, RL = m.rl_n;
   const int n = blockIdx.z, N = gridDim.z;
   const int h0 = blockIdx.y * hw_per_split, h1 = min(HW, h0 + hw_per_split);
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-  if (cv * 8 < C) {
+  if (m.on) {
     const int c0 = cv * 8;
     float mu[8], rs[8];
 #pragma unroll
@@ -300,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_vec_kernel(
       rs[e] = rsqrtf(var[c0 + e] + eps);
     }
     const int64_t base = (int64_t)n * HW * C + c0;
-    for (int p = h0 + rl; p < h1; p += 8) {
+    for (int p = h0 + rl; p < h1; p += RL) {
       const int64_t o = base + (int64_t)p * C;
       V8 vx, vy, vg;
       vx.q = *reinterpret_cast<const uint4*>(x + o);
@@ -317,19 +386,15 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_vec_kernel(
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    sm[rl][cg][e] = s1[e];
-    sm[rl][cg][8 + e] = s2[e];
+    sm[threadIdx.x][e] = s1[e];
+    sm[threadIdx.x][8 + e] = s2[e];
   }
   __syncthreads();
-  const int cg2 = threadIdx.x >> 3, e2 = threadIdx.x & 7;
+  float a, b;
+  int cg2, e2;
+  bn_block_reduce(sm, m, threadIdx.x, a, b, cg2, e2);
   const int cv2 = blockIdx.x * 32 + cg2;
-  if (cv2 * 8 < C) {
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      a += sm[r][cg2][e2];
-      b += sm[r][cg2][8 + e2];
-    }
+  if (cg2 < m.lw) {
     float* p = part + (int64_t)blockIdx.y * 2 * N * C;
     p[(int64_t)n * C + cv2 * 8 + e2] = a;
     p[(int64_t)N * C + (int64_t)n * C + cv2 * 8 + e2] = b;
@@ -424,9 +489,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_vec_kernel(
     int HW, int C, int hw_per_chunk, const float* __restrict__ mean,
     const float* __restrict__ var, float eps, const float* __restrict__ gamma, int per_sample,
     int relu, int batch_stats, const float* __restrict__ m12, bf16_t* __restrict__ dx) {
-  const int cv = blockIdx.x * 32 + (threadIdx.x & 31);
-  if (cv * 8 >= C) return;
-  const int rl = threadIdx.x >> 5;
+  const BnLane m = bn_lane(C / 8, blockIdx.x, threadIdx.x);
+  if (!m.on) return;
+  const int cv = blockIdx.x * 32 + m.cg;
+  const int rl = m.rl, RL = m.rl_n;
   const int n = blockIdx.z;
   const int c0 = cv * 8;
   float mu[8], rs[8], gm[8], k1[8], k2[8];
@@ -440,7 +506,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_vec_kernel(
   }
   const int h0 = blockIdx.y * hw_per_chunk, h1 = min(HW, h0 + hw_per_chunk);
   const int64_t base = (int64_t)n * HW * C + c0;
-  for (int p = h0 + rl; p < h1; p += 8) {
+  for (int p = h0 + rl; p < h1; p += RL) {
     const int64_t o = base + (int64_t)p * C;
     V8 vx, vy, vg, vo;
     vg.q = *reinterpret_cast<const uint4*>(dy + o);

@@ -130,6 +130,61 @@ __global__ void pool2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __r
   }
 }
 
+// the same, 8 channels per thread (C % 8 == 0): one 16-byte gradient load, four 16-byte stores (and
+// four 16-byte loads of x for the maximum): the scalar form moved 2 bytes per thread and instruction
+// (2.1-2.8 TB/s algorithmic; profiles/r06_stream_rates.txt)
+template <bool MAXP>
+__global__ __launch_bounds__(256) void pool2_bwd_vec8_kernel(const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ dy, int N,
+                                                             int H, int W, int C,
+                                                             bf16_t* __restrict__ dx) {
+  const int Ho = H / 2, Wo = W / 2, CV = C / 8;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int ow = (int)(p % Wo);
+    p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int64_t base = (((int64_t)n * H + oh * 2) * W + ow * 2) * C + cv * 8;
+    const int64_t o1 = C, o2 = (int64_t)W * C, o3 = (int64_t)W * C + C;
+    V8 g;
+    g.q = *reinterpret_cast<const uint4*>(dy + i * 8);
+    V8 r0, r1, r2, r3;
+    if (MAXP) {
+      V8 a, b, c, d;
+      a.q = *reinterpret_cast<const uint4*>(x + base);
+      b.q = *reinterpret_cast<const uint4*>(x + base + o1);
+      c.q = *reinterpret_cast<const uint4*>(x + base + o2);
+      d.q = *reinterpret_cast<const uint4*>(x + base + o3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float fa = bf2f(a.h[e]), fb = bf2f(b.h[e]), fc = bf2f(c.h[e]), fd = bf2f(d.h[e]);
+        const float m = fmaxf(fmaxf(fa, fb), fmaxf(fc, fd));
+        int sel = 3;
+        if (fa == m) sel = 0;
+        else if (fb == m) sel = 1;
+        else if (fc == m) sel = 2;
+        const bf16_t z = 0, gv = g.h[e];
+        r0.h[e] = sel == 0 ? gv : z;
+        r1.h[e] = sel == 1 ? gv : z;
+        r2.h[e] = sel == 2 ? gv : z;
+        r3.h[e] = sel == 3 ? gv : z;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r0.h[e] = f2bf(0.25f * bf2f(g.h[e]));
+      r1 = r0; r2 = r0; r3 = r0;
+    }
+    *reinterpret_cast<uint4*>(dx + base) = r0.q;
+    *reinterpret_cast<uint4*>(dx + base + o1) = r1.q;
+    *reinterpret_cast<uint4*>(dx + base + o2) = r2.q;
+    *reinterpret_cast<uint4*>(dx + base + o3) = r3.q;
+  }
+}
+
 // ---- spatial reduce over HW per (n, c) -----------------------------------------------------
 // block = 256 threads handles one n and 64 channels; 4 waves split HW; LDS combine.
 __global__ void spatial_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
@@ -624,6 +679,10 @@ extern "C" int cg_avgpool2_bwd(const void* dy, int N, int H, int W, int C, void*
   int rc = check_pool(dy, N, H, W, C, dx, "cg_avgpool2_bwd");
   if (rc) return rc;
   const int64_t work = (int64_t)N * (H / 2) * (W / 2) * C;
+  if ((C % 8) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0)
+    pool2_bwd_vec8_kernel<false><<<grid_for(work / 8), 256, 0, (hipStream_t)stream>>>(
+        nullptr, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
+  else
   pool2_bwd_kernel<false><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
       nullptr, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
   CG_CHECK_LAUNCH("cg_avgpool2_bwd");
@@ -667,6 +726,10 @@ extern "C" int cg_maxpool2_bwd(const void* x, const void* dy, int N, int H, int 
   if (rc) return rc;
   if (!dy) CG_FAIL(CG_ERR_BAD_ARG, "cg_maxpool2_bwd: null dy");
   const int64_t work = (int64_t)N * (H / 2) * (W / 2) * C;
+  if ((C % 8) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0)
+    pool2_bwd_vec8_kernel<true><<<grid_for(work / 8), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
+  else
   pool2_bwd_kernel<true><<<grid_for(work), kBlock, 0, (hipStream_t)stream>>>(
       (const bf16_t*)x, (const bf16_t*)dy, N, H, W, C, (bf16_t*)dx);
   CG_CHECK_LAUNCH("cg_maxpool2_bwd");
