@@ -787,6 +787,8 @@ def reduce_spatial(inputs, mean):
 
 
 _FOLD_SIGMA = _os.environ.get("CGAMD_FOLD_SIGMA", "1") != "0"    # A/B switch (read once)
+# the four consumers of the self-attention block's input summed by one launch (A/B switch)
+_FORK_ATTENTION = _os.environ.get("CGAMD_FORK_ATTENTION", "1") != "0"
 _DOUBLE_BWD = [False]
 _FUSED_HEAD = _os.environ.get("CGAMD_FUSED_HEAD", "1") != "0"    # A/B switch (read once)
 
@@ -849,10 +851,12 @@ def non_local_block(x, name, use_sn):
     cap, cgp = (ca + 31) // 32 * 32, (cg + 31) // 32 * 32
     if not _PAD_ATTENTION or c % 32:
       cap, cgp = ca, cg
-    theta = conv1x1(x, ca, name="conv2d_theta", use_sn=use_sn, use_bias=False, pad_out_to=cap)
-    phi = max_pool2(conv1x1(x, ca, name="conv2d_phi", use_sn=use_sn, use_bias=False,
+    # x has four consumers: their gradient contributions are summed by one launch (Fn.ForkNFn)
+    x_t, x_p, x_g, x = Fn.fork_n(x, 4) if _FORK_ATTENTION else (x, x, x, x)
+    theta = conv1x1(x_t, ca, name="conv2d_theta", use_sn=use_sn, use_bias=False, pad_out_to=cap)
+    phi = max_pool2(conv1x1(x_p, ca, name="conv2d_phi", use_sn=use_sn, use_bias=False,
                             pad_out_to=cap))
-    g = max_pool2(conv1x1(x, cg, name="conv2d_g", use_sn=use_sn, use_bias=False, pad_out_to=cgp))
+    g = max_pool2(conv1x1(x_g, cg, name="conv2d_g", use_sn=use_sn, use_bias=False, pad_out_to=cgp))
     if x.is_meta:
       attn_g = torch.empty((n, h, w, cgp), dtype=BF16, device="meta")
     else:

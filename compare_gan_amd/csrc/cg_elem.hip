@@ -576,6 +576,44 @@ extern "C" int cg_axpby(const void* a, float alpha, const void* b, float beta, v
   return CG_OK;
 }
 
+// out = a + b + c (+ d): the gradient contributions of a tensor with three / four consumers (the input
+// of the self-attention block, arch_ops.py:709-758: three 1x1 projections and the residual path), summed
+// in fp32 with ONE rounding -- autograd's accumulation was a chain of bf16 torch adds, each a pass of
+// 2 reads + 1 write over the [N, H, W, C] map.
+__global__ __launch_bounds__(256) void sum4_kernel(const bf16_t* __restrict__ a,
+                                                   const bf16_t* __restrict__ b,
+                                                   const bf16_t* __restrict__ c,
+                                                   const bf16_t* __restrict__ d,
+                                                   bf16_t* __restrict__ out, int64_t n) {
+  const bool aligned = ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) |
+                         ((uintptr_t)out)) & 15) == 0;
+  const int64_t nv = aligned ? n / 8 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    V8 va, vb, vc, vd, vo;
+    va.q = reinterpret_cast<const uint4*>(a)[i];
+    vb.q = reinterpret_cast<const uint4*>(b)[i];
+    vc.q = reinterpret_cast<const uint4*>(c)[i];
+    if (d) vd.q = reinterpret_cast<const uint4*>(d)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      vo.h[e] = f2bf(((bf2f(va.h[e]) + bf2f(vb.h[e])) + bf2f(vc.h[e])) + (d ? bf2f(vd.h[e]) : 0.f));
+    reinterpret_cast<uint4*>(out)[i] = vo.q;
+  }
+  for (int64_t i = nv * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = f2bf(((bf2f(a[i]) + bf2f(b[i])) + bf2f(c[i])) + (d ? bf2f(d[i]) : 0.f));
+}
+extern "C" int cg_sum4(const void* a, const void* b, const void* c, const void* d, void* out,
+                       int64_t n, cgStream stream) {
+  CG_NONNEG(n, "cg_sum4");
+  if (n == 0) return CG_OK;
+  if (!a || !b || !c || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_sum4: null pointer");
+  sum4_kernel<<<grid_for(n / 8 + 1), 256, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (const bf16_t*)d, (bf16_t*)out, n);
+  CG_CHECK_LAUNCH("cg_sum4");
+  return CG_OK;
+}
+
 // ---- zero-insertion upsampling (resnet_ops.unpool) on its own --------------------------------------
 // The convolutions take the upsampling as a launch parameter (U = 2, no zero is ever stored); the
 // BigGAN-deep generator also upsamples its shortcut branch WITHOUT a convolution

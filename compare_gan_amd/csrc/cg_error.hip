@@ -14,7 +14,7 @@ void cg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int cg_abi_version(void) { return 5; }   // round 5: cgDeferCtx replaces cg_reduce_defer_*
+extern "C" int cg_abi_version(void) { return 6; }   // round 6: + cg_sum4 (round 5: cgDeferCtx replaces cg_reduce_defer_*)
 extern "C" const char* cg_last_error(void) { return g_err; }
 
 // ---- optional per-kernel-family timing with HIP events (bench.py's roofline leg) -------------

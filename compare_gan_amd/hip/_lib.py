@@ -135,6 +135,7 @@ SIGNATURES = {
     "cg_lrelu_bwd": (c_int, [vp, vp, c_f32, vp, c_i64, vp]),
     "cg_axpby": (c_int, [vp, c_f32, vp, c_f32, vp, c_i64, vp]),
     "cg_axpby_f32": (c_int, [vp, c_f32, vp, c_f32, vp, c_i64, vp]),
+    "cg_sum4": (c_int, [vp, vp, vp, vp, vp, c_i64, vp]),
     "cg_axpy_dev": (c_int, [vp, vp, vp, vp, c_i64, vp]),
     "cg_dot_bf16_workspace_bytes": (c_sz, [c_i64]),
     "cg_dot_bf16": (c_int, [vp, vp, c_i64, vp, vp, c_sz, vp]),

@@ -1112,6 +1112,56 @@ class ForkFn(torch.autograd.Function):
       return SumFn.forward(None, g1, g2)
 
 
+class Sum4Fn(torch.autograd.Function):
+  """a + b + c (+ d) of bf16 tensors in one launch (cg_sum4); linear, differentiable to any order."""
+
+  @staticmethod
+  def forward(ctx, *ts):
+    ctx.n = len(ts)
+    return K.sum4(*[t.contiguous() for t in ts])
+
+  @staticmethod
+  def backward(ctx, d):
+    return (d,) * ctx.n
+
+
+class ForkNFn(torch.autograd.Function):
+  """A tensor with THREE or FOUR consumers (the input of the self-attention block, arch_ops.py:709-758:
+  theta / phi / g projections and the residual path): aliases forward, one fused sum of the gradient
+  contributions backward (autograd would chain bf16 torch adds: 3 passes of 2 reads + 1 write over the
+  [N, H, W, C] map -- 27 launches, 2.4 ms of the BigGAN bs-256 step, r05_torch_ops_per_step.txt)."""
+
+  @staticmethod
+  def forward(ctx, x, n):
+    ctx.set_materialize_grads(False)
+    return tuple(x.view_as(x) for _ in range(n))
+
+  @staticmethod
+  def backward(ctx, *gs):
+    live = [g for g in gs if g is not None]
+    if not live:
+      return None, None
+    if len(live) == 1:
+      return live[0], None
+    same = all(g.dtype == BF16 for g in live)
+    if len(live) == 2 or not same:
+      acc = live[0]
+      for g in live[1:]:
+        acc = SumFn.apply(acc, g) if torch.is_grad_enabled() else SumFn.forward(None, acc, g)
+      return acc, None
+    if torch.is_grad_enabled():
+      return Sum4Fn.apply(*live), None
+    with torch.no_grad():
+      return K.sum4(*[g.contiguous() for g in live]), None
+
+
+def fork_n(x, n):
+  """n aliases of x for n (3 or 4) consumers when a gradient will flow back; plain aliases otherwise."""
+  if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and not x.is_meta:
+    return ForkNFn.apply(x, n)
+  return (x,) * n
+
+
 def fork(x):
   """(x, x) for two consumers when a gradient will flow back; plain aliases otherwise."""
   if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and not x.is_meta:

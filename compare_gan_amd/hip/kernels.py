@@ -703,6 +703,16 @@ def axpby(a, alpha, b=None, beta=0.0):
     return out
 
 
+def sum4(a, b, c, d=None):
+    """a + b + c (+ d): bf16 tensors of one shape, fp32 sum with one rounding (cg_sum4)."""
+    for t, nm in ((a, "a"), (b, "b"), (c, "c")):
+        _req(t, BF16, nm)
+    _req(d, BF16, "d", True)
+    out = torch.empty_like(a)
+    check(lib().cg_sum4(_p(a), _p(b), _p(c), _p(d), _p(out), a.numel(), _stream()), "cg_sum4")
+    return out
+
+
 def axpby_f32(a, alpha, b=None, beta=0.0):
     _req(a, F32, "a")
     _req(b, F32, "b", True)

@@ -401,6 +401,12 @@ int cg_axpby(const void* a, float alpha, const void* b, float beta, void* out, i
              cgStream stream);
 /* out = alpha*a + beta*b on fp32 (logit + projection term, resnet_biggan.py:423;
  * d_loss += lambda * penalty, modular_gan.py:670).  b may be NULL. */
+/* out = a + b + c (+ d, may be NULL): bf16 tensors of n elements, summed in fp32 with one rounding.
+ * Replaces autograd's accumulation of the gradient of a tensor with three or four consumers -- the
+ * input of the self-attention block, compare_gan/architectures/arch_ops.py:709-758 (theta, phi, g
+ * projections and the residual path). */
+int cg_sum4(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n,
+            cgStream stream);
 int cg_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, int64_t n,
                  cgStream stream);
 /* HOST utility (no device work): CRC32C (Castagnoli) of n bytes, continuing from `seed` (0 for a

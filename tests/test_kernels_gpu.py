@@ -1354,6 +1354,27 @@ def _bf(t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 4])
+def test_fork_n_sums_gradients_in_one_launch(K, dev, n):
+    """Fn.fork_n / cg_sum4: the gradient of a tensor with three or four consumers (the input of the
+    self-attention block, arch_ops.py:709-758) = the fp32 sum of the contributions, rounded once."""
+    from compare_gan_amd.hip import functional as Fn
+    g = _gen(40 + n)
+    x = torch.randn((2, 5, 7, 24), generator=g).to(BF16).to(dev).requires_grad_(True)
+    ws = [torch.randn((2, 5, 7, 24), generator=g).to(BF16).to(dev) for _ in range(n)]
+    parts = Fn.fork_n(x, n)
+    assert len(parts) == n
+    loss = sum((p.float() * w.float()).sum() for p, w in zip(parts, ws))
+    (gx,) = torch.autograd.grad(loss, [x])
+    ref = sum(w.double() for w in ws)
+    assert gx.dtype == BF16
+    assert_close_bf16(gx, ref.cpu(), "fork_n gradient")
+    # direct entry point, ragged tail (not a multiple of 8 elements)
+    a, b, c = (torch.randn(1003, generator=g).to(BF16).to(dev) for _ in range(3))
+    out = K.sum4(a, b, c)
+    assert_close_bf16(out, (a.double() + b.double() + c.double()).cpu(), "sum4 of three")
+
+
 @pytest.mark.parametrize("N,HW,C,mean", [(128, 64, 128, True), (16, 16, 512, True), (6, 16, 1536, False),
                                          (3, 5, 24, False), (2, 4, 2056, True)],
                          ids=["cifar", "resnet5", "biggan", "small_ragged", "wide"])
