@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const void* __restrict__ 
 // Round r of a sweep pairs rows by the circle method; one block per pair.
 __global__ void jacobi_init_kernel(double* __restrict__ v, int d, int* __restrict__ flags) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)d * d) v[i] = (i / d == i % d) ? 1.0 : 0.0;
+  if (v && i < (int64_t)d * d) v[i] = (i / d == i % d) ? 1.0 : 0.0;
   if (i == 0) {
     flags[0] = 0;  // converged
     flags[1] = 0;  // rotations in current sweep
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void bj_apply_kernel(double* __restrict__ g,
   auto grow = [&](int r) -> int64_t { return (int64_t)(r < JB ? P * JB + r : Q * JB + r - JB); };
   for (int e = t; e < JR * JR; e += 256) J[e / JR][e % JR] = jg[(int64_t)blockIdx.x * (JR * JR) + e];
   const int ti = t >> 5, tj = t & 31;
-  const int per = 2 * (d / JCW) / as;            // chunks of this workgroup (G chunks, then V chunks)
+  const int per = (v ? 2 : 1) * (d / JCW) / as;  // chunks of this workgroup (G chunks, then V chunks)
   const int cbeg = blockIdx.y * per, cendc = cbeg + per;
   auto chunk_ptr = [&](int ci) -> double* { return (ci < d / JCW ? g : v); };
   auto chunk_col = [&](int ci) -> int { return (ci < d / JCW ? ci : ci - d / JCW) * JCW; };
@@ -640,11 +640,15 @@ __global__ __launch_bounds__(256) void jacobi_eigvals_kernel(const double* __res
   __shared__ double sm[4];
   const int i = blockIdx.x;
   double s = 0.0;
-  for (int k = threadIdx.x; k < d; k += 256) s += g[(int64_t)i * d + k] * v[(int64_t)i * d + k];
+  if (v) {
+    for (int k = threadIdx.x; k < d; k += 256) s += g[(int64_t)i * d + k] * v[(int64_t)i * d + k];
+  } else {   // without the vectors: |lambda_i| = |g_i| (the singular values)
+    for (int k = threadIdx.x; k < d; k += 256) s += g[(int64_t)i * d + k] * g[(int64_t)i * d + k];
+  }
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) w[i] = sm[0] + sm[1] + sm[2] + sm[3];
+  if (threadIdx.x == 0) w[i] = v ? sm[0] + sm[1] + sm[2] + sm[3] : sqrt(sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
 // ---- inception score ----------------------------------------------------------------------------
@@ -878,7 +882,7 @@ extern "C" size_t cg_syevj_workspace_bytes(int d) {
 
 extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol,
                             void* ws, size_t ws_bytes, cgStream stream) {
-  if (!a || !w || !v || d <= 0 || max_sweeps <= 0)
+  if (!a || !w || d <= 0 || max_sweeps <= 0)
     CG_FAIL(CG_ERR_BAD_ARG, "cg_syevj_f64: bad argument");
   if (!ws || ws_bytes < cg_syevj_workspace_bytes(d))
     CG_FAIL(CG_ERR_WORKSPACE, "cg_syevj_f64: workspace too small");
@@ -892,15 +896,21 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
     const char* e = getenv("CGAMD_JACOBI_BLOCK_MIN");   // smallest d for the block form (0 = off)
     return e ? atoi(e) : 256;
   }();
-  if (block_min > 0 && d >= block_min && d % JCW == 0) {   // whole 64-column chunks, nb even
+  const bool block_form = block_min > 0 && d >= block_min && d % JCW == 0;
+  if (!v && !block_form)
+    CG_FAIL(CG_ERR_UNSUPPORTED, "cg_syevj_f64: values-only (v = NULL) needs d >= %d, d %% %d == 0",
+            block_min, JCW);
+  if (block_form) {   // whole 64-column chunks, nb even
     const int nb = d / JB;   // even
-    static const int split_env = []() {
+    static const int split_env0 = []() {
       const char* e = getenv("CGAMD_JACOBI_SPLIT");   // 0: the fused round kernel (A/B)
       return e ? atoi(e) : 1;
     }();
+    const int split_env = v ? split_env0 : 1;   // (the fused round kernel always carries V)
     const int chunks = d / JCW;
     const int gs = (chunks % 4 == 0) ? 4 : ((chunks % 2 == 0) ? 2 : 1);
-    const int as = (2 * chunks) % 8 == 0 ? 8 : ((2 * chunks) % 4 == 0 ? 4 : 2);
+    const int ac = (v ? 2 : 1) * chunks;        // chunks the apply pass walks: G (and V)
+    const int as = ac % 8 == 0 ? 8 : (ac % 4 == 0 ? 4 : (ac % 2 == 0 ? 2 : 1));
     double* mpart = reinterpret_cast<double*>((char*)ws + 256);
     double* jg = mpart + (size_t)(nb / 2) * 4 * JR * JR;
     int* rot = reinterpret_cast<int*>(jg + (size_t)(nb / 2) * JR * JR);

@@ -1345,12 +1345,15 @@ def fid_combine_f64(sigma, sigma_v, mean, mean_v, sqrt_trace):
     return out
 
 
-def syevj_f64(a, max_sweeps=30, tol=1e-15):
-    """Destroys `a`.  Returns (w [d], v [d,d] with eigenvectors as ROWS)."""
+def syevj_f64(a, max_sweeps=30, tol=1e-15, want_vectors=True):
+    """Destroys `a`.  Returns (w [d], v [d,d] with eigenvectors as ROWS).  want_vectors=False (block
+    form only: d >= 256, d % 64 == 0; otherwise the vectors are computed and dropped): (|w|, None)."""
     _req(a, F64, "a")
     d = a.shape[0]
     w = torch.empty((d,), dtype=F64, device=a.device)
-    v = torch.empty((d, d), dtype=F64, device=a.device)
+    if not want_vectors and not (d >= 256 and d % 64 == 0):
+        want_vectors = True
+    v = torch.empty((d, d), dtype=F64, device=a.device) if want_vectors else None
     ws = _ws(lib().cg_syevj_workspace_bytes(d), a)
     check(lib().cg_syevj_f64(_p(a), d, _p(w), _p(v), int(max_sweeps), float(tol), _p(ws),
                              ws.numel(), _stream()), "cg_syevj_f64")

@@ -40,6 +40,8 @@ def _activations_on_device(acts, device):
 # iteration when both covariances come from more samples than features and it certifies itself (see
 # _sqrt_newton_schulz), the Jacobi eigen-solver otherwise; "jacobi" / "newton" force one (tests).
 _SOLVER = os.environ.get("CGAMD_FID_SOLVER", "auto")
+# the second matrix square root only contributes its TRACE: no eigenvectors (A/B switch, 1 = on)
+_VALUES_ONLY = int(os.environ.get("CGAMD_FID_VALUES_ONLY", "1"))
 _NS_MAX_ITER = 64
 LAST_SOLVER = {"sqrt_sigma": None, "trace_sqrt": None}   # what the last call used (tests, bench)
 LAST_NEWTON = []   # one record per _sqrt_newton_schulz call of the last frechet_distance()
@@ -130,7 +132,7 @@ def frechet_distance(real_activations, generated_activations, device="cuda:0"):
       LAST_SOLVER["trace_sqrt"] = "newton-schulz"
       sqrt_trace = torch.tensor([res[1]], dtype=torch.float64, device=sigma.device)
       return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
-    w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL)
+    w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL, want_vectors=_VALUES_ONLY == 0)
     _, sqrt_trace = K.spectral_sqrt_f64(w2, _EPS, want_values=False)
     return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
   # sqrt(sigma) = V^T diag(f(w)) V  (rows of V are eigenvectors); f and every scalar stay on the
@@ -139,7 +141,7 @@ def frechet_distance(real_activations, generated_activations, device="cuda:0"):
   f, _ = K.spectral_sqrt_f64(w, _EPS)
   sqrt_sigma = K.gemm_f64(v, K.rowscale_f64(v, f), ta=True)
   inner = K.gemm_f64(K.gemm_f64(sqrt_sigma, sigma_v), sqrt_sigma)
-  w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL)
+  w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL, want_vectors=_VALUES_ONLY == 0)
   _, sqrt_trace = K.spectral_sqrt_f64(w2, _EPS, want_values=False)
   return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
 

@@ -663,7 +663,12 @@ int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
  * row of `a`: the null space of a rank-deficient matrix); a sweep without rotations ends the work
  * on the device (the remaining launches return at once), max_sweeps bounds it.  From d = 256
  * (d % 64 == 0) the sweeps run in block form: 32 rows per workgroup, their Gram matrix, one cyclic
- * sweep on it, one pass applying the accumulated rotations.  ws >= cg_syevj_workspace_bytes(d). */
+ * sweep on it, one pass applying the accumulated rotations.  ws >= cg_syevj_workspace_bytes(d).
+ * v = NULL (block form only: d >= 256, d % 64 == 0): no eigenvectors are accumulated (half the
+ * traffic of every apply pass) and w receives the MAGNITUDES |lambda_i| = |g_i| -- the singular
+ * values, which is what the second matrix square root of the Frechet distance consumes
+ * (tfgan's _symmetric_matrix_square_root sums f(s_i) over the SVD of a matrix that is positive
+ * semi-definite up to rounding; metrics/fid_score.py:58-75). */
 size_t cg_syevj_workspace_bytes(int d);
 int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,
                  size_t ws_bytes, cgStream stream);
