@@ -316,12 +316,14 @@ constexpr int THIN_PIX = 4;
 // block = gpb channel groups x ppb pixels (gpb * ppb <= 256): thread -> (pixel slot t / gpb, group
 // blockIdx.y * gpb + t % gpb); iteration i covers the ppb consecutive pixels blockIdx.x * THIN_PIX *
 // ppb + i * ppb ..: the stores of a block iteration are one contiguous span of pixel rows
-__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups, int gpb, int ppb) {
+// `iters` spans of THIN_PIX * ppb pixels per block: the weights of a thread (8 x 16 bytes, 64 conversions)
+// are set up once per block, which at one span cost as much as the span itself
+__global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups, int gpb, int ppb,
+                                                        int iters) {
   const int gl = threadIdx.x % gpb, ps = threadIdx.x / gpb;
   const int g = blockIdx.y * gpb + gl;
   if (g >= groups || ps >= ppb) return;
   const int co = g * 8;
-  const int64_t m0 = (int64_t)blockIdx.x * THIN_PIX * ppb + ps;
   float w[8][8], bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {   // clamped row, zeroed afterwards
@@ -330,16 +332,53 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups,
     for (int k = 0; k < 8; ++k) w[e][k] = co + e < a.Co ? w[e][k] : 0.f;
   }
   vconv_bias8(a, co, bv);
+  for (int it = 0; it < iters; ++it) {
+  const int64_t m0 = ((int64_t)blockIdx.x * iters + it) * THIN_PIX * ppb + ps;
+  if (m0 >= a.M) break;
   // all inputs of the thread's pixels first: unconditional loads from clamped offsets, selected
   // afterwards (the weights of the padding k are zero anyway)
   float x[THIN_PIX][8];
+  if (a.Ci == 3 && !a.gate_in) {   // kernel-uniform
+    // RGB pixels (the 1x1 shortcut of BigGAN's first discriminator block, resnet_biggan.py:372-377): the
+    // 6 bytes of a pixel out of the two aligned dwords that cover them instead of eight 2-byte loads
+    // (342 us for a 402 MB output at batch 512: 1.2 TB/s); the tensor's very last pixel keeps the
+    // element-wise loads (its second dword would end 2 bytes behind the tensor)
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(a.in);
 #pragma unroll
-  for (int i = 0; i < THIN_PIX; ++i) {
-    const int64_t m = min(m0 + (int64_t)i * ppb, (int64_t)a.M - 1);
+    for (int i = 0; i < THIN_PIX; ++i) {
+      const int64_t m = min(m0 + (int64_t)i * ppb, (int64_t)a.M - 2);
+      const int64_t mm = m < 0 ? 0 : m;
+      const int64_t d0 = (mm * 6) >> 2;
+      const uint32_t lo = in32[d0], hi = in32[d0 + 1];
+      const bool odd = ((mm * 6) & 2) != 0;   // pixel starts at the upper half of `lo`
+      const uint32_t c0 = odd ? lo >> 16 : lo & 0xffffu;
+      const uint32_t c1 = odd ? hi & 0xffffu : lo >> 16;
+      const uint32_t c2 = odd ? hi >> 16 : hi & 0xffffu;
+      x[i][0] = __uint_as_float(c0 << 16);
+      x[i][1] = __uint_as_float(c1 << 16);
+      x[i][2] = __uint_as_float(c2 << 16);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float v = vconv_in(a, m * a.Ci + min(k, a.Ci - 1));
-      x[i][k] = k < a.Ci ? v : 0.f;
+      for (int k = 3; k < 8; ++k) x[i][k] = 0.f;
+    }
+    if (m0 + (int64_t)(THIN_PIX - 1) * ppb >= (int64_t)a.M - 1 || a.M < 2) {
+      // a block that touches the last pixel: element-wise for exactly that pixel
+#pragma unroll
+      for (int i = 0; i < THIN_PIX; ++i) {
+        if (m0 + (int64_t)i * ppb == (int64_t)a.M - 1) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) x[i][k] = bf2f(a.in[((int64_t)a.M - 1) * 3 + k]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < THIN_PIX; ++i) {
+      const int64_t m = min(m0 + (int64_t)i * ppb, (int64_t)a.M - 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = vconv_in(a, m * a.Ci + min(k, a.Ci - 1));
+        x[i][k] = k < a.Ci ? v : 0.f;
+      }
     }
   }
 #pragma unroll
@@ -354,6 +393,7 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(GConvArgs a, int groups,
       for (int k = 0; k < 8; ++k) val[e] += x[i][k] * w[e][k];   // Kp == 8, padding is zero
     }
     vconv_store8(a, m, co, val, bv);
+  }
   }
 }
 
@@ -903,8 +943,10 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   if (g->kh == 1 && g->kw == 1 && g->S == 1 && g->U == 1 && g->Ci <= 8 && a.Kp == 8) {
     const int groups = cdiv(g->Co, 8);
     const int gpb = groups < 64 ? groups : 64, ppb = 256 / gpb;
-    dim3 grid(cdiv(a.M, THIN_PIX * ppb), cdiv(groups, gpb));
-    thin_conv_kernel<<<grid, 256, 0, st>>>(a, groups, gpb, ppb);
+    const int spans = cdiv(a.M, THIN_PIX * ppb);
+    const int iters = spans >= 8192 ? 8 : (spans >= 2048 ? 4 : 1);
+    dim3 grid(cdiv(spans, iters), cdiv(groups, gpb));
+    thin_conv_kernel<<<grid, 256, 0, st>>>(a, groups, gpb, ppb, iters);
     CG_CHECK_LAUNCH("cg_gconv(thin)");
     return CG_OK;
   }
