@@ -38,6 +38,11 @@ def parse_args(argv=None):
   p.add_argument("--data_reading_num_threads", type=int, default=64, help="accepted, unused")
   p.add_argument("--use_tpu", type=_flag_bool, nargs="?", const=True, default=None,
                  help="accepted, ignored: the accelerator path (unrolled steps) is always taken")
+  # absl's negative forms of the boolean flags (--nouse_tpu, --nodata_fake_dataset)
+  p.add_argument("--nodata_fake_dataset", dest="data_fake_dataset", action="store_const", const=False,
+                 help=argparse.SUPPRESS)
+  p.add_argument("--nouse_tpu", dest="use_tpu", action="store_const", const=False,
+                 help=argparse.SUPPRESS)
   return p.parse_args(argv)
 
 
@@ -56,6 +61,11 @@ def configure_data(args):
   path = args.tfds_data_dir or os.environ.get("CGAMD_DATA_DIR") or None
   if args.data_fake_dataset:
     path = None
+  elif args.data_fake_dataset is False and path is None:
+    # the reference would read the real dataset here; silently training on noise instead would be a
+    # different experiment
+    raise SystemExit("--data_fake_dataset=false needs a data directory (--tfds_data_dir or "
+                     "CGAMD_DATA_DIR): there is no network to fetch datasets from")
   datasets.use_data_dir(path, shuffle_buffer_size=args.data_shuffle_buffer_size)
   return path
 

@@ -107,17 +107,26 @@ class TaskManager(object):
     for p in os.listdir(self.model_dir):
       if not p.startswith("model.ckpt-"):
         continue
-      if p.endswith(".pt"):
-        found[_step_of(p)] = os.path.join(self.model_dir, p)
-      elif p.endswith(".index"):
-        found.setdefault(_step_of(p[:-len(".index")]), os.path.join(self.model_dir, p[:-len(".index")]))
+      try:   # (a stray `model.ckpt-best.pt` / `model.ckpt-7_temp.index` is not a checkpoint of a step)
+        if p.endswith(".pt"):
+          found[_step_of(p)] = os.path.join(self.model_dir, p)
+        elif p.endswith(".index"):
+          found.setdefault(_step_of(p[:-len(".index")]),
+                           os.path.join(self.model_dir, p[:-len(".index")]))
+      except ValueError:
+        continue
     return [found[k] for k in sorted(found)]
 
-  def unevaluated_checkpoints(self, timeout=0, eval_every_steps=None, poll_seconds=60):
+  WAIT = "<wait>"   # yielded instead of sleeping (yield_waits): nothing new yet, poll again later
+
+  def unevaluated_checkpoints(self, timeout=0, eval_every_steps=None, poll_seconds=60,
+                              yield_waits=False):
     """Generator for checkpoints without evaluation results (runner_lib.py:137-180): ascending by
     step; with eval_every_steps only steps > 0 divisible by it; with timeout > 0 it keeps polling
     the directory (every poll_seconds) until no new checkpoint has appeared for `timeout` seconds or
-    training is marked done -- the continuous-evaluation schedule."""
+    training is marked done -- the continuous-evaluation schedule.  yield_waits: between polls the
+    generator yields TaskManager.WAIT instead of sleeping itself, so that a multi-rank caller can
+    keep every collective short (the other ranks must not sit in a broadcast for hours)."""
     evaluated = set(self.get_checkpoints_with_results())
     last_eval = time.time()
     while True:
@@ -132,7 +141,10 @@ class TaskManager(object):
         continue
       if time.time() - last_eval > timeout or self.is_training_done():
         break
-      time.sleep(poll_seconds)
+      if yield_waits:
+        yield self.WAIT
+      else:
+        time.sleep(poll_seconds)
 
 
 class TaskManagerWithCsvResults(TaskManager):
@@ -326,11 +338,17 @@ def run_with_schedule(schedule, run_config, task_manager, options, use_tpu=False
     if tpu_ops.replica_id() == 0:
       pending = iter(task_manager.unevaluated_checkpoints(
           timeout=_CONTINUOUS_EVAL_TIMEOUT_S if schedule == "continuous_eval" else 0,
-          eval_every_steps=every, poll_seconds=_CONTINUOUS_EVAL_POLL_S))
+          eval_every_steps=every, poll_seconds=_CONTINUOUS_EVAL_POLL_S, yield_waits=True))
     while True:
+      # every broadcast is short: while rank 0 has nothing new it hands out a WAIT token and ALL ranks
+      # sleep one poll interval outside any collective (a rank parked in a broadcast for longer than
+      # the process group's timeout -- 10 minutes on RCCL -- would be killed by its watchdog)
       checkpoint_path = _broadcast_from_rank0(next(pending, None) if pending is not None else None)
       if checkpoint_path is None:
         break
+      if checkpoint_path == TaskManager.WAIT:
+        time.sleep(_CONTINUOUS_EVAL_POLL_S)
+        continue
       _run_eval(gan, checkpoint_path, task_manager, options, num_eval_averaging_runs, device)
   _barrier()    # nobody tears the process group down while another rank still works
   return gan

@@ -76,6 +76,20 @@ def test_task_manager_polls_for_new_checkpoints(tmp_path):
     tm2 = runner_lib.TaskManager(str(tmp_path / "m2"))
     assert list(tm2.unevaluated_checkpoints(timeout=0.3, poll_seconds=0.05)) == []
     assert 0.25 <= time.time() - t0 < 5.0
+    # yield_waits (the multi-rank caller): the generator never sleeps itself -- it hands out
+    # WAIT tokens between polls, so that rank 0 can keep every broadcast short; stray file names that
+    # do not end in a step number are skipped instead of aborting the poll
+    tm3 = runner_lib.TaskManager(str(tmp_path / "m3"))
+    only = _touch_ckpt(tm3.model_dir, 3)
+    open(os.path.join(tm3.model_dir, "model.ckpt-best.pt"), "w").close()
+    open(os.path.join(tm3.model_dir, "model.ckpt-7_temp.index"), "w").close()
+    gen = tm3.unevaluated_checkpoints(timeout=30, poll_seconds=60, yield_waits=True)
+    t0 = time.time()
+    assert next(gen) == only
+    assert next(gen) == runner_lib.TaskManager.WAIT and next(gen) == runner_lib.TaskManager.WAIT
+    assert time.time() - t0 < 5.0            # (poll_seconds = 60 was never slept)
+    tm3.mark_training_done()
+    assert list(gen) == []
 
 
 def test_schedule_validation(tmp_path):
@@ -248,3 +262,9 @@ def test_main_accepts_the_reference_flags():
         datasets._SOURCE.update(saved)     # pylint: disable=protected-access
     with pytest.raises(SystemExit):
         main.parse_args(["--model_dir", "/tmp/x", "--use_tpu=maybe"])
+    # absl's negative forms, and an explicit "real data" request without a data directory
+    c = main.parse_args(["--model_dir", "/tmp/x", "--nouse_tpu", "--nodata_fake_dataset"])
+    assert c.use_tpu is False and c.data_fake_dataset is False
+    if not os.environ.get("CGAMD_DATA_DIR"):
+        with pytest.raises(SystemExit):
+            main.configure_data(c)
