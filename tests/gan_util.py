@@ -155,20 +155,35 @@ class stepwise_parity(object):
     Before every sub-step the oracle takes over the product's complete state (resync_oracle) and
     runs the same sub-step (oracle/modular_gan.py train_step, taken apart); finish() compares:
       d_losses / g_loss      relative tol_loss (default 2e-3; measured <= 3e-4)
-      the discriminator's update of every sub-step  cosine >= cos_min (default 0.98; measured
-      >= 0.9906), the generator's >= cos_min_g (default 0.95; measured 0.979 at batch 8: its biases
-      in front of a batch norm have a mathematically zero gradient, so their sign-like first
-      update is decided by rounding on either side),
+      the GRADIENT of every sub-step -- recovered from the product's first-moment slots, g = (m_after -
+      beta1 m_before) / (1 - beta1), the states being identical before the sub-step -- against the
+      oracle's: cosine >= cos_grad (default 0.999 for BOTH networks; measured >= 0.99969 D, 0.99998 G).  This is the
+      magnitude-weighted check a 2 % direction error of a kernel cannot pass (VERDICT r05 weak 2);
+      the UPDATE of every sub-step: cosine >= cos_min (discriminator, default 0.98; measured >= 0.9906)
+      / cos_min_g (generator, default 0.95; measured 0.979).  Adam's first update is lr * sign(g) for
+      every element, so this cosine is 1 - 2 x (share of elements whose gradient SIGN differs), i.e. a
+      count of coin flips among the small-gradient elements: round 5 blamed the generator's 0.979 on
+      the biases in front of a batch norm (mathematically zero gradient); masking every element whose
+      oracle gradient is below 1e-4 of the network's rms (0.2 % of G) moves it from 0.97879 to 0.97919
+      only -- the flips are spread over ~1 % of ALL elements, which is what bf16 kernels against an
+      fp64 restatement with bf16 storage give.  Kept as a sanity band; the gradient cosine is the test,
       and per element |update_p - update_o| <= 3.5 lr (opposite signs of a ~0 gradient)."""
 
-    def __init__(self, gan, ora, subs, lr_d, lr_g=None, tol_loss=2e-3, cos_min=0.98, cos_min_g=0.95):
+    def __init__(self, gan, ora, subs, lr_d, lr_g=None, tol_loss=2e-3, cos_min=0.98, cos_min_g=0.95,
+                 cos_grad=0.999):
         self.gan, self.ora, self.subs = gan, ora, subs
         self.lr_d, self.lr_g = lr_d, lr_g if lr_g is not None else lr_d
         self.tol_loss, self.cos_min, self.cos_min_g = tol_loss, cos_min, cos_min_g
+        self.cos_grad = cos_grad
         self.d_o, self.g_o = [], None
-        self.pending = None      # (net, names, before, oracle_after) of the sub-step in flight
+        self.pending = None      # (net, names, before, oracle_after, lr, oracle grads) in flight
         self.rows = []
         self._joint = None
+
+    @staticmethod
+    def _m_before(popt, names):
+        idx = {n: i for i, n in enumerate(popt.names)}
+        return {n: popt.m[idx[n]].detach().cpu().double().clone() for n in names}
 
     def _names(self, net):
         return [n for n, _ in self.gan.store.trainable_variables(net)]
@@ -176,17 +191,25 @@ class stepwise_parity(object):
     def _close(self):
         if self.pending is None:
             return
-        net, names, before, after_o, lr = self.pending
-        ups, uos = [], []
+        net, names, before, after_o, lr, grads_o, m_before = self.pending
+        popt = self.gan.g_opt if net == "generator" else self.gan.d_opt
+        idx = {n: i for i, n in enumerate(popt.names)}
+        beta1 = float(popt.opt.beta1)
+        ups, uos, gos, gps = [], [], [], []
         for n in names:
             up = self.gan.store.vars[n].detach().cpu().double() - before[n]
             uo = after_o[n] - before[n]
             assert float((up - uo).abs().max()) <= 2.2 * lr * 1.6, (net, n, float((up - uo).abs().max()) / lr)
             ups.append(up.reshape(-1))
             uos.append(uo.reshape(-1))
+            gos.append(grads_o[n].reshape(-1))
+            m_after = popt.m[idx[n]].detach().cpu().double()
+            gps.append(((m_after - beta1 * m_before[n]) / (1.0 - beta1)).reshape(-1))
         c = cosine(torch.cat(ups), torch.cat(uos))
-        self.rows.append((net, c))
+        cg = cosine(torch.cat(gps), torch.cat(gos))
+        self.rows.append((net, c, cg))
         floor = self.cos_min_g if net == "generator" else self.cos_min
+        assert cg >= self.cos_grad, "gradient of the %s: cosine %.5f" % (net, cg)
         assert c >= floor, "update of the %s: cosine %.5f" % (net, c)
         self.pending = None
 
@@ -209,22 +232,29 @@ class stepwise_parity(object):
                     generated = ora.G(s["z"], sy)
             d_loss, _, _ = ora.create_loss(s["images"], generated, s.get("labels"),
                                            s.get("sampled_labels"), s.get("alpha"))
-            ora.d_opt.step(torch.autograd.grad(d_loss, ora.d_vars()))
+            dgr = torch.autograd.grad(d_loss, ora.d_vars())
+            grads_o = {n: g.detach().double() for n, g in zip(ora.d_var_names(), dgr)}
+            ora.d_opt.step(dgr)
             ora.global_step_disc += 1
             self.d_o.append(float(d_loss.detach()))
             after = {n: ora.vs.vars[n].detach().double().clone() for n in names}
-            self.pending = ("discriminator", names, before, after, self.lr_d)
+            self.pending = ("discriminator", names, before, after, self.lr_d, grads_o,
+                            self._m_before(gan.d_opt, names))
         else:
             names = self._names("generator")
             before = {n: gan.store.vars[n].detach().cpu().double().clone() for n in names}
             generated = ora.G(s["z"], sy)
             _, g_loss, _ = ora.create_loss(s["images"], generated, s.get("labels"),
                                            s.get("sampled_labels"), with_penalty=False)
-            ora.g_opt.step(torch.autograd.grad(g_loss, ora.g_vars()))
+            ggr = torch.autograd.grad(g_loss, ora.g_vars())
+            gnames = [n for n in ora.vs.trainable if n.startswith("generator")]
+            grads_o = {n: g.detach().double() for n, g in zip(gnames, ggr)}
+            ora.g_opt.step(ggr)
             ora.global_step += 1
             self.g_o = float(g_loss.detach())
             after = {n: ora.vs.vars[n].detach().double().clone() for n in names}
-            self.pending = ("generator", names, before, after, self.lr_g)
+            self.pending = ("generator", names, before, after, self.lr_g, grads_o,
+                            self._m_before(gan.g_opt, names))
 
     def finish(self, out):
         """out: what train_step() returned.  Returns (d_losses oracle, g_loss oracle)."""
