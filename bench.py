@@ -396,6 +396,10 @@ def main():
         result["calibration"] = {
             "mfma_bf16_tflops": round(calib["mfma_bf16_tflops"], 1),
             "hbm_copy_gbs": round(calib["hbm_copy_gbs"], 1),
+            # the same MFMA loop on zero operands (clock not power-capped), and an
+            # 8192^3 GEMM through this library's own convolution main loop (1x1 convolution)
+            "mfma_zero_tflops": round(calib["mfma_zero_tflops"], 1),
+            "gemm_tflops": round(calib["gemm_tflops"], 1),
             # DERIVED, not read: 1024 SIMDs x 1024 FLOP per cycle (one 32x32x16 MFMA per 32 cycles
             # and SIMD) -> the shader clock at which back-to-back MFMA issue gives this rate.  The
             # 2.5 PFLOP/s datasheet peak is that arithmetic at 2.4 GHz; the sysfs clock table of the

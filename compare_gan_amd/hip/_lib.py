@@ -73,6 +73,7 @@ SIGNATURES = {
     "cg_layer_norm_bwd_bwd_workspace_bytes": (c_sz, [c_int, c_int]),
     "cg_layer_norm_bwd_bwd": (c_int, [vp, vp, vp, vp, vp, vp, c_int, c_i64, c_int, vp, vp, vp, vp, c_sz, vp]),
     "cg_calib_mfma_bf16": (c_int, [c_int, c_int, vp, ctypes.POINTER(c_f64), vp]),
+    "cg_calib_mfma_bf16_zero": (c_int, [c_int, c_int, vp, ctypes.POINTER(c_f64), vp]),
     "cg_calib_copy": (c_int, [vp, vp, c_sz, vp]),
     "cg_prof_family_count": (c_int, []),
     "cg_prof_family_name": (ctypes.c_char_p, [c_int]),

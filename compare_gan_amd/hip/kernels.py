@@ -1419,8 +1419,29 @@ def calibrate(device, mfma_ms=50.0, copy_mb=1024):
     torch.cuda.synchronize()
     t_m = ev[0].elapsed_time(ev[1]) * 1e-3
     t_c = ev[2].elapsed_time(ev[3]) * 1e-3
-    return {"mfma_bf16_tflops": fl.value / t_m / 1e12, "mfma_ms": t_m * 1e3,
-            "hbm_copy_gbs": 4 * 2.0 * n / t_c / 1e9, "copy_mb": int(copy_mb)}
+    out = {"mfma_bf16_tflops": fl.value / t_m / 1e12, "mfma_ms": t_m * 1e3,
+           "hbm_copy_gbs": 4 * 2.0 * n / t_c / 1e9, "copy_mb": int(copy_mb)}
+    del src, dst
+    # (1) the same MFMA loop on ZERO operands; (2) what this library's own main loop reaches on a
+    # plain GEMM: 8192 x 8192 x 8192 as a 1x1 convolution (8192 pixels, 8192 -> 8192 channels)
+    fz = ctypes.c_double(0.0)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    check(lib().cg_calib_mfma_bf16_zero(2048, int(iters), _p(sink), ctypes.byref(fz), _stream()),
+          "cg_calib_mfma_bf16_zero")
+    e[1].record()
+    geom = geom_conv_same(8, 32, 32, 8192, 8192, 1, 1, 1, 1)
+    x = torch.randn(8, 32, 32, 8192, device=device).to(BF16)
+    w = (torch.randn(8192, 8192, device=device) * 0.01).to(BF16).reshape(8192, 8192)   # [Co][K] image
+    gconv(geom, x, w)
+    e[2].record()
+    for _ in range(3):
+        gconv(geom, x, w)
+    e[3].record()
+    torch.cuda.synchronize()
+    out["mfma_zero_tflops"] = fz.value / (e[0].elapsed_time(e[1]) * 1e-3) / 1e12
+    out["gemm_tflops"] = 3 * 2.0 * 8192.0 ** 3 / (e[2].elapsed_time(e[3]) * 1e-3) / 1e12
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

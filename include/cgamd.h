@@ -63,6 +63,9 @@ int cg_prof_collect(int family, double* total_ms, int64_t* launches, double* flo
  * 8 independent MFMAs per wave on random operands; *flops = what the launch executes) and a float4
  * copy of `bytes` (multiple of 16) bytes.  The caller times them with stream events. */
 int cg_calib_mfma_bf16(int blocks, int iters, float* sink, double* flops, cgStream stream);
+/* The same loop on all-zero operands (bench.py `calibration.mfma_zero_tflops`): the chip holds a higher
+ * clock under it, which tells a power-capped clock from a loop that is not tight. */
+int cg_calib_mfma_bf16_zero(int blocks, int iters, float* sink, double* flops, cgStream stream);
 int cg_calib_copy(const void* src, void* dst, size_t bytes, cgStream stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -264,4 +264,8 @@ class stepwise_parity(object):
         for i, (a, b) in enumerate(zip(d_p, self.d_o)):
             assert abs(a - b) <= self.tol_loss * max(1.0, abs(b)), ("d_loss", i, a, b)
         assert abs(g_p - self.g_o) <= self.tol_loss * max(1.0, abs(self.g_o)), ("g_loss", g_p, self.g_o)
+        # state carried between the sub-steps: the step counters after the whole step (the Adam slots
+        # are covered by the recovered gradients above)
+        assert int(self.gan.global_step.item()) == self.ora.global_step, "global_step"
+        assert int(self.gan.global_step_disc.item()) == self.ora.global_step_disc, "global_step_disc"
         return self.d_o, self.g_o
