@@ -498,6 +498,9 @@ def main():
             ("resnet128_dstep", "resnet_lsun-bedroom128.gin", ("penalty.fn = @no_penalty",), 64,
              "dstep", 20, 3, 3.53),
             ("resnet128_dstep_gp", "resnet_lsun-bedroom128.gin", (), 64, "dstep", 10, 2, None),
+            # C4 of BASELINE.json as written: resnet_lsun-bedroom128.gin, the whole unrolled step (5 D
+            # sub-steps with the WGAN-GP double backward + 1 G sub-step) at 32 per GPU
+            ("resnet_lsun128_step", "resnet_lsun-bedroom128.gin", (), 32, "step", 6, 2, None),
             # one BigGAN-128 iteration (2 D + 1 G) ~ 0.6 TFLOP per image of batch
             ("biggan128", "biggan_imagenet128.gin", (), args.biggan_batch, "step", 4, 2, None),
             # C5 of BASELINE.json: global batch 2048 on 8 GPUs = 256 per GPU
@@ -567,8 +570,8 @@ def main():
             result["fid10k_cold_start_s"] = f["cold_start_s"]
             result["fid10k_split_s"] = f["split_s"]
         # ... and so do the north-star legs (they sat mid-line and were cut off)
-        for key in ("resnet128_dstep", "resnet128_dstep_gp", "biggan128", "biggan128_bs256",
-                    "sndcgan128"):
+        for key in ("resnet128_dstep", "resnet128_dstep_gp", "resnet_lsun128_step", "biggan128",
+                    "biggan128_bs256", "sndcgan128"):
             leg = result.get(key)
             if isinstance(leg, dict) and "ms" in leg:
                 result[key + "_ms"] = leg["ms"]

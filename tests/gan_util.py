@@ -123,7 +123,8 @@ def resync_oracle(gan, ora):
     free-running comparison of later steps meaningless."""
     with torch.no_grad():
         for name, v in gan.store.vars.items():
-            ora.vs.vars[name].copy_(v.detach().to("cpu").to(ora.vs.vars[name].dtype))
+            ov = ora.vs.vars[name]
+            ov.copy_(v.detach().to(ov.device).to(ov.dtype))
     ora._ensure_opts()   # pylint: disable=protected-access
     pairs = ((gan.g_opt, ora.g_opt, [n for n in ora.vs.trainable if n.startswith("generator")]),
              (gan.d_opt, ora.d_opt, ora.d_var_names()))
@@ -131,8 +132,8 @@ def resync_oracle(gan, ora):
         idx = {n: i for i, n in enumerate(popt.names)}
         with torch.no_grad():
             for j, n in enumerate(onames):
-                oopt.m[j].copy_(popt.m[idx[n]].detach().cpu().to(oopt.m[j].dtype))
-                oopt.v[j].copy_(popt.v[idx[n]].detach().cpu().to(oopt.v[j].dtype))
+                oopt.m[j].copy_(popt.m[idx[n]].detach().to(oopt.m[j].device).to(oopt.m[j].dtype))
+                oopt.v[j].copy_(popt.v[idx[n]].detach().to(oopt.v[j].device).to(oopt.v[j].dtype))
     ora.g_opt.t = ora.global_step = int(gan.global_step.item())
     ora.d_opt.t = ora.global_step_disc = int(gan.global_step_disc.item())
 
@@ -198,11 +199,11 @@ class stepwise_parity(object):
         ups, uos, gos, gps = [], [], [], []
         for n in names:
             up = self.gan.store.vars[n].detach().cpu().double() - before[n]
-            uo = after_o[n] - before[n]
+            uo = after_o[n].cpu() - before[n]
             assert float((up - uo).abs().max()) <= 2.2 * lr * 1.6, (net, n, float((up - uo).abs().max()) / lr)
             ups.append(up.reshape(-1))
             uos.append(uo.reshape(-1))
-            gos.append(grads_o[n].reshape(-1))
+            gos.append(grads_o[n].cpu().reshape(-1))
             m_after = popt.m[idx[n]].detach().cpu().double()
             gps.append(((m_after - beta1 * m_before[n]) / (1.0 - beta1)).reshape(-1))
         c = cosine(torch.cat(ups), torch.cat(uos))

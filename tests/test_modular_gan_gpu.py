@@ -298,6 +298,45 @@ def test_resnet128_d_substep_at_the_benchmark_batch(dev, penalty):
     print("resnet128 D sub-step bs64 worst grad cosine", w)
 
 
+def test_train_step_resnet_lsun128(dev):
+    """resnet_lsun-bedroom128.gin AS WRITTEN (BASELINE.json configs[3]; bench.py leg
+    `resnet_lsun128_step`): one whole unrolled train_step() -- five discriminator sub-steps with the
+    WGAN-GP double backward (penalty_lib.py:59-82, modular_gan.py:512-604) and one generator sub-step --
+    against the bf16-storage oracle SUB-STEP BY SUB-STEP from identical states (U.stepwise_parity: losses,
+    the gradient recovered from the Adam slots, the update, the step counters).  Batch 8, the oracle
+    resident on the device (fp64 per-tap GEMMs in plain torch; on the CPU the six double-backward
+    sub-steps at 128 x 128 take many minutes).  The penalty's interpolation coefficients are the
+    product's own Philox stream (penalty_lib.alpha_name per sub-step)."""
+    from compare_gan_amd.gans import penalty_lib
+    config = "resnet_lsun-bedroom128.gin"
+    bsz = 8
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=SEED)
+    assert options["disc_iters"] == 5
+    ora = U.build_oracle(config, U.mirror_to_oracle(gan, emulate_bf16=True, device=dev))
+    nsub = options["disc_iters"] + 1
+    rng = np.random.RandomState(321)
+    images = rng.uniform(size=(nsub * bsz,) + tuple(dataset.image_shape)).astype(np.float32)
+    labels = np.ones((nsub * bsz,), dtype=np.int32)
+    subs = [{"images": torch.from_numpy(images[i * bsz:(i + 1) * bsz]).double().to(dev),
+             "z": U.host_uniform((bsz, options["z_dim"]), "z/%d" % i, -1.0, 1.0, SEED, 0).double().to(dev),
+             "alpha": U.host_uniform((bsz,), penalty_lib.alpha_name(i), 0.0, 1.0, SEED, 0).double().to(dev)}
+            for i in range(nsub)]
+    # measured (round 6, batch 8): losses within 3e-4, gradient cosines >= 0.9990 (D, through the
+    # double backward) / 0.99996 (G), update cosines >= 0.985 / 0.991
+    check = U.stepwise_parity(gan, ora, subs, lr_d=1e-4, lr_g=1e-4, cos_grad=0.998, cos_min=0.97,
+                              cos_min_g=0.88)
+    gan.sub_step_hook = check
+    try:
+        out = gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+    finally:
+        gan.sub_step_hook = None
+    d_o, g_o = check.finish(out)
+    print("lsun128 step d", [float(x) for x in out["d_losses"]], d_o, "g", float(out["g_loss"]), g_o,
+          "cosines (update, gradient)", [(r[0][0], round(r[1], 5), round(r[2], 5)) for r in check.rows])
+    assert len(check.rows) == nsub
+    assert int(gan.global_step.item()) == 1 and int(gan.global_step_disc.item()) == 5
+
+
 def test_wgangp_step_with_layer_norm(dev):
     """resnet_lsun-bedroom128.gin with `D.layer_norm = True` -- the pairing layer norm exists for
     (resnet_ops.py:162-173 under penalty_lib.py:59-82): Wasserstein loss + gradient penalty at
