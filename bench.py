@@ -478,6 +478,11 @@ def main():
                                "included: cold_start_s, one untimed 128-image evaluation before it "
                                "(first use of every kernel of the evaluation path)",
             "split_s": {k: round(v, 3) for k, v in eval_gan_lib.LAST_TIMING.items()},
+            # which symmetric-square-root path the statistics took (metrics/fid_score.py: the GEMM-only
+            # Newton-Schulz iteration when it certifies itself, the Jacobi eigen-solver otherwise)
+            "sqrt_solver": dict(fid_lib.LAST_SOLVER),
+            "newton_schulz": [{k: (float("%.4g" % v) if isinstance(v, float) else v)
+                               for k, v in rec.items()} for rec in fid_lib.LAST_NEWTON],
             "fid": round(float(res["fid_score_mean"]), 4),
             "inception_score": round(float(res["inception_score_mean"]), 4),
             "note": "synthetic reference images; seeded (untrained) Inception weights, the trained "

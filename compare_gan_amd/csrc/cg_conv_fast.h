@@ -10,6 +10,14 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
                          const void* gate_out, float slope_out, const void* residual,
                          hipStream_t st);
 
+// the same kernels on channel slices: consecutive pixels of the input / output are in_ld / out_ld
+// elements apart (>= Ci / Co, multiples of 8; the gate / residual tensors, if any, share out's pitch)
+bool cg_fast_conv_ld_supported(const cgConvGeom* g, int in_ld, int out_ld);
+void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, const void* bt, void* out,
+                            int out_ld, int out_is_f32, const float* bias, const void* gate_in,
+                            const void* gate_out, float slope_out, const void* residual,
+                            hipStream_t st);
+
 // halo-staged kernel for unit-stride <= 3x3 filters on >= 16x16 maps (cg_conv_halo.hip)
 bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in);
 bool cg_hconv_narrow(const cgConvGeom* g);   // Co < 8: scalar epilogue, no gate tensor / residual

@@ -79,6 +79,8 @@ struct FastConvArgs {
   const bf16_t* residual;
   int N, Hin, Win, Ci, Ho, Wo, Co, kh, kw, S, U, pt, pl;
   int Kp;
+  int in_ld, out_ld;  // elements between consecutive pixels of the input / output (Ci / Co when dense;
+                      // wider when the tensor is a channel slice of a concatenation, cg_gconv_ld)
   int Hp, Wp, Mp;  // per-phase output grid (Ho/U, Wo/U) and N*Hp*Wp
   int cblocks;     // Ci / 64
   int mtiles, ntiles;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
     const int ohp = (int)(t1 - n * a.Hp);
     a_ih[j] = (a.U == 2) ? ohp + bh : ohp * a.S + bh;
     a_iw[j] = (a.U == 2) ? owp + bw : owp * a.S + bw;
-    a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.Ci + c * 8;
+    a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.in_ld + c * 8;
   }
   int b_off[BJ], b_c8[BJ];
   bool b_ok[BJ];
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
   // tap iteration state of the NEXT slice to stage (all scalar)
   int st_ri = 0, st_si = 0, st_cb = 0;
   auto stage = [&](int buf) {
-    const int tapoff = (st_ri * a.Win + st_si) * a.Ci + st_cb * 64;
+    const int tapoff = (st_ri * a.Win + st_si) * a.in_ld + st_cb * 64;
     const int koff = ((r0 + a.U * st_ri) * a.kw + (s0 + a.U * st_si)) * a.Ci + st_cb * 64;
     bf16_t* Ab = Abuf(buf) + (wave * AJ) * 512;
     bf16_t* Bb = Bbuf(buf) + (wave * BJ) * 512;
@@ -239,6 +241,34 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
   const int arow0 = (wm * (BM / WM) + frow) * 64;
   const int brow0 = (wn * (BN / WN) + frow) * 64;
 
+  // two of the four 16-channel MFMA steps of a K-slice.  A channel count that is an odd multiple of
+  // 32 (Inception: 32 / 96 / 160 / 288; BigGAN: 96) leaves the upper half of its LAST 64-channel
+  // block empty: the slice still stages 128-byte rows (zero page), its upper two steps are skipped
+  // (wave-uniform: the consumer's channel-block counter c_cb is scalar)
+  auto mma2 = [&](const bf16_t* Ab, const bf16_t* Bb, int k0) {
+#pragma unroll
+    for (int kk = k0; kk < k0 + 2; ++kk) {
+      bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
+        if (RELU) af[i] = relu_bf16x8(af[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  const bool ragged_k = (a.Ci & 63) != 0;
+  int c_cb = 0;   // channel block of the slice being consumed
+  auto half_slice = [&]() { return ragged_k && c_cb == a.cblocks - 1; };
+  auto next_slice = [&]() { if (++c_cb == a.cblocks) c_cb = 0; };
+
   int staged = 0;
   TSTAMP();   // 1: descriptors done
   for (; staged < D && staged < nk; ++staged) stage(staged % NS);
@@ -251,23 +281,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
       __syncthreads();
       const bf16_t* Ab = Abuf(0);
       const bf16_t* Bb = Bbuf(0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
-          if (RELU) af[i] = relu_bf16x8(af[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
+      mma2(Ab, Bb, 0);
+      if (!half_slice()) mma2(Ab, Bb, 2);
+      next_slice();
       __syncthreads();
     }
   } else
@@ -289,23 +305,9 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
     const int buf = it % NS;
     const bf16_t* Ab = Abuf(buf);
     const bf16_t* Bb = Bbuf(buf);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
-        if (RELU) af[i] = relu_bf16x8(af[i]);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+    mma2(Ab, Bb, 0);
+    if (!half_slice()) mma2(Ab, Bb, 2);
+    next_slice();
     TSTAMP();   // 6 + 4 it: MFMA work of the slice issued
   }
   TSTAMP();     // 3 + 4 nk: loop done
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
         const uint32_t n = fdiv(t1, a.dHp);
         const int ohp = (int)t1 - (int)n * a.Hp;
         const int64_t o =
-            ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + co;
+            ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.out_ld + co;
         const float4 lo = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8);
         const float4 hi = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8 + 4);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
     const uint32_t n = fdiv(t1, a.dHp);
     const int ohp = (int)t1 - (int)n * a.Hp;
     const int64_t opix =
-        ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co;
+        ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.out_ld;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
     const int ohp = (int)(t1 - n * a.Hp);
     a_ih[j] = (a.U == 2) ? ohp + bh : ohp * a.S + bh;
     a_iw[j] = (a.U == 2) ? owp + bw : owp * a.S + bw;
-    a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.Ci + c * 8;
+    a_off[j] = (((int)n * a.Hin + a_ih[j]) * a.Win + a_iw[j]) * a.in_ld + c * 8;
   }
   int b_off[BJ], b_c8[BJ];
   bool b_ok[BJ];
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
     }
   };
   auto stage = [&](int buf) {
-    const int tapoff = (st_ri * a.Win + st_si) * a.Ci + st_cb * 64;
+    const int tapoff = (st_ri * a.Win + st_si) * a.in_ld + st_cb * 64;
     const int koff = ((r0 + a.U * st_ri) * a.kw + (s0 + a.U * st_si)) * a.Ci + st_cb * 64;
     bf16_t* Ab = Abuf(buf) + (wave * AJ) * 512;
     bf16_t* Bb = Bbuf(buf) + (wave * BJ) * 512;
@@ -610,6 +612,30 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
   const int arow0 = (wm * (BM / WM) + frow) * 64;
   const int brow0 = (wn * (BN / WN) + frow) * 64;
 
+  // (see fast_conv_kernel: the empty upper half of a ragged last channel block is skipped)
+  auto mma2 = [&](const bf16_t* Ab, const bf16_t* Bb, int k0) {
+#pragma unroll
+    for (int kk = k0; kk < k0 + 2; ++kk) {
+      bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
+        if (RELU) af[i] = relu_bf16x8(af[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  const bool ragged_k = (a.Ci & 63) != 0;
+  int c_cb = kg;   // channel block of this group's slice being consumed (slices kg, kg + 2, ...)
+  while (c_cb >= a.cblocks) c_cb -= a.cblocks;
+
   int staged = 0;
   for (; staged < D && staged < nk; ++staged) stage(staged % NS);
 
@@ -629,23 +655,10 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
     const int buf = it % NS;
     const bf16_t* Ab = Abuf(buf);
     const bf16_t* Bb = Bbuf(buf);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + arow0 + i * 32 * 64 + koffs[kk]);
-        if (RELU) af[i] = relu_bf16x8(af[i]);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + brow0 + j * 32 * 64 + koffs[kk]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+    mma2(Ab, Bb, 0);
+    if (!(ragged_k && c_cb == a.cblocks - 1)) mma2(Ab, Bb, 2);
+    c_cb += 2;                                  // this group's next slice is two further on
+    while (c_cb >= a.cblocks) c_cb -= a.cblocks;
   }
 
   // ---- group 1 -> group 0: accumulators through group 1's ring, one float per thread per register
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
         const uint32_t n = fdiv(t1, a.dHp);
         const int ohp = (int)t1 - (int)n * a.Hp;
         const int64_t o =
-            ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co + co;
+            ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.out_ld + co;
         const float4 lo = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8);
         const float4 hi = *reinterpret_cast<const float4*>(Cs + row * LDC + c8 * 8 + 4);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -763,7 +776,7 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
     const uint32_t n = fdiv(t1, a.dHp);
     const int ohp = (int)t1 - (int)n * a.Hp;
     const int64_t opix =
-        ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.Co;
+        ((int64_t)((int)n * a.Ho + ohp * a.U + ph) * a.Wo + (owp * a.U + pw)) * a.out_ld;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -2169,7 +2182,24 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
                          int out_is_f32, const float* bias, const void* gate_in,
                          const void* gate_out, float slope_out, const void* residual,
                          hipStream_t st) {
+  cg_fast_conv_launch_ld(g, in, g->Ci, bt, out, g->Co, out_is_f32, bias, gate_in, gate_out, slope_out,
+                         residual, st);
+}
+
+bool cg_fast_conv_ld_supported(const cgConvGeom* g, int in_ld, int out_ld) {
+  if (in_ld < g->Ci || out_ld < g->Co || (in_ld % 8) != 0 || (out_ld % 8) != 0 || (g->Co % 8) != 0)
+    return false;
+  if ((int64_t)g->N * g->Hin * g->Win * in_ld >= (1ll << 31)) return false;
+  return cg_fast_conv_supported(g, nullptr, nullptr, 0.f);
+}
+
+void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, const void* bt, void* out,
+                            int out_ld, int out_is_f32, const float* bias, const void* gate_in,
+                            const void* gate_out, float slope_out, const void* residual,
+                            hipStream_t st) {
   FastConvArgs a;
+  a.in_ld = in_ld;
+  a.out_ld = out_ld;
   a.in = (const bf16_t*)in;
   a.bt = (const bf16_t*)bt;
   a.out = out;
@@ -2294,6 +2324,44 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
     CgProfScope prof(CG_PROF_FAST_CONV_128x64, g, st);
     CG_LAUNCH_CONV(128, 64, grid);
     return;
+  }
+  // 96- and 192-channel tiles for the channel counts a 128-wide tile pads by a quarter or more
+  // (Inception: 96 / 160 / 192 outputs; BigGAN: 96 / 192) on grids large enough for the shallow rings
+  // (CGAMD_CONV_BN_WIDE=0: the 128-wide tiles everywhere)
+  static const int wide_env = [] {
+    const char* e = getenv("CGAMD_CONV_BN_WIDE");
+    return e ? atoi(e) : 1;
+  }();
+  if (wide_env) {
+    const int pad128 = cdiv(g->Co, 128) * 128;
+    const int bn = g->Co <= 96 ? 96 : (cdiv(g->Co, 192) * 192 < pad128 ? 192 : 128);
+    const int blocks = cdiv(a.Mp, 128) * cdiv(g->Co, bn) * phases;
+    if (bn != 128 && blocks >= 512) {
+      a.ntiles = cdiv(g->Co, bn);
+      a.dNt = make_fastdiv(a.ntiles);
+      a.mtiles = cdiv(a.Mp, 128);
+      dim3 grid(a.mtiles * a.ntiles, phases);
+      const bool one = ns_env ? ns_env == 1 : blocks >= 768;
+#define CG_LAUNCH_WIDE(BN_)                                                              \
+  do {                                                                                   \
+    if (one) {                                                                           \
+      if (a.relu_in) fast_conv_kernel<128, BN_, true, 1><<<grid, 256, 0, st>>>(a);       \
+      else fast_conv_kernel<128, BN_, false, 1><<<grid, 256, 0, st>>>(a);                \
+    } else {                                                                             \
+      if (a.relu_in) fast_conv_kernel<128, BN_, true, 2><<<grid, 256, 0, st>>>(a);       \
+      else fast_conv_kernel<128, BN_, false, 2><<<grid, 256, 0, st>>>(a);                \
+    }                                                                                    \
+  } while (0)
+      if (bn == 96) {
+        CgProfScope prof(CG_PROF_FAST_CONV_128x96, g, st);
+        CG_LAUNCH_WIDE(96);
+      } else {
+        CgProfScope prof(CG_PROF_FAST_CONV_128x192, g, st);
+        CG_LAUNCH_WIDE(192);
+      }
+#undef CG_LAUNCH_WIDE
+      return;
+    }
   }
   a.ntiles = cdiv(g->Co, 128);
   a.dNt = make_fastdiv(a.ntiles);

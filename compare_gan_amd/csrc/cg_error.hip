@@ -14,7 +14,7 @@ void cg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int cg_abi_version(void) { return 6; }   // round 6: + cg_sum4 (round 5: cgDeferCtx replaces cg_reduce_defer_*)
+extern "C" int cg_abi_version(void) { return 7; }   // round 6: + cg_sum4, cg_gconv_ld (round 5: cgDeferCtx replaces cg_reduce_defer_*)
 extern "C" const char* cg_last_error(void) { return g_err; }
 
 // ---- optional per-kernel-family timing with HIP events (bench.py's roofline leg) -------------
@@ -35,7 +35,8 @@ const char* const g_prof_names[CG_PROF_COUNT] = {
     "fast_conv_kernel<128, 32, *>",  "stem_fwd_kernel<*>",           "gconv_kernel<...>",
     "hwgrad_kernel<*>",              "halo_wgrad_kernel<*>",
     "fast_wgrad_kernel<128, *>",     "fast_wgrad_kernel<64, *>",     "stem_wgrad_kernel<*>",
-    "gwgrad_kernel<...>",            "sconv_kernel<*>",              "swgrad_kernel<*>"};
+    "gwgrad_kernel<...>",            "sconv_kernel<*>",              "swgrad_kernel<*>",
+    "fast_conv_kernel<128, 192, *>", "fast_conv_kernel<128, 96, *>"};
 }  // namespace
 
 bool cg_prof_enabled() { return g_prof_on; }

@@ -967,6 +967,29 @@ extern "C" int cg_gconv(const cgConvGeom* g, const void* in, const void* bt, voi
   return CG_OK;
 }
 
+extern "C" int cg_gconv_ld_supported(const cgConvGeom* g, int in_ld, int out_ld) {
+  if (!g || check_geom(g, "cg_gconv_ld_supported")) return 0;
+  return cg_fast_conv_ld_supported(g, in_ld, out_ld) ? 1 : 0;
+}
+
+extern "C" int cg_gconv_ld(const cgConvGeom* g, const void* in, int in_ld, const void* bt, void* out,
+                           int out_ld, int out_is_f32, const float* bias, int relu_out,
+                           cgStream stream) {
+  int rc = check_geom(g, "cg_gconv_ld");
+  if (rc) return rc;
+  if (!in || !bt || !out) CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_ld: null tensor");
+  if (!cg_fast_conv_ld_supported(g, in_ld, out_ld))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_ld: no kernel with pixel pitches for this geometry "
+                            "(cg_gconv_ld_supported)");
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_ld: slices must start on 16-byte boundaries");
+  hipStream_t st = (hipStream_t)stream;
+  cg_fast_conv_launch_ld(g, in, in_ld, bt, out, out_ld, out_is_f32, bias, nullptr,
+                         relu_out ? out : nullptr, 0.f, nullptr, st);
+  CG_CHECK_LAUNCH("cg_gconv_ld");
+  return CG_OK;
+}
+
 extern "C" int cg_gconv_fused_phases(const cgConvGeom* g) {
   if (!g || check_geom(g, "cg_gconv_fused_phases") || !cg_hconv_geom_ok(g)) return 0;
   return cg_hconv_stats_phases(g);

@@ -78,13 +78,26 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
   tpu_random.set_random_offset(42, eval_step)
   next_index = 1
 
-  def generate(index):
+  def draw(index):
     z = z_generator(shape=[batch_size, gan._z_dim], name="eval_z/%d" % index,  # pylint: disable=protected-access
                     device=device)
     labels = None
     if gan.conditional:
       labels = tpu_random.labels(batch_size, dataset.num_classes, "eval_labels/%d" % index, device)
-    return gan.generate(z, labels)
+    return z, labels
+
+  def generate_eager(index):
+    return gan.generate(*draw(index))
+
+  # the sampling loop proper: one hipGraph replay of the generator per batch (its result is a static
+  # buffer that the sink consumes before the next replay); the accumulator fill below changes
+  # host-side state per call and stays on generate()
+  sampler = [None]
+
+  def generate(index):
+    if sampler[0] is None:
+      sampler[0] = gan.make_sampler(batch_size)
+    return sampler[0](*draw(index))
 
   import time
   timing = {"accumulators": 0.0, "sample": 0.0, "sample_first_batch": 0.0, "inception": 0.0,
@@ -97,8 +110,8 @@ def evaluate_gan(gan, eval_tasks, num_averaging_runs=1, num_accu_examples=204800
   transform = lambda images: eval_utils.inception_transform_np(images, batch_size)
   try:
     t0 = tick()
-    next_index += _update_bn_accumulators(gan, generate, batch_size, num_accu_examples, next_index,
-                                          rank, world)
+    next_index += _update_bn_accumulators(gan, generate_eager, batch_size, num_accu_examples,
+                                          next_index, rank, world)
     timing["accumulators"] = tick() - t0
     if not eval_tasks:
       return None

@@ -865,6 +865,45 @@ class ModularGAN(AbstractGAN):
           for p, s in zip(self.g_opt.params, swapped):
             p.copy_(s)
 
+  def make_sampler(self, batch_size, use_ema=None):
+    """sample(z [B, z_dim], labels [B] or None) -> the same images as generate(z, labels), as ONE
+    hipGraph replay per batch: the evaluation samples its 10,000 images in batches of 64
+    (eval_gan_lib.py:95-140), ~60 launches of a few microseconds each per batch when issued one by
+    one.  The graph reads the variables (or their EMA shadows) where they live, so later in-place
+    updates are seen; the result is a STATIC buffer, overwritten by the next call -- consume (or
+    copy) it first, stream order is enough.  CGAMD_EVAL_GRAPH=0 (or no GPU) returns generate itself.
+    The batch-norm accumulator fill (eval_gan_lib._update_bn_accumulators) changes host-side control
+    flow and keeps calling generate()."""
+    if not (torch.cuda.is_available() and self.device.type == "cuda") or \
+        os.environ.get("CGAMD_EVAL_GRAPH", "1") == "0":
+      return lambda z, labels=None: self.generate(z, labels, use_ema=use_ema)
+    bsz = int(batch_size)
+    z_static = torch.zeros((bsz, self._z_dim), dtype=torch.float32, device=self.device)
+    y_static = None
+    if self.conditional:
+      y_static = torch.zeros((bsz,), dtype=torch.int32, device=self.device)
+    side = torch.cuda.Stream(device=self.device)
+    side.wait_stream(torch.cuda.current_stream(self.device))
+    with torch.cuda.stream(side):          # first use of every kernel / workspace outside the capture
+      self.generate(z_static, y_static, use_ema=use_ema)
+    torch.cuda.current_stream(self.device).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    kwargs = {}
+    if tpu_ops.num_replicas() > 1 or tpu_ops.force_data_parallel():
+      kwargs["capture_error_mode"] = "thread_local"    # see _capture: the watchdog thread
+    with torch.cuda.graph(graph, **kwargs):
+      out = self.generate(z_static, y_static, use_ema=use_ema)
+
+    def sample(z, labels=None):
+      z_static.copy_(z, non_blocking=True)
+      if y_static is not None:
+        y_static.copy_(labels, non_blocking=True)
+      graph.replay()
+      return out
+
+    sample.graph = graph
+    return sample
+
   # -- checkpoint state (SURVEY section 5 / App. D naming) -------------------------------------------------
   def state_dict(self):
     sd = dict(self.store.state_dict())

@@ -83,6 +83,8 @@ SIGNATURES = {
     "cg_weight_prep": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
     "cg_weight_prep_elems": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cg_gconv": (c_int, [GP, vp, vp, vp, c_int, vp, vp, c_f32, vp, c_f32, vp, vp]),
+    "cg_gconv_ld_supported": (c_int, [GP, c_int, c_int]),
+    "cg_gconv_ld": (c_int, [GP, vp, c_int, vp, vp, c_int, c_int, vp, c_int, vp]),
     "cg_defer_create": (vp, []),
     "cg_defer_destroy": (None, [vp]),
     "cg_defer_pending": (c_int, [vp]),

@@ -181,6 +181,45 @@ def gconv(geom, x, bt, bias=None, gate_in=None, slope_in=0.0, gate_out=None, slo
     return out
 
 
+def _pixel_pitch(t, c, name):
+    """Elements between consecutive pixels of an NHWC tensor or of a channel slice t[..., a:a+c] of
+    one; the pixels themselves must be densely packed at that pitch."""
+    if t.dim() != 4 or t.shape[3] != c or t.stride(3) != 1:
+        raise ValueError("%s must be [N, H, W, %d] with unit channel stride" % (name, c))
+    ld = t.stride(2)
+    if t.stride(1) != ld * t.shape[2] or t.stride(0) != ld * t.shape[2] * t.shape[1]:
+        raise ValueError("%s: pixels are not a dense grid at pitch %d" % (name, ld))
+    return ld
+
+
+def gconv_ld_supported(geom, in_ld, out_ld):
+    return bool(lib().cg_gconv_ld_supported(ctypes.byref(geom), int(in_ld), int(out_ld)))
+
+
+def gconv_ld(geom, x, bt, out, bias=None, relu=False):
+    """cg_gconv_ld: conv (+ bias, + ReLU) reading a channel slice `x` of a wider NHWC tensor and
+    writing into the channel slice `out` of another (bf16, or fp32 out) -- both torch views."""
+    for t, dt, nm in ((x, BF16, "x"), (bt, BF16, "bt")):
+        if not t.is_cuda or t.dtype != dt:
+            raise ValueError("%s must be %s on the GPU" % (nm, dt))
+    if not out.is_cuda or out.dtype not in (BF16, F32):
+        raise ValueError("out must be bf16 or fp32 on the GPU")
+    _req(bias, F32, "bias", True)
+    if tuple(x.shape) != (geom.N, geom.Hin, geom.Win, geom.Ci):
+        raise ValueError("x shape %s, geometry expects %s" % (tuple(x.shape), geom.key()))
+    if tuple(out.shape) != (geom.N, geom.Ho, geom.Wo, geom.Co):
+        raise ValueError("out shape %s, geometry expects %s" % (tuple(out.shape), geom.key()))
+    Kp = (geom.kh * geom.kw * geom.Ci + 7) // 8 * 8
+    if tuple(bt.shape) != (geom.Co, Kp) or not bt.is_contiguous():
+        raise ValueError("bt shape %s != (%d, %d)" % (tuple(bt.shape), geom.Co, Kp))
+    if bias is not None and bias.numel() != geom.Co:
+        raise ValueError("bias has the wrong number of elements")
+    check(lib().cg_gconv_ld(ctypes.byref(geom), _p(x), _pixel_pitch(x, geom.Ci, "x"), _p(bt), _p(out),
+                            _pixel_pitch(out, geom.Co, "out"), int(out.dtype == F32), _p(bias),
+                            int(bool(relu)), _stream()), "cg_gconv_ld")
+    return out
+
+
 def gconv_fused_rows(geom):
     """Rows of batch-norm partial sums the fused convolution kernel emits for `geom`; 0 when the
     geometry is not covered (use gconv + bn_stats / bn_apply then)."""

@@ -13,8 +13,29 @@ import torch.distributed as dist
 
 from compare_gan_amd import gin
 
-_STATE = {"enabled": False, "groups": {}}
+_STATE = {"enabled": False, "groups": {}, "log": None}
 _LOCAL = threading.local()   # in-process replica sets (InProcessReplicas) are per thread
+
+
+def record_collectives(log):
+  """Diagnostic: from now on every collective this process issues appends
+  (kind, numel, dtype, group_size, issuing thread: "main" | "worker") to `log` (a list; None stops
+  the recording); returns the previous log.  RCCL needs every rank to issue the collectives of one
+  communicator in the same order, and two threads issue them here (the main thread: batch-norm
+  forwards; autograd's device thread: batch-norm backwards and the gradient buckets -- see
+  modular_gan._OptimizerState.arm): the tests compare the recorded sequences of the ranks
+  (tests/test_data_parallel_gloo.py, tests/test_data_parallel_gpu.py)."""
+  prev = _STATE["log"]
+  _STATE["log"] = log
+  return prev
+
+
+def _note(kind, tensor, group_size=None):
+  log = _STATE["log"]
+  if log is not None:
+    log.append((kind, int(tensor.numel()), str(tensor.dtype).replace("torch.", ""),
+                int(group_size or 0),
+                "main" if threading.current_thread() is threading.main_thread() else "worker"))
 
 
 class InProcessReplicas(object):
@@ -200,6 +221,7 @@ def cross_replica_sum_(tensor, group_size=None):
   """In-place all-reduce SUM (the one primitive the reference builds everything from)."""
   if not data_parallel() or group_size == 1:
     return tensor, 1
+  _note("all_reduce_sum", tensor, group_size)
   local = _in_process()
   if local is not None:
     if group_size not in (None, 0) and group_size < local[0].world:
@@ -236,6 +258,7 @@ def cross_replica_concat(value, replica_id_, num_replicas_):
   if num_replicas() == 1:
     return value
   parts = [torch.empty_like(value) for _ in range(num_replicas_)]
+  _note("all_gather", value)
   dist.all_gather(parts, value.contiguous())
   return torch.cat(parts, dim=0)
 

@@ -119,6 +119,19 @@ int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, 
              const float* bias, const void* gate_in, float slope_in, const void* gate_out,
              float slope_out, const void* residual, cgStream stream);
 
+/* cg_gconv on CHANNEL SLICES: consecutive pixels of `in` are in_ld elements apart and those of `out`
+ * out_ld (in_ld >= Ci, out_ld >= Co, both multiples of 8, Co % 8 == 0; bf16 in, bf16 or fp32 out).
+ * What it replaces: the tf.concat(axis=3) that ends every Inception block and the reads of a block's
+ * sibling 1x1 convolutions (the frozen graph behind eval_utils.py:41-49,165-175) -- a branch writes its
+ * channels straight into the block's output, and the 1x1 convolutions that share an input run as one
+ * convolution whose output the next layers read slice by slice.  Same arithmetic as cg_gconv with
+ * gate_in = residual = NULL and gate_out = (relu_out ? out : NULL), slope 0.
+ * cg_gconv_ld_supported: 1 when the geometry has a kernel with this addressing (the MFMA one-tap
+ * kernel: Ci % 32 == 0), else 0 -- the caller then uses cg_gconv on dense tensors. */
+int cg_gconv_ld_supported(const cgConvGeom* geom, int in_ld, int out_ld);
+int cg_gconv_ld(const cgConvGeom* geom, const void* in, int in_ld, const void* bt, void* out,
+                int out_ld, int out_is_f32, const float* bias, int relu_out, cgStream stream);
+
 /* Batch-norm fusion around cg_gconv for forward passes that keep no autograd graph (the generator
  * forward of every discriminator sub-step, modular_gan.py:465-467): the producer convolution emits
  * the per-channel sums of the values it stores, the consumer convolution normalises its input in

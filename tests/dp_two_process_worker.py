@@ -5,7 +5,10 @@ ranks), the process group uses the host-staged `gloo` debugging backend of
 tpu_ops.cross_replica_sum_; everything else is the product's data-parallel path: per-replica z /
 label streams, cross-replica batch norm forward AND backward (collectives issued from autograd's
 device thread), one gradient bucket per network, 1/world scaling.  Two eager training steps on this
-replica's shard of the fixed global batch; the variables are written to out_path.<rank>.
+replica's shard of the fixed global batch; the variables are written to out_path.<rank>, the
+sequence of collectives this rank issued in each step (tpu_ops.record_collectives) to
+out_path.<rank>.collectives.  CGAMD_DP_OVERLAP / CGAMD_DP_BUCKET_MIN_MB in the environment choose
+between one all-reduce per network after its backward pass and buckets leaving during it.
 """
 import os
 import sys
@@ -47,11 +50,17 @@ def main():
     assert tpu_ops.in_replica_context()
     gan, options, dataset = U.build_product(CONFIG, BS, dev, seed=SEED, bindings=BINDINGS)
     nsub = options["disc_iters"] + 1
+    sequences = []
     for per_rank in global_batches(dataset, world, nsub):
         images, labels = per_rank[rank]
+        log = []
+        tpu_ops.record_collectives(log)
         gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+        tpu_ops.record_collectives(None)
+        sequences.append(log)
     torch.cuda.synchronize()
     assert gan.d_opt.flat is not None
+    torch.save(sequences, "%s.%d.collectives" % (out_path, rank))
     torch.save({k: v.detach().cpu() for k, v in gan.store.vars.items()}, "%s.%d" % (out_path, rank))
     import torch.distributed as dist
     dist.barrier()

@@ -229,6 +229,46 @@ def _body_reference_goldens(rank):
 
 
 # ---- tests -----------------------------------------------------------------------------------------
+def _body_collective_sequence(rank):
+  """tpu_ops.record_collectives: the recorded (kind, numel, dtype, group, thread) sequence of a rank,
+  with collectives issued from the main thread AND from autograd's worker thread (a custom Function's
+  backward, as the cross-replica batch norm's is), equals the other rank's."""
+  from compare_gan_amd.tpu import tpu_ops
+
+  class SumInBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+      return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+      g = g.clone()
+      tpu_ops.cross_replica_sum_(g)
+      return g
+
+  log = []
+  assert tpu_ops.record_collectives(log) is None
+  x = torch.randn(4, 5, dtype=torch.float64, requires_grad=True)
+  tpu_ops.cross_replica_moments(x.detach(), axis=(0,), parallel=True)      # 2 all-reduces, main thread
+  y = SumInBackward.apply(x * (rank + 1.0)).sum()
+  y.backward()                                                              # 1 all-reduce in backward
+  tpu_ops.cross_replica_concat(torch.zeros(3), rank, WORLD)                 # all-gather
+  tpu_ops.cross_replica_mean(torch.zeros(7), group_size=1)                  # identity: nothing issued
+  assert tpu_ops.record_collectives(None) is log
+  tpu_ops.cross_replica_mean(torch.zeros(7))                                # not recorded any more
+  assert [c[:2] for c in log] == [("all_reduce_sum", 5), ("all_reduce_sum", 5),
+                                  ("all_reduce_sum", 20), ("all_gather", 3)], log
+  assert log[0][2] == "float64" and log[0][4] == "main"
+  both = [None] * WORLD
+  dist.all_gather_object(both, log)
+  assert both[0] == both[1], both
+  assert torch.allclose(x.grad, torch.full((4, 5), 2.0 * (rank + 1), dtype=torch.float64))   # ones summed over 2 ranks
+
+
+def test_collective_sequence_world2():
+  _run("_body_collective_sequence")
+
+
 def test_reference_goldens_world2():
   _run("_body_reference_goldens")
 

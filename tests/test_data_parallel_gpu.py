@@ -268,3 +268,56 @@ def test_two_processes_match_one_replica_on_the_global_batch(dev, tmp_path):
           "norm ratio %.5f, beyond noise: %s" % (dp_cos, noise_cos, dp_ratio, worse))
     assert dp_cos >= 0.999 and abs(dp_ratio - 1.0) <= 0.005, (dp_cos, dp_ratio)
     assert not worse, worse
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_ranks_issue_their_collectives_in_the_same_order(dev, tmp_path, overlap):
+    """RCCL requires every rank to issue the collectives of a communicator in the same order; here two
+    threads issue them (main thread: the cross-replica batch norms of the forward passes; autograd's
+    device thread: their backward all-reduces and the gradient buckets, modular_gan._OptimizerState.arm
+    -- reference: modular_gan.py:606-616 CrossShardOptimizer, tpu/tpu_ops.py:94-125).  Two processes run
+    two data-parallel steps of resnet_cifar10.gin each (both on cuda:0, sums through the host) and
+    record (kind, numel, dtype, group, issuing thread) of every collective: the sequences of the two
+    ranks must be identical, step by step, with the gradients leaving in one all-reduce per network
+    after its backward pass (overlap 0) and in buckets during it (overlap 1, 1 MiB buckets so that
+    the small networks split); the step must contain both threads' collectives, and with the overlap
+    on the first gradient bucket must leave BEFORE the backward pass's last batch-norm all-reduce."""
+    import socket
+    from tests import dp_two_process_worker as W
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out_path = str(tmp_path / "vars.pt")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update({"CGAMD_DP_OVERLAP": overlap, "CGAMD_DP_BUCKET_MIN_MB": "1", "CGAMD_DP_BUCKETS": "2"})
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_two_process_worker.py"),
+                               str(r), str(world), port, out_path], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode("utf-8", "replace") for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and "DP_WORKER_OK" in outs[r], outs[r][-3000:]
+    seqs = [torch.load("%s.%d.collectives" % (out_path, r)) for r in range(world)]
+    assert len(seqs[0]) == W.STEPS
+    for step in range(W.STEPS):
+        a, b = seqs[0][step], seqs[1][step]
+        assert len(a) == len(b) and len(a) > 0
+        for i, (ca, cb) in enumerate(zip(a, b)):
+            assert tuple(ca) == tuple(cb), (step, i, ca, cb)
+        threads = {c[4] for c in a}
+        assert threads == {"main", "worker"}, threads
+        # gradient all-reduces are the large fp32 ones (batch-norm messages are [2C], C <= 256)
+        grads = [i for i, c in enumerate(a) if c[1] > 4096]
+        bn_bwd = [i for i, c in enumerate(a) if c[4] == "worker" and c[1] <= 4096]
+        assert grads and bn_bwd
+        if overlap == "1":
+            assert any(g < max(bn_bwd) for g in grads), (grads, max(bn_bwd))
+        else:
+            # 5 D sub-steps + 1 G sub-step: one all-reduce each
+            assert len(grads) == 6, len(grads)
+    assert seqs[0][0] == seqs[0][1]     # and the sequence is the same from step to step
+    print("collectives per step:", len(seqs[0][0]), "gradient all-reduces:",
+          len([c for c in seqs[0][0] if c[1] > 4096]), "overlap", overlap)

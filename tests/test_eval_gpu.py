@@ -318,3 +318,37 @@ def test_generate_with_ema_weights(dev):
             p.copy_(e)
     img_ref = gan.generate(z, lab, use_ema=False)
     assert torch.equal(img_ema, img_ref)
+
+
+@pytest.mark.parametrize("config,bind", [
+    ("resnet_cifar10.gin", []),
+    ("biggan_imagenet128.gin", ["resnet_biggan.Generator.ch = 32", "resnet_biggan.Discriminator.ch = 32",
+                                "ModularGAN.ema_decay = 0.5", "ModularGAN.ema_start_step = 0",
+                                "G.spectral_norm = False"])])
+def test_captured_sampler_equals_generate(dev, config, bind):
+    """ModularGAN.make_sampler (the evaluation's sampling loop, eval_gan_lib.py:95-140 /
+    modular_gan.py:266-285): one hipGraph replay per batch returns bit for bit what generate() returns --
+    unconditional and class-conditional with EMA shadows -- and follows the variables when a training
+    step updates them in place after the capture."""
+    bsz = 4
+    gan, options, dataset = U.build_product(config, bsz, dev, seed=11, bindings=bind)
+    sample = gan.make_sampler(bsz)
+    assert hasattr(sample, "graph")
+    nsub = options["disc_iters"] + 1
+    rng = np.random.RandomState(7)
+    for round_ in range(2):
+        for k in range(3):
+            z = U.host_uniform((bsz, options["z_dim"]), "z/%d/%d" % (round_, k), -1.0, 1.0, 11, 0).float().to(dev)
+            lab = None
+            if gan.conditional:
+                lab = torch.from_numpy(rng.randint(0, dataset.num_classes, size=bsz).astype(np.int32)).to(dev)
+            got = sample(z, lab).clone()
+            want = gan.generate(z, lab)
+            assert torch.equal(got, want), (config, round_, k, float((got - want).abs().max()))
+        if round_ == 0:
+            images = rng.uniform(size=(nsub * bsz,) + tuple(dataset.image_shape)).astype(np.float32)
+            labels = rng.randint(0, max(1, dataset.num_classes), size=nsub * bsz).astype(np.int32)
+            before = want.clone()
+            gan.train_step(torch.from_numpy(images).to(dev), torch.from_numpy(labels).to(dev))
+            torch.cuda.synchronize()
+            assert not torch.equal(gan.generate(z, lab), before)   # the weights did move

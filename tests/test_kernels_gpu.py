@@ -1266,6 +1266,54 @@ def test_inception_preprocess_and_pool(K, dev):
     assert_close_bf16(K.pool2d(xb.to(dev), 3, 1, 1, 1, 9, 9), ref_avg, "avgpool 3x3/1 same")
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co, kh, kw, stride, padding, in_extra (before, after), out_extra (before, after)
+    (3, 17, 17, 64, 96, 1, 1, 1, "SAME", (32, 8), (64, 16)),       # sibling 1x1 head read from a slice
+    (2, 17, 17, 160, 192, 1, 7, 1, "SAME", (0, 32), (192, 384)),   # 1x7 into the middle of a block output
+    (2, 17, 17, 128, 128, 7, 1, 1, "SAME", (64, 0), (0, 8)),
+    (2, 35, 35, 96, 96, 3, 3, 2, "VALID", (0, 0), (384, 288)),     # reduction block: stride 2, VALID
+    (4, 8, 8, 384, 384, 3, 1, 1, "SAME", (448, 0), (320, 384)),    # mixed_9 split branch
+    (130, 8, 8, 64, 72, 1, 1, 1, "SAME", (0, 0), (8, 0)),          # > one workgroup per CU; Co % 8 only
+])
+def test_gconv_on_channel_slices(K, dev, case):
+    """cg_gconv_ld (the concatenations of the Inception graph behind eval_utils.py:165-175 written in
+    place): conv + bias + ReLU reading a channel slice of a wider tensor and writing into a channel
+    slice of another equals -- bit for bit, same kernel arithmetic -- cg_gconv on dense copies, and
+    leaves the neighbouring channels of the output untouched; against the fp64 oracle within the
+    bf16 tolerance of the file header."""
+    N, H, W, Ci, Co, kh, kw, stride, padding, (ib, ia), (ob, oa) = case
+    g = _gen(sum(case[:8]))
+    wide64, wide = rand_bf16((N, H, W, ib + Ci + ia), g)
+    w64, wb = rand_bf16((kh, kw, Ci, Co), g, scale=1.0 / math.sqrt(kh * kw * Ci))
+    bias = torch.randn((Co,), generator=g, dtype=torch.float32)
+    if padding == "SAME":
+        geom = K.geom_conv_same(N, H, W, Ci, Co, kh, kw, stride, 1)
+    else:
+        geom = K.make_geom(N, H, W, Ci, (H - kh) // stride + 1, (W - kw) // stride + 1, Co, kh, kw, stride, 1, 0, 0)
+    assert K.gconv_ld_supported(geom, ib + Ci + ia, ob + Co + oa)
+    bt = K.weight_prep(wb.float().to(dev), want_fwd=True)[0]
+    wide_d = wide.to(dev)
+    x_view = wide_d[..., ib:ib + Ci]
+    out_wide = torch.full((N, geom.Ho, geom.Wo, ob + Co + oa), 7.0, dtype=BF16, device=dev)
+    got = K.gconv_ld(geom, x_view, bt, out_wide[..., ob:ob + Co], bias=bias.to(dev), relu=True)
+    dense = K.gconv(geom, x_view.contiguous(), bt, bias=bias.to(dev), act_out=0.0)
+    assert torch.equal(got, dense)
+    assert bool((out_wide[..., :ob] == 7.0).all()) and bool((out_wide[..., ob + Co:] == 7.0).all())
+    x64 = wide64[..., ib:ib + Ci]
+    xp = x64.permute(0, 3, 1, 2)
+    if padding == "SAME":
+        xp = F.pad(xp, (geom.pl, kw - 1 - geom.pl, geom.pt, kh - 1 - geom.pt))
+    ref = F.conv2d(xp, w64.permute(3, 2, 0, 1), stride=stride).permute(0, 2, 3, 1) + bias.double()
+    assert_close_bf16(got, ref.clamp(min=0.0), "gconv_ld %s" % (case,))
+    # fp32 output, no ReLU (the logits layer's form)
+    out32 = torch.zeros((N, geom.Ho, geom.Wo, Co + 8), dtype=torch.float32, device=dev)
+    K.gconv_ld(geom, x_view, bt, out32[..., 8:], bias=None, relu=False)
+    assert_close_f32(out32[..., 8:], ref - bias.double(), "gconv_ld fp32 %s" % (case,))
+    # what is not a slice is refused
+    with pytest.raises(ValueError):
+        K.gconv_ld(geom, x_view.transpose(1, 2), bt, out_wide[..., ob:ob + Co])   # H == W: shape fits, pitch not
+
+
 def test_error_codes(K, dev):
     from compare_gan_amd.hip._lib import CgamdError
     x = torch.zeros((1, 4, 4, 8), dtype=BF16, device=dev)
