@@ -481,6 +481,8 @@ def main():
             # which symmetric-square-root path the statistics took (metrics/fid_score.py: the GEMM-only
             # Newton-Schulz iteration when it certifies itself, the Jacobi eigen-solver otherwise)
             "sqrt_solver": dict(fid_lib.LAST_SOLVER),
+            "tridiagonal_certificate": {k: (float("%.4g" % v) if isinstance(v, float) else v)
+                                        for k, v in fid_lib.LAST_TRIDIAG.items()},
             "newton_schulz": [{k: (float("%.4g" % v) if isinstance(v, float) else v)
                                for k, v in rec.items()} for rec in fid_lib.LAST_NEWTON],
             "fid": round(float(res["fid_score_mean"]), 4),

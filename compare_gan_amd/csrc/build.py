@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcgamd.so")
 SOURCES = ["cg_error.hip", "cg_gconv.hip", "cg_conv_fast.hip", "cg_conv_halo.hip", "cg_conv_small.hip", "cg_multi.hip", "cg_elem.hip", "cg_bn.hip", "cg_sn.hip",
-           "cg_optim.hip", "cg_attn.hip", "cg_fid.hip", "cg_calib.hip", "cg_ln.hip", "cg_head.hip"]
+           "cg_optim.hip", "cg_attn.hip", "cg_fid.hip", "cg_tridiag.hip", "cg_calib.hip", "cg_ln.hip", "cg_head.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-I" + os.path.join(ROOT, "include"), "-I" + HERE]

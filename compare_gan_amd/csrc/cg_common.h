@@ -128,7 +128,6 @@ enum {
   CG_PROF_SCONV,                  // sconv_kernel<*> (cg_conv_small.hip)
   CG_PROF_SWGRAD,                 // swgrad_kernel<*> (cg_conv_small.hip)
   CG_PROF_FAST_CONV_128x192,      // fast_conv_kernel<128, 192, *>
-  CG_PROF_FAST_CONV_128x96,       // fast_conv_kernel<128, 96, *>
   CG_PROF_COUNT
 };
 void cg_prof_begin(int family, double flops, double bytes, hipStream_t st);

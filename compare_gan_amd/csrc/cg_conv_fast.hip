@@ -2325,16 +2325,18 @@ void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, cons
     CG_LAUNCH_CONV(128, 64, grid);
     return;
   }
-  // 96- and 192-channel tiles for the channel counts a 128-wide tile pads by a quarter or more
-  // (Inception: 96 / 160 / 192 outputs; BigGAN: 96 / 192) on grids large enough for the shallow rings
-  // (CGAMD_CONV_BN_WIDE=0: the 128-wide tiles everywhere)
+  // 192-channel tiles for the channel counts 128-wide tiles pad by a quarter or more (Inception: 160 /
+  // 192 outputs; BigGAN: 192) on grids large enough for the shallow rings: -13 ... -18 % per launch on
+  // the 17 x 17 layers of an Inception batch (profiles/r06_inception_tiles_ab.txt).  A 96-wide tile
+  // (one 32 x 96 MFMA tile per wave) measured equal on 3x3 and slower on 1x1 layers with 96 outputs and
+  // was dropped.  CGAMD_CONV_BN_WIDE=0: the 128-wide tiles everywhere
   static const int wide_env = [] {
     const char* e = getenv("CGAMD_CONV_BN_WIDE");
     return e ? atoi(e) : 1;
   }();
   if (wide_env) {
     const int pad128 = cdiv(g->Co, 128) * 128;
-    const int bn = g->Co <= 96 ? 96 : (cdiv(g->Co, 192) * 192 < pad128 ? 192 : 128);
+    const int bn = cdiv(g->Co, 192) * 192 < pad128 ? 192 : 128;
     const int blocks = cdiv(a.Mp, 128) * cdiv(g->Co, bn) * phases;
     if (bn != 128 && blocks >= 512) {
       a.ntiles = cdiv(g->Co, bn);
@@ -2352,13 +2354,8 @@ void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, cons
       else fast_conv_kernel<128, BN_, false, 2><<<grid, 256, 0, st>>>(a);                \
     }                                                                                    \
   } while (0)
-      if (bn == 96) {
-        CgProfScope prof(CG_PROF_FAST_CONV_128x96, g, st);
-        CG_LAUNCH_WIDE(96);
-      } else {
-        CgProfScope prof(CG_PROF_FAST_CONV_128x192, g, st);
-        CG_LAUNCH_WIDE(192);
-      }
+      CgProfScope prof(CG_PROF_FAST_CONV_128x192, g, st);
+      CG_LAUNCH_WIDE(192);
 #undef CG_LAUNCH_WIDE
       return;
     }

@@ -36,7 +36,7 @@ const char* const g_prof_names[CG_PROF_COUNT] = {
     "hwgrad_kernel<*>",              "halo_wgrad_kernel<*>",
     "fast_wgrad_kernel<128, *>",     "fast_wgrad_kernel<64, *>",     "stem_wgrad_kernel<*>",
     "gwgrad_kernel<...>",            "sconv_kernel<*>",              "swgrad_kernel<*>",
-    "fast_conv_kernel<128, 192, *>", "fast_conv_kernel<128, 96, *>"};
+    "fast_conv_kernel<128, 192, *>"};
 }  // namespace
 
 bool cg_prof_enabled() { return g_prof_on; }

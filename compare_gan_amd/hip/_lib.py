@@ -199,6 +199,9 @@ SIGNATURES = {
     "cg_rowscale_f64": (c_int, [vp, vp, vp, c_int, c_int, vp]),
     "cg_spectral_sqrt_f64": (c_int, [vp, c_int, c_f64, vp, vp, vp]),
     "cg_fid_combine_f64": (c_int, [vp, vp, vp, vp, c_int, vp, vp, vp]),
+    "cg_sytrd_eigvals_workspace_bytes": (c_sz, [c_int]),
+    "cg_sytrd_eigvals_f64": (c_int, [vp, c_int, vp, vp, vp, c_sz, vp]),
+    "cg_spectral_sqrt_bound_f64": (c_int, [vp, c_int, c_f64, c_f64, c_f64, vp, vp, vp]),
     "cg_syevj_workspace_bytes": (c_sz, [c_int]),
     "cg_syevj_f64": (c_int, [vp, c_int, vp, vp, c_int, c_f64, vp, c_sz, vp]),
     "cg_inception_score_workspace_bytes": (c_sz, [c_i64, c_int]),

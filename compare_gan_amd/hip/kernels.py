@@ -1399,6 +1399,33 @@ def syevj_f64(a, max_sweeps=30, tol=1e-15, want_vectors=True):
     return w, v
 
 
+def sytrd_eigvals_f64(a):
+    """Destroys `a` ([n, n] symmetric fp64, n <= 4096).  Returns (w [n] ascending, |a|_F [1]): the
+    eigenvalues by Householder tridiagonalisation + bisection -- absolute accuracy c n u |a|_F."""
+    _req(a, F64, "a")
+    n = a.shape[0]
+    if a.dim() != 2 or a.shape[1] != n:
+        raise ValueError("a must be square")
+    w = torch.empty((n,), dtype=F64, device=a.device)
+    fro = torch.empty((1,), dtype=F64, device=a.device)
+    ws = _ws(lib().cg_sytrd_eigvals_workspace_bytes(n), a)
+    check(lib().cg_sytrd_eigvals_f64(_p(a), n, _p(w), _p(fro), _p(ws), ws.numel(), _stream()),
+          "cg_sytrd_eigvals_f64")
+    return w, fro
+
+
+def spectral_sqrt_bound_f64(w, eps, delta_f_rel, delta_2_rel, fro):
+    """[sum_i f(|w_i|), bound on its error when w are the eigenvalues of A + E with |E|_F <= delta_f_rel *
+    fro and |E|_2 <= delta_2_rel * fro] (device, fp64); f(s) = s < eps ? s : sqrt(s)."""
+    _req(w, F64, "w")
+    _req(fro, F64, "fro")
+    out = torch.empty((2,), dtype=F64, device=w.device)
+    check(lib().cg_spectral_sqrt_bound_f64(_p(w), w.numel(), float(eps), float(delta_f_rel),
+                                           float(delta_2_rel), _p(fro), _p(out), _stream()),
+          "cg_spectral_sqrt_bound_f64")
+    return out
+
+
 def inception_score_f64(logits):
     _req(logits, F32, "logits")
     n, k = logits.shape

@@ -89,6 +89,7 @@ SPEC = [
 ]
 _CHUNK = int(os.environ.get("CGAMD_INCEPTION_BATCH", "512"))   # images per call of transform()
 _USE_LD = os.environ.get("CGAMD_INCEPTION_LD", "1") != "0"    # branches write into the block output
+_MERGE_HEADS = os.environ.get("CGAMD_INCEPTION_HEADS", "1") != "0"   # sibling 1x1 convolutions as one
 POOL3_DIM = 2048
 NUM_LOGITS = 1008
 INPUT_SIZE = 299
@@ -179,6 +180,30 @@ class InceptionV3(object):
         self._bt[name] = K.weight_prep(v, want_fwd=True, want_bwd=False)[0]
     wl = self.weights["logits/kernel"]
     self._bt["logits/kernel"] = K.weight_prep(wl.reshape(1, 1, *wl.shape), want_fwd=True)[0]
+    # Sibling 1x1 convolutions: the branches of a block that START with a unit-stride 1x1 convolution
+    # of the block input (three of four in every mixed block) run as ONE convolution with their kernels
+    # side by side -- the input is read once instead of three times and the column tiles fill up
+    # (17x17x768 -> 192 + 160 + 160: five 128-wide tiles, two of them 62 % full, become 512 columns);
+    # the next layer of each branch reads its channel slice of the result (K.gconv_ld).
+    self._heads = {}
+    if _MERGE_HEADS:
+      for op in SPEC:
+        if op[0] != "mixed":
+          continue
+        heads = [(i, b[0]) for i, b in enumerate(op[2])
+                 if b[0][0] == "conv" and b[0][3:6] == (1, 1, 1)]
+        if len(heads) < 2:
+          continue
+        ks = [self.weights[h[1] + "/kernel"] for _, h in heads]
+        bs = [self.weights[h[1] + "/bias"] for _, h in heads]
+        name = op[1] + "/heads"
+        self._bt[name + "/kernel"] = K.weight_prep(torch.cat(ks, dim=3).contiguous(), want_fwd=True)[0]
+        self.weights[name + "/bias"] = torch.cat(bs).contiguous()
+        cols, off = {}, 0
+        for (i, _), k in zip(heads, ks):
+          cols[i] = (off, int(k.shape[3]))
+          off += int(k.shape[3])
+        self._heads[op[1]] = (cols, off)
 
   # -- ops -----------------------------------------------------------------------------------------
   # Every block of the graph ends in a concatenation along the channels.  Here the block's output is
@@ -199,6 +224,8 @@ class InceptionV3(object):
     name = op[1]
     geom = self._geom(x, op)
     bt, bias = self._bt[name + "/kernel"], self.weights[name + "/bias"]
+    if not x.is_contiguous() and geom.kh == 3 and geom.kw == 3 and geom.Hin == 8:
+      x = x.contiguous()     # 8x8 maps: the four-image halo kernel (dense input) beats the one-tap one
     if dst is None and x.is_contiguous():
       return K.gconv(geom, x, bt, bias=bias, act_out=0.0)
     if dst is None:
@@ -236,15 +263,29 @@ class InceptionV3(object):
         h, w_, c = outs[0][0], outs[0][1], sum(o[2] for o in outs)
     return h, w_, c
 
-  def _concat(self, branches, x, dst):
+  def _concat(self, branches, x, dst, block=None):
     n, h, w_, c = x.shape
     outs = [self._shape_after(b, h, w_, c) for b in branches]
     if dst is None:
       dst = torch.empty((n, outs[0][0], outs[0][1], sum(o[2] for o in outs)), dtype=BF16,
                         device=x.device)
+    cols, heads = {}, None
+    if block in self._heads and x.is_contiguous():
+      cols, width = self._heads[block]
+      geom = K.make_geom(n, h, w_, c, h, w_, width, 1, 1)
+      heads = K.gconv(geom, x, self._bt[block + "/heads/kernel"],
+                      bias=self.weights[block + "/heads/bias"], act_out=0.0)
     off = 0
-    for b, o in zip(branches, outs):
-      self._emit(b, x, dst[..., off:off + o[2]])
+    for i, (b, o) in enumerate(zip(branches, outs)):
+      d = dst[..., off:off + o[2]]
+      if i in cols:
+        xb = heads[..., cols[i][0]:cols[i][0] + cols[i][1]]
+        if len(b) == 1:
+          d.copy_(xb)           # the branch IS its 1x1 convolution: its columns move into the block
+        else:
+          self._emit(b[1:], xb, d)
+      else:
+        self._emit(b, x, d)
       off += o[2]
     return dst
 
@@ -255,7 +296,7 @@ class InceptionV3(object):
         x = self._conv(x, op, d)
         continue
       if op[0] == "mixed":
-        x = self._concat(op[2], x, d)
+        x = self._concat(op[2], x, d, block=op[1])
         continue
       if op[0] == "split":
         x = self._concat(op[1], x, d)

@@ -43,6 +43,28 @@ _SOLVER = os.environ.get("CGAMD_FID_SOLVER", "auto")
 # the second matrix square root only contributes its TRACE: no eigenvectors (A/B switch, 1 = on)
 _VALUES_ONLY = int(os.environ.get("CGAMD_FID_VALUES_ONLY", "1"))
 _NS_MAX_ITER = 64
+# The trace of the second square root from eigenvalues computed by tridiagonalisation + bisection
+# (cg_sytrd_eigvals_f64: ~0.05 s at d = 2048 against ~0.33 s of values-only Jacobi sweeps), accepted only
+# under a certificate.  The method is backward stable in the ABSOLUTE sense: its values are the exact
+# eigenvalues of A + E.  |E|_F is taken as _TRIDIAG_C * sqrt(d) * u * |A|_F (the sqrt(d) growth of the
+# probabilistic rounding-error model, Higham & Mary 2019) and |E|_2 as a quarter of that from d = 64 on
+# (a rounding-error matrix has |E|_2 ~ 2 |E|_F / sqrt(d)): at d = 2048 that is 181 u resp. 45 u of |A|_F
+# against 17 u resp. 6 u measured, and tests/test_kernels_gpu.py::test_tridiagonal_eigenvalues asserts
+# the measured errors of ten matrix kinds (d = 2 ... 2048) at a quarter resp. half of the assumed ones.
+# cg_spectral_sqrt_bound_f64 turns the two into a bound on the error of sum f(|w_i|) (Weyl, Hoffman-
+# Wielandt + Cauchy-Schwarz; an eigenvalue within |E|_2 of tfgan's 1e-10 cut-off, where f jumps from
+# 1e-10 to 1e-5, is charged that jump).  Twice the bound (the trace enters the distance twice) must
+# stay below _TRIDIAG_ACCEPT * (tr sigma + tr sigma_v), the natural scale of the distance; 1e-6 is the
+# band the parity tests hold the distance to.  What fails it: many (near-)zero eigenvalues together
+# with a norm large enough that their rounding level reaches the cut-off (fewer samples than features
+# at feature scales >> 1) -- those take the Jacobi solve, whose eigenvalues are accurate relative to
+# themselves.  CGAMD_FID_TRIDIAG=0 switches the path off.
+_TRIDIAG = int(os.environ.get("CGAMD_FID_TRIDIAG", "1"))
+_TRIDIAG_MIN_D = 128
+_TRIDIAG_MAX_D = 4096
+_TRIDIAG_C = 4.0
+_TRIDIAG_ACCEPT = 1e-6
+LAST_TRIDIAG = {}      # certificate of the last call (tests, bench)
 LAST_SOLVER = {"sqrt_sigma": None, "trace_sqrt": None}   # what the last call used (tests, bench)
 LAST_NEWTON = []   # one record per _sqrt_newton_schulz call of the last frechet_distance()
 
@@ -105,6 +127,30 @@ def _sqrt_newton_schulz(a, want_matrix):
   return root, (c ** 0.5) * tr_y
 
 
+def _trace_sqrt_values_only(inner, scale):
+  """Device scalar [1] = sum_i f(|lambda_i(inner)|), f = tfgan's square-root rule: tridiagonalisation +
+  bisection under its certificate (see _TRIDIAG above; `scale` = tr sigma + tr sigma_v), else the
+  values-only Jacobi solve.  Destroys `inner`."""
+  d = inner.shape[0]
+  LAST_TRIDIAG.clear()
+  if _TRIDIAG and _TRIDIAG_MIN_D <= d <= _TRIDIAG_MAX_D:
+    keep = inner.clone()
+    w, fro = K.sytrd_eigvals_f64(inner)
+    delta_rel = _TRIDIAG_C * (d ** 0.5) * 2.220446049250313e-16
+    out = K.spectral_sqrt_bound_f64(w, _EPS, delta_rel, delta_rel / (4.0 if d >= 64 else 1.0), fro)
+    total, bound = out.tolist()              # one host read: the certificate
+    ok = np.isfinite(total) and np.isfinite(bound) and 2.0 * bound <= _TRIDIAG_ACCEPT * scale
+    LAST_TRIDIAG.update({"fro": float(fro.item()), "delta": delta_rel * float(fro.item()),
+                         "bound": bound, "scale": scale, "accepted": bool(ok)})
+    if ok:
+      LAST_SOLVER["trace_sqrt"] = "tridiagonal+bisection"
+      return out[:1]
+    inner = keep
+  w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL, want_vectors=_VALUES_ONLY == 0)
+  _, sqrt_trace = K.spectral_sqrt_f64(w2, _EPS, want_values=False)
+  return sqrt_trace
+
+
 def frechet_distance(real_activations, generated_activations, device="cuda:0"):
   """tfgan.eval.frechet_classifier_distance_from_activations(real, generated) -> float."""
   real = _activations_on_device(real_activations, device)
@@ -132,8 +178,7 @@ def frechet_distance(real_activations, generated_activations, device="cuda:0"):
       LAST_SOLVER["trace_sqrt"] = "newton-schulz"
       sqrt_trace = torch.tensor([res[1]], dtype=torch.float64, device=sigma.device)
       return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
-    w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL, want_vectors=_VALUES_ONLY == 0)
-    _, sqrt_trace = K.spectral_sqrt_f64(w2, _EPS, want_values=False)
+    sqrt_trace = _trace_sqrt_values_only(inner, _trace_scale(sigma, sigma_v))
     return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
   # sqrt(sigma) = V^T diag(f(w)) V  (rows of V are eigenvectors); f and every scalar stay on the
   # device: one host read at the very end
@@ -141,9 +186,12 @@ def frechet_distance(real_activations, generated_activations, device="cuda:0"):
   f, _ = K.spectral_sqrt_f64(w, _EPS)
   sqrt_sigma = K.gemm_f64(v, K.rowscale_f64(v, f), ta=True)
   inner = K.gemm_f64(K.gemm_f64(sqrt_sigma, sigma_v), sqrt_sigma)
-  w2, _ = K.syevj_f64(inner, max_sweeps=_SWEEPS, tol=_TOL, want_vectors=_VALUES_ONLY == 0)
-  _, sqrt_trace = K.spectral_sqrt_f64(w2, _EPS, want_values=False)
+  sqrt_trace = _trace_sqrt_values_only(inner, _trace_scale(sigma, sigma_v))
   return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
+
+
+def _trace_scale(sigma, sigma_v):
+  return float(K.mat_stats_f64(sigma).tolist()[0]) + float(K.mat_stats_f64(sigma_v).tolist()[0])
 
 
 class FIDScoreTask(eval_task.EvalTask):

@@ -688,6 +688,24 @@ int cg_rowscale_f64(const double* a, const double* scale, double* out, int rows,
 size_t cg_syevj_workspace_bytes(int d);
 int cg_syevj_f64(double* a, int d, double* w, double* v, int max_sweeps, double tol, void* ws,
                  size_t ws_bytes, cgStream stream);
+/* Eigenvalues only, by Householder tridiagonalisation + Sturm bisection (csrc/cg_tridiag.hip): what
+ * the SECOND matrix square root of the Frechet distance needs -- trace(sqrtm(sqrt(sigma) sigma_v
+ * sqrt(sigma))) is a sum over a spectrum (metrics/fid_score.py:58-75 via tfgan trace_sqrt_product).
+ *   a    [n, n] symmetric fp64, DESTROYED (n <= 4096)
+ *   w    [n] eigenvalues, ascending
+ *   fro_out  optional [1]: |a|_F (of the tridiagonal form, the same number)
+ * Backward stable: w are the exact eigenvalues of a + E with |E|_F a modest multiple of u |a|_F -- an
+ * absolute statement; tiny eigenvalues of a graded matrix carry no relative accuracy (cg_syevj_f64's do).
+ * cg_spectral_sqrt_bound_f64: out2[0] = sum_i f(|w_i|) with tfgan's rule f(s) = s < eps ? s : sqrt(s),
+ * out2[1] = a bound on the error of that sum for |E|_F <= delta_f_rel * *fro and |E|_2 <= d2 =
+ * delta_2_rel * *fro (Hoffman-Wielandt + Cauchy-Schwarz: |E|_F * sqrt(sum_i sup|f'|^2), plus
+ * sqrt(eps + 2 d2) for every value within d2 of the cut-off, where f jumps) -- the certificate under
+ * which metrics/fid_score.py uses this path instead of the Jacobi solve. */
+size_t cg_sytrd_eigvals_workspace_bytes(int n);
+int cg_sytrd_eigvals_f64(double* a, int n, double* w, double* fro_out, void* ws, size_t ws_bytes,
+                         cgStream stream);
+int cg_spectral_sqrt_bound_f64(const double* w, int n, double eps, double delta_f_rel,
+                               double delta_2_rel, const double* fro, double* out2, cgStream stream);
 /* The scalar part of the Frechet distance on the device (fid_score.py:58-75 through tfgan's
  * frechet_classifier_distance_from_activations), so that no host round trip sits between the two
  * eigen-decompositions:

@@ -25,6 +25,19 @@ def gconv(geom, *a, **kw):
 
 
 K.gconv = gconv
+_gconv_ld = K.gconv_ld
+
+
+def gconv_ld(geom, *a, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = _gconv_ld(geom, *a, **kw)
+    e1.record()
+    records.append((geom.key(), 2.0 * geom.N * geom.Ho * geom.Wo * geom.kh * geom.kw * geom.Ci * geom.Co, e0, e1))
+    return out
+
+
+K.gconv_ld = gconv_ld
 net = inception.InceptionV3(dev)
 x = torch.rand((bsz, 32, 32, 3), device=dev) * 255.0
 for _ in range(2):

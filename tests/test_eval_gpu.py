@@ -100,6 +100,58 @@ def test_fid_newton_schulz_path(dev, n, d, cond):
     assert abs(g2 - j2) <= 1e-9 * abs(j2)
 
 
+@pytest.mark.parametrize("n,d", [(100, 256), (3000, 512), (600, 1024)])
+def test_fid_tridiagonal_trace_path(dev, n, d):
+    """The trace of the second matrix square root from eigenvalues by tridiagonalisation + bisection
+    (metrics/fid_score.py: _trace_sqrt_values_only; fid_score.py:58-75 via tfgan trace_sqrt_product): on
+    small-norm features with dead and nearly dead channels (what the seeded extractor of bench.py
+    produces; rank-deficient for n < d) the certificate holds and the distance agrees with the
+    values-only Jacobi solve to 1e-9 and with the oracle to 1e-6; at other feature scales (x 1e2, 1e4,
+    1e6: the rounding level of an absolute-accuracy eigenvalue moves across tfgan's 1e-10 cut-off)
+    whichever path the certificate picks gives the oracle's number; a certificate that cannot hold
+    takes the Jacobi fallback."""
+    from compare_gan_amd.metrics import fid_score
+    rng = np.random.RandomState(n + d)
+    scales = np.geomspace(1e-1, 1e-6, d)
+    scales[::7] = 0.0                                         # dead channels
+    a = (np.maximum(rng.standard_normal((n, d)), 0.0) * scales).astype(np.float32)
+    b = (np.maximum(rng.standard_normal((n, d)) + 0.3, 0.0) * scales[::-1] * 0.5).astype(np.float32)
+    old = (fid_score._SOLVER, fid_score._TRIDIAG)
+    try:
+        fid_score._SOLVER = "jacobi"       # (no Newton-Schulz: dead channels rule it out anyway)
+        fid_score._TRIDIAG = 1
+        got = fid_score.frechet_distance(a, b, device=dev)
+        used, cert = dict(fid_score.LAST_SOLVER), dict(fid_score.LAST_TRIDIAG)
+        fid_score._TRIDIAG = 0
+        jac = fid_score.frechet_distance(a, b, device=dev)
+        assert fid_score.LAST_SOLVER["trace_sqrt"] == "jacobi"
+        fid_score._TRIDIAG = 1
+        scaled = []
+        for sc in (1e2, 1e4, 1e6):
+            val = fid_score.frechet_distance(a * sc, b * sc, device=dev)
+            scaled.append((sc, val, fid_score.LAST_SOLVER["trace_sqrt"], dict(fid_score.LAST_TRIDIAG)))
+        # a certificate that cannot hold: the fallback is taken and gives the Jacobi number
+        fid_score._TRIDIAG_ACCEPT, keep = 1e-30, fid_score._TRIDIAG_ACCEPT
+        try:
+            refused = fid_score.frechet_distance(a, b, device=dev)
+            assert fid_score.LAST_SOLVER["trace_sqrt"] == "jacobi" and not fid_score.LAST_TRIDIAG["accepted"]
+        finally:
+            fid_score._TRIDIAG_ACCEPT = keep
+    finally:
+        fid_score._SOLVER, fid_score._TRIDIAG = old
+    assert used["trace_sqrt"] == "tridiagonal+bisection" and cert["accepted"], (used, cert)
+    assert abs(got - jac) <= 1e-9 * abs(jac), (got, jac)
+    assert refused == jac
+    ref = ofid.frechet_distance(a, b)
+    assert abs(got - ref) <= 1e-6 * abs(ref), (got, ref)
+    # whatever the certificate decides at other feature scales, the number is the oracle's
+    for sc, val, path, c in scaled:
+        ref_sc = ofid.frechet_distance(a * sc, b * sc)
+        assert abs(val - ref_sc) <= 1e-6 * abs(ref_sc), (sc, path, val, ref_sc, c)
+    print("tridiagonal trace path n %d d %d: certificate %s | scaled: %s" % (
+        n, d, cert, [(sc, path, "%.2e" % (2 * c["bound"] / c["scale"])) for sc, _, path, c in scaled]))
+
+
 def test_inception_score_matches_oracle(dev):
     from compare_gan_amd.metrics import inception_score
     rng = np.random.RandomState(3)

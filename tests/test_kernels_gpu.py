@@ -1252,6 +1252,65 @@ def test_syevj_block_form(K, dev, d, rank):
         np.testing.assert_allclose(v @ v.T, np.eye(d), atol=1e-10, err_msg=name)
 
 
+@pytest.mark.parametrize("n,kind", [(2, "random"), (3, "random"), (37, "random"), (128, "psd"),
+                                    (300, "graded"), (512, "rank"), (1000, "psd"), (2048, "graded"),
+                                    (257, "diagonal"), (200, "tridiagonal")])
+def test_tridiagonal_eigenvalues(K, dev, n, kind):
+    """cg_sytrd_eigvals_f64 (Householder tridiagonalisation + Sturm bisection: the eigenvalues behind the
+    trace of the second matrix square root, metrics/fid_score.py:58-75 via tfgan) against LAPACK
+    (numpy.linalg.eigvalsh, fp64): the l2 norm of the eigenvalue errors within a QUARTER of 4 sqrt(n) u
+    |A|_F and the largest one within HALF of a quarter of that (n >= 64) -- the |E|_F and |E|_2
+    metrics/fid_score.py certifies its result with (measured: 1 ... 17 u |A|_F); ascending order; |A|_F
+    returned; cg_spectral_sqrt_bound_f64 equals its definition and really bounds the error of the sum
+    against the sum over LAPACK's eigenvalues."""
+    u = 2.220446049250313e-16
+    rng = np.random.RandomState(n)
+    if kind == "random":
+        a = rng.randn(n, n)
+        a = a + a.T
+    elif kind == "psd":
+        x = rng.randn(3 * n, n) * (rng.rand(n) * 2)
+        a = x.T @ x / (3 * n - 1)
+    elif kind == "graded":       # spectrum over 14 decades, as the covariances of dead-ish features
+        q, _ = np.linalg.qr(rng.randn(n, n))
+        a = (q * np.logspace(-15, -1, n)) @ q.T
+        a = 0.5 * (a + a.T)
+    elif kind == "rank":         # fewer samples than features
+        x = rng.randn(n // 4, n)
+        x -= x.mean(axis=0)
+        a = x.T @ x / (n // 4 - 1)
+    elif kind == "diagonal":
+        a = np.diag(rng.randn(n))
+    else:
+        a = np.diag(rng.randn(n)) + np.diag(rng.randn(n - 1), 1)
+        a = a + np.triu(a, 1).T
+    want = np.linalg.eigvalsh(a)
+    fro_want = np.linalg.norm(a)
+    w, fro = K.sytrd_eigvals_f64(torch.from_numpy(a).to(dev))
+    got = w.cpu().numpy()
+    assert abs(float(fro.item()) - fro_want) <= 1e-12 * fro_want
+    assert np.all(np.diff(got) >= 0)
+    delta_rel = 4.0 * np.sqrt(n) * u
+    delta2_rel = delta_rel / (4.0 if n >= 64 else 1.0)
+    delta, delta2 = delta_rel * fro_want, delta2_rel * fro_want
+    err = np.abs(got - want).max()                     # what Weyl bounds by |E|_2
+    err_f = np.sqrt(((got - want) ** 2).sum())         # what Hoffman-Wielandt bounds by |E|_F
+    assert err <= 0.5 * delta2 and err_f <= 0.25 * delta, (kind, n, err / (u * fro_want), err_f / (u * fro_want))
+    eps = 1e-10
+    f = lambda s: np.where(s < eps, s, np.sqrt(s))
+    out = K.spectral_sqrt_bound_f64(w, eps, delta_rel, delta2_rel, fro).cpu().numpy()
+    ag = np.abs(got)
+    assert abs(out[0] - f(ag).sum()) <= 1e-12 * max(1.0, f(ag).sum())
+    above, below = ag - delta2 >= eps, ag + delta2 < eps
+    g2 = (1.0 / (4.0 * (ag[above] - delta2))).sum() + below.sum()
+    bound = delta * np.sqrt(g2) + (~above & ~below).sum() * np.sqrt(eps + 2 * delta2)
+    assert abs(out[1] - bound) <= 1e-9 * bound
+    assert abs(f(ag).sum() - f(np.abs(want)).sum()) <= out[1]
+    print("tridiagonal eigenvalues n %d %s: max error %.1f u|A|_F, l2 error %.1f u|A|_F (assumed |E|_F %.0f u|A|_F), "
+          "sum error %.2e <= bound %.2e" % (n, kind, err / (u * fro_want), err_f / (u * fro_want), delta_rel / u,
+                                          abs(f(ag).sum() - f(np.abs(want)).sum()), out[1]))
+
+
 def test_inception_preprocess_and_pool(K, dev):
     rng = np.random.RandomState(1)
     img = (rng.rand(2, 32, 32, 3) * 255).astype(np.float32)
@@ -1312,6 +1371,46 @@ def test_gconv_on_channel_slices(K, dev, case):
     # what is not a slice is refused
     with pytest.raises(ValueError):
         K.gconv_ld(geom, x_view.transpose(1, 2), bt, out_wide[..., ob:ob + Co])   # H == W: shape fits, pitch not
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co, kh, kw, padding          what it exercises in cg_conv_fast.hip
+    (64, 35, 35, 96, 96, 3, 3, "SAME"),        # two-deep ring, half-empty last K block
+    (100, 35, 35, 64, 96, 3, 3, "SAME"),       # single buffer, 96 of 128 columns
+    (128, 17, 17, 160, 160, 1, 7, "SAME"),     # 128-wide tiles (grid too small for the wide ones), K 160
+    (256, 17, 17, 160, 192, 7, 1, "SAME"),     # 192-wide tile, two-deep ring, K 160
+    (400, 17, 17, 192, 192, 1, 1, "SAME"),     # 192-wide tile, single buffer
+    (400, 17, 17, 192, 160, 1, 1, "SAME"),     # 192-wide tile with 32 empty columns
+    (8, 73, 73, 96, 192, 3, 3, "VALID"),       # K 96 on the 128-wide tiles
+    (16, 147, 147, 32, 64, 3, 3, "SAME"),      # 64-wide tile, every K block half empty
+    (16, 149, 149, 32, 32, 3, 3, "VALID"),     # 32-wide tile, the same
+    (4, 8, 8, 160, 128, 3, 3, "SAME"),         # 8-wave split-K form, K 160 (slices alternate between groups)
+    (4, 8, 8, 96, 128, 3, 3, "SAME"),          # ... and K 96
+])
+def test_fast_conv_ragged_channel_counts(K, dev, case):
+    """The one-tap MFMA kernel on channel counts that are odd multiples of 32 (the Inception graph of
+    eval_utils.py:165-175: 32 / 96 / 160 / 288 inputs, 96 / 160 / 192 outputs; BigGAN ch = 96): the
+    upper half of a half-empty last 64-channel K block is skipped, and 192-wide output tiles
+    replace quarter-empty 128-wide ones.  conv + bias + ReLU against the fp64 oracle, tolerance of the
+    file header."""
+    N, H, W, Ci, Co, kh, kw, padding = case
+    g = _gen(sum(case[:7]))
+    x64, xb = rand_bf16((N, H, W, Ci), g)
+    w64, wb = rand_bf16((kh, kw, Ci, Co), g, scale=1.0 / math.sqrt(kh * kw * Ci))
+    bias = torch.randn((Co,), generator=g, dtype=torch.float32)
+    if padding == "SAME":
+        geom = K.geom_conv_same(N, H, W, Ci, Co, kh, kw, 1, 1)
+    else:
+        geom = K.make_geom(N, H, W, Ci, H - kh + 1, W - kw + 1, Co, kh, kw, 1, 1, 0, 0)
+    bt = K.weight_prep(wb.float().to(dev), want_fwd=True)[0]
+    got = K.gconv(geom, xb.to(dev), bt, bias=bias.to(dev), act_out=0.0)
+    xp = x64.permute(0, 3, 1, 2)
+    if padding == "SAME":
+        xp = F.pad(xp, (geom.pl, kw - 1 - geom.pl, geom.pt, kh - 1 - geom.pt))
+    ref = F.conv2d(xp.float(), w64.permute(3, 2, 0, 1).float()).double().permute(0, 2, 3, 1) + bias.double()
+    # (fp32 reference convolution of bf16-exact operands: its own error, ~1e-6 relative, is far inside
+    # the bf16 output tolerance; the fp64 one takes minutes at these sizes on the host)
+    assert_close_bf16(got, ref.clamp(min=0.0), "fast conv %s" % (case,))
 
 
 def test_error_codes(K, dev):
