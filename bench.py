@@ -123,9 +123,10 @@ def cpu_baseline(config, batch, budget_s=20.0, mode="step", no_penalty=False):
 
 
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-PMC_TRAFFIC_FILE = next((p for p in (os.path.join(_PROFILES, "r05_pmc_traffic.json"),
+PMC_TRAFFIC_FILE = next((p for p in (os.path.join(_PROFILES, "r06_pmc_traffic.json"),
+                                     os.path.join(_PROFILES, "r05_pmc_traffic.json"),
                                      os.path.join(_PROFILES, "r04_pmc_traffic.json"))
-                         if os.path.exists(p)), os.path.join(_PROFILES, "r05_pmc_traffic.json"))
+                         if os.path.exists(p)), os.path.join(_PROFILES, "r06_pmc_traffic.json"))
 PMC_TRAFFIC_NOTE = ("HBM bytes per launch of this kernel family = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                     "from two rocprofv3 --pmc passes of this workload (scripts/pmc_traffic.py -> "
                     "profiles/%s, one table per workload; counters cannot be read from inside the "

@@ -11,7 +11,7 @@
 #   stats WORKLOAD [TAG]            rocprofv3 --kernel-trace --stats summary (csv):
 #                                   WORKLOAD = cifar | fid | resnet128_dstep | resnet128_dstep_gp | biggan128
 #   traffic WORKLOAD                the two --pmc passes (FETCH_SIZE, WRITE_SIZE; own runs, no other
-#                                   trace domain) + scripts/pmc_traffic.py -> gpurun_out/r05_pmc_traffic.json
+#                                   trace domain) + scripts/pmc_traffic.py -> gpurun_out/r06_pmc_traffic.json
 #                                   WORKLOAD = cifar | resnet128_dstep
 #   ab VAR V1,V2,... LEG [TAG]      the same build under VAR=V1, VAR=V2, ... on one box (boxes of the
 #                                   pool differ by +-15 % in clocks): bench.py --legs LEG, prints the
@@ -89,7 +89,7 @@ case $task in
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$W /tmp/pw_$W &&
       timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$W -o p -- $CMD > "$R/gpurun_out/traffic_pf_$W.log" 2>&1 &&
       timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$W -o p -- $CMD > "$R/gpurun_out/traffic_pw_$W.log" 2>&1 )
-    python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r05_pmc_traffic.json $W | head -14 ;;
+    python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r06_pmc_traffic.json $W | head -14 ;;
   ab) VAR=$1; VALS=$2; LEG=$3; TAG=${4:-ab}
     for v in ${VALS//,/ }; do
       env $VAR=$v timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fid --no-roofline --legs $LEG \

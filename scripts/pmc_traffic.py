@@ -22,6 +22,7 @@ FAMILIES = [
     (r"swgrad_kernel", "swgrad_kernel<*>"),
     (r"wstem_fwd_kernel", "stem_fwd_kernel<*>"),
     (r"wstem_wgrad_kernel", "stem_wgrad_kernel<*>"),
+    (r"fast_conv(_sk)?_kernel<128, 192", "fast_conv_kernel<128, 192, *>"),
     (r"fast_conv(_sk)?_kernel<128, 128", "fast_conv_kernel<128, 128, *>"),
     (r"fast_conv(_sk)?_kernel<64, 128", "fast_conv_kernel<64, 128, *>"),
     (r"fast_conv(_sk)?_kernel<128, 64", "fast_conv_kernel<128, 64, *>"),

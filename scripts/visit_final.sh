@@ -5,7 +5,7 @@
 #   gpurun --timeout 3000 -- 'bash scripts/visit_final.sh TAG'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
-T=${1:-r05_final}
+T=${1:-r06_final}
 mkdir -p gpurun_out
 echo "== bench (all legs)"; date +%s
 timeout 1200 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
@@ -24,14 +24,18 @@ stats fid python $R/bench.py --steps 2 --warmup 1 --preheat-s 0 --no-cpu-baselin
 stats resnet128_dstep python $R/scripts/run_leg_eager.py resnet128_dstep 3
 stats biggan128_bs256 python $R/scripts/run_leg_eager.py biggan128_bs256 3
 echo "== PMC traffic (FETCH_SIZE / WRITE_SIZE, own passes)"; date +%s
-for W in cifar resnet128_dstep; do
+for W in cifar resnet128_dstep biggan128_bs256; do
   case $W in cifar) CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fid --no-legs --preheat-s 0" ;;
              *) CMD="python $R/scripts/run_leg_eager.py $W 2" ;; esac
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$W /tmp/pw_$W &&
     timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$W -o p -- $CMD > "$R/gpurun_out/${T}_pf_$W.log" 2>&1 &&
     timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$W -o p -- $CMD > "$R/gpurun_out/${T}_pw_$W.log" 2>&1 )
-  python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r05_pmc_traffic.json $W | head -8
+  python scripts/pmc_traffic.py /tmp/pf_$W /tmp/pw_$W gpurun_out/r06_pmc_traffic.json $W | head -12
 done
+# the committed traffic table bench.py reads must not be older than the library
+if [ -f profiles/r06_pmc_traffic.json ] && [ profiles/r06_pmc_traffic.json -ot compare_gan_amd/lib/libcgamd.so ]; then
+  echo "NOTE: profiles/r06_pmc_traffic.json is older than libcgamd.so -- copy gpurun_out/r06_pmc_traffic.json over it after this visit"
+fi
 echo "== forced DP (one-rank RCCL group, overlap off / on)"; date +%s
 for ov in 0 1; do
   CGAMD_FORCE_DP=1 CGAMD_DP_OVERLAP=$ov CGAMD_DP_BUCKET_MIN_MB=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=2956$ov \
