@@ -84,6 +84,8 @@ struct FastConvArgs {
   int Hp, Wp, Mp;  // per-phase output grid (Ho/U, Wo/U) and N*Hp*Wp
   int cblocks;     // Ci / 64
   int mtiles, ntiles;
+  int gm;          // M tiles per tile group (1: all N tiles of an M tile are consecutive work ids)
+  FastDiv dGrp;    // gm * ntiles
   int relu_in, out_f32;
   int self_gate;  // gate_out == out: the output activation is applied to the value itself
   float slope_out;
@@ -136,8 +138,24 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
   TSTAMP();   // 0: kernel entry
   const int wm = wave / WN, wn = wave % WN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = (int)fdiv((uint32_t)wg, a.dNt);
-  const int nt = wg - mt * a.ntiles;
+  // work id -> (M tile, N tile).  gm == 1: the N tiles of an M tile are consecutive (they share the
+  // activation rows; the weight panels of all N tiles have to fit the XCD's L2 beside them).  Weight
+  // images far larger than an L2 (BigGAN's 3x3x1536x1536: 42 MB) were streamed once per ~6 M tiles that
+  // happened to run together (counter traffic 10x algorithmic, profiles/r06_pmc_traffic.json); with
+  // gm > 1 a group of gm M tiles walks the N tiles together, M fastest: the workgroups in flight on an XCD
+  // hold gm activation tiles and only ~64 / gm weight panels.
+  int mt, nt;
+  if (a.gm <= 1) {
+    mt = (int)fdiv((uint32_t)wg, a.dNt);
+    nt = wg - mt * a.ntiles;
+  } else {
+    const int grp = (int)fdiv((uint32_t)wg, a.dGrp);
+    const int r = wg - grp * a.gm * a.ntiles;
+    const int mb = grp * a.gm;
+    const int gcur = min(a.gm, a.mtiles - mb);   // the last group may be short
+    nt = r / gcur;
+    mt = mb + (r - nt * gcur);
+  }
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- phase geometry (wave-uniform) ----
@@ -2200,6 +2218,8 @@ void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, cons
   FastConvArgs a;
   a.in_ld = in_ld;
   a.out_ld = out_ld;
+  a.gm = 1;
+  a.dGrp = make_fastdiv(1);
   a.in = (const bf16_t*)in;
   a.bt = (const bf16_t*)bt;
   a.out = out;
@@ -2375,6 +2395,19 @@ void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, cons
   const int tiles64 = cdiv(a.Mp, 64) * a.ntiles * phases;
   if (tiles128 >= t128_min || (tiles128 <= 256 && tiles64 > 256 && tiles64 <= 384)) {
     a.mtiles = cdiv(a.Mp, 128);
+    // tile groups (see the kernel) where the weight image dwarfs an XCD's 4 MB L2 and there are enough M
+    // tiles to form groups; CGAMD_CONV_GM = group height (1 = off, 0 = this policy)
+    static const int gm_env = [] {
+      const char* e = getenv("CGAMD_CONV_GM");
+      return e ? atoi(e) : 0;
+    }();
+    const int64_t wbytes = (int64_t)g->Co * a.Kp * 2;
+    int gm = gm_env ? gm_env : ((wbytes >= (8ll << 20) && a.mtiles >= 32 && a.ntiles >= 2) ? 16 : 1);
+    if (gm > a.mtiles) gm = a.mtiles;
+    if (gm > 1) {
+      a.gm = gm;
+      a.dGrp = make_fastdiv(gm * a.ntiles);
+    }
     dim3 grid(a.mtiles * a.ntiles, phases);
     CgProfScope prof(CG_PROF_FAST_CONV_128x128, g, st);
     CG_LAUNCH_CONV(128, 128, grid);

@@ -443,7 +443,9 @@ __global__ __launch_bounds__(1024) void rowdot_linear_kernel(GConvArgs a) {
 // block = 64 rows x ONE 8-channel group; wave w takes the 8-element K pieces w, w + 4, ... (the
 // weight loads of a wave are uniform), lane -> row; the four partial sums meet in LDS.  The 8 weight
 // rows of a group are read once per 64 rows (a wave per output re-read them per row: 100 MB of L2
-// traffic for a 0.5 MB matrix).
+// traffic for a 0.5 MB matrix).  Round 6 tried the x tile staged in LDS with coalesced loads, four
+// channel groups per block, one wave per group over the whole K: 178.1 / 178.5 -> 179.5 / 179.5 ms on the
+// BigGAN bs-256 step (a quarter of the blocks, a serial K loop per wave) -- not kept.
 __global__ __launch_bounds__(256) void small_linear_kernel(GConvArgs a) {
   __shared__ float part[4][64][9];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

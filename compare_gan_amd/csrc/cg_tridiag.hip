@@ -16,7 +16,7 @@
 //                           per element and step, n^3 / 3 * 16 B = 46 GB at n = 2048
 //   the step index lives on the device, so one captured hipGraph of TD_CHUNK (S, P) pairs is replayed
 //   ceil(n / TD_CHUNK) times (4094 dependent launches otherwise);
-//   then every eigenvalue by bisection on the Sturm count of (d, e), one thread each.
+//   then every eigenvalue by multisection on the Sturm count of (d, e), one wave each.
 //
 // Accuracy: backward stable -- the computed values are the exact eigenvalues of A + E, |E|_F a modest
 // multiple of u |A|_F (measured against LAPACK: <= 17 u |A|_F in the Frobenius sense for n <= 2048,
@@ -151,48 +151,84 @@ __global__ __launch_bounds__(256) void td_p_kernel(double* __restrict__ a, int n
   }
 }
 
-// Sturm count bisection (LAPACK dstebz's recurrence): thread j -> the j-th smallest eigenvalue.  The
-// loop index is wave-uniform, so d[i] / e[i]^2 arrive through the scalar cache.  Block 0 also writes
-// |T|_F = |A|_F.
-__global__ __launch_bounds__(64) void td_bisect_kernel(const double* __restrict__ dd,
-                                                       const double* __restrict__ ee, int n,
-                                                       double* __restrict__ w,
-                                                       double* __restrict__ fro_out) {
+// Gershgorin interval, pivmin and |T|_F = |A|_F of (d, e): bnd = {gl, gu, pivmin, fro}.
+__global__ __launch_bounds__(256) void td_bounds_kernel(const double* __restrict__ dd,
+                                                        const double* __restrict__ ee, int n,
+                                                        double* __restrict__ bnd) {
+  __shared__ double sm[4][4];
   double gl = DBL_MAX, gu = -DBL_MAX, emax2 = 0.0, fro2 = 0.0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = threadIdx.x; i < n; i += 256) {
     const double el = i > 0 ? fabs(ee[i - 1]) : 0.0, er = i < n - 1 ? fabs(ee[i]) : 0.0;
     gl = fmin(gl, dd[i] - el - er);
     gu = fmax(gu, dd[i] + el + er);
     emax2 = fmax(emax2, er * er);
     fro2 += dd[i] * dd[i] + 2.0 * er * er;
   }
-  if (fro_out && blockIdx.x == 0 && threadIdx.x == 0) *fro_out = sqrt(fro2);
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const double pivmin = DBL_MIN * fmax(1.0, emax2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gl = fmin(gl, __shfl_xor(gl, o, 64));
+    gu = fmax(gu, __shfl_xor(gu, o, 64));
+    emax2 = fmax(emax2, __shfl_xor(emax2, o, 64));
+  }
+  fro2 = wave_sum_d(fro2);
+  if ((threadIdx.x & 63) == 0) {
+    const int wv = threadIdx.x >> 6;
+    sm[0][wv] = gl; sm[1][wv] = gu; sm[2][wv] = emax2; sm[3][wv] = fro2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bnd[0] = fmin(fmin(sm[0][0], sm[0][1]), fmin(sm[0][2], sm[0][3]));
+    bnd[1] = fmax(fmax(sm[1][0], sm[1][1]), fmax(sm[1][2], sm[1][3]));
+    bnd[2] = DBL_MIN * fmax(1.0, fmax(fmax(sm[2][0], sm[2][1]), fmax(sm[2][2], sm[2][3])));
+    bnd[3] = sqrt((sm[3][0] + sm[3][1]) + (sm[3][2] + sm[3][3]));
+  }
+}
+
+// Sturm-count multisection (LAPACK dstebz's recurrence): ONE WAVE per eigenvalue j -- its 64 lanes count
+// the eigenvalues below 64 interior points of the current interval, the sub-interval in which the count
+// crosses j + 1 is the next one: 6 bits per pass instead of bisection's one, ~9 passes of n dependent
+// divisions instead of ~56 (a thread per eigenvalue measured 25 ms at n = 2048: a latency-bound chain on
+// one wave per CU).  The loop index is wave-uniform, so d[i] / e[i]^2 arrive through the scalar cache.
+// Invariant: count(lo) < j + 1 <= count(hi).
+__global__ __launch_bounds__(64) void td_bisect_kernel(const double* __restrict__ dd,
+                                                       const double* __restrict__ ee, int n,
+                                                       const double* __restrict__ bnd,
+                                                       double* __restrict__ w,
+                                                       double* __restrict__ fro_out) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  const double gl = bnd[0], gu = bnd[1], pivmin = bnd[2];
+  if (fro_out && j == 0 && lane == 0) *fro_out = bnd[3];
   const double tn = fmax(fabs(gl), fabs(gu));
   double lo = gl - 2.0 * DBL_EPSILON * n * tn - 2.0 * pivmin;
   double hi = gu + 2.0 * DBL_EPSILON * n * tn + 2.0 * pivmin;
-  const int want = (j < n ? j : n - 1) + 1;
-  for (int it = 0; it < 128; ++it) {
-    const double mid = 0.5 * (lo + hi);
-    // every lane runs the same trip count: the stopping test is wave-collective
-    const bool done = !(hi - lo > 2.0 * DBL_EPSILON * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) ||
-                      mid <= lo || mid >= hi;
-    if (__all(done)) break;
-    double q = dd[0] - mid;
+  const int want = j + 1;
+  for (int pass = 0; pass < 24; ++pass) {
+    if (!(hi - lo > 2.0 * DBL_EPSILON * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin)) break;
+    const double x = lo + (hi - lo) * ((double)(lane + 1) / 65.0);
+    double q = dd[0] - x;
     if (fabs(q) < pivmin) q = -pivmin;
     int cnt = q < 0.0;
     for (int i = 1; i < n; ++i) {
       const double e2 = ee[i - 1] * ee[i - 1];
-      q = dd[i] - mid - e2 / q;
+      q = dd[i] - x - e2 / q;
       if (fabs(q) < pivmin) q = -pivmin;
       cnt += q < 0.0;
     }
-    if (!done) {
-      if (cnt >= want) hi = mid; else lo = mid;
+    // the points ascend with the lane and the count is monotone in x (up to rounding: the FIRST lane
+    // whose count reaches j + 1 is taken, as bisection would)
+    const unsigned long long ge = __ballot(cnt >= want);
+    if (ge == 0ull) {
+      lo = __shfl(x, 63, 64);
+    } else {
+      const int first = __ffsll((long long)ge) - 1;
+      const double nhi = __shfl(x, first, 64);
+      const double nlo = __shfl(x, first > 0 ? first - 1 : 0, 64);
+      if (first > 0) lo = nlo;
+      hi = nhi;
     }
+    if (!(hi > lo)) break;   // the interval collapsed to neighbouring floating-point numbers
   }
-  if (j < n) w[j] = 0.5 * (lo + hi);
+  if (lane == 0) w[j] = 0.5 * (lo + hi);
 }
 
 // out[0] = sum_i f(|w_i|), f(s) = s < eps ? s : sqrt(s) (tfgan's _symmetric_matrix_square_root rule);
@@ -238,8 +274,8 @@ size_t td_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t cg_sytrd_eigvals_workspace_bytes(int n) {
   if (n <= 0) return 0;
-  // ctr (256 B) + vb [2n] + wv [n] + pv [n] + col [n] + dd [n] + ee [n] + tau [2]
-  return 256 + td_align((size_t)(7 * (size_t)n + 2) * sizeof(double));
+  // ctr (256 B) + vb [2n] + wv [n] + pv [n] + col [n] + dd [n] + ee [n] + tau [2] + bnd [4]
+  return 256 + td_align((size_t)(7 * (size_t)n + 6) * sizeof(double));
 }
 
 extern "C" int cg_sytrd_eigvals_f64(double* a, int n, double* w, double* fro_out, void* ws,
@@ -258,6 +294,7 @@ extern "C" int cg_sytrd_eigvals_f64(double* a, int n, double* w, double* fro_out
   double* dd = col + n;
   double* ee = dd + n;
   double* tau = ee + n;
+  double* bnd = tau + 2;
   const size_t lds = (size_t)3 * n * sizeof(double);
   static const bool attr_set = [] {
     (void)hipFuncSetAttribute((const void*)td_p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -316,7 +353,8 @@ extern "C" int cg_sytrd_eigvals_f64(double* a, int n, double* w, double* fro_out
   }
   if (!done) launch_chunk(st, n);
   CG_CHECK_LAUNCH("cg_sytrd_eigvals_f64(steps)");
-  td_bisect_kernel<<<(n + 63) / 64, 64, 0, st>>>(dd, ee, n, w, fro_out);
+  td_bounds_kernel<<<1, 256, 0, st>>>(dd, ee, n, bnd);
+  td_bisect_kernel<<<n, 64, 0, st>>>(dd, ee, n, bnd, w, fro_out);
   CG_CHECK_LAUNCH("cg_sytrd_eigvals_f64(bisection)");
   return CG_OK;
 }

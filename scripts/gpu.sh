@@ -52,8 +52,8 @@ PY
 }
 stats_cmd() {   # WORKLOAD -> command line profiled
   case $1 in
-    cifar) echo "python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-fid --no-legs" ;;
-    fid) echo "python $R/bench.py --steps 2 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-roofline --no-legs" ;;
+    cifar) echo "python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-fid --no-legs --no-calibration" ;;
+    fid) echo "python $R/bench.py --steps 2 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-roofline --no-legs --no-calibration" ;;
     *) echo "python $R/scripts/run_leg_eager.py $1 3" ;;
   esac
 }
@@ -84,7 +84,7 @@ case $task in
     leg_summary gpurun_out/${TAG}_bench.json $LEG; wc -l gpurun_out/${TAG}_$LEG.txt ;;
   stats) run_stats $1 ${2:-stats} ;;
   traffic) W=$1
-    case $W in cifar) CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fid --no-legs --preheat-s 0" ;;
+    case $W in cifar) CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fid --no-legs --preheat-s 0 --no-calibration" ;;
                *) CMD="python $R/scripts/run_leg_eager.py $W 2" ;; esac
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$W /tmp/pw_$W &&
       timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$W -o p -- $CMD > "$R/gpurun_out/traffic_pf_$W.log" 2>&1 &&

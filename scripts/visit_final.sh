@@ -19,13 +19,13 @@ stats() {  # NAME CMD...
   cp "$(find /tmp/p_$name -name '*kernel_stats.csv' | head -1)" gpurun_out/${T}_${name}_kernel_stats.csv
   head -4 gpurun_out/${T}_${name}_kernel_stats.csv | cut -c1-140
 }
-stats cifar python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-fid --no-legs
-stats fid python $R/bench.py --steps 2 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-roofline --no-legs
+stats cifar python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-fid --no-legs --no-calibration
+stats fid python $R/bench.py --steps 2 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-roofline --no-legs --no-calibration
 stats resnet128_dstep python $R/scripts/run_leg_eager.py resnet128_dstep 3
 stats biggan128_bs256 python $R/scripts/run_leg_eager.py biggan128_bs256 3
 echo "== PMC traffic (FETCH_SIZE / WRITE_SIZE, own passes)"; date +%s
 for W in cifar resnet128_dstep biggan128_bs256; do
-  case $W in cifar) CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fid --no-legs --preheat-s 0" ;;
+  case $W in cifar) CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fid --no-legs --preheat-s 0 --no-calibration" ;;
              *) CMD="python $R/scripts/run_leg_eager.py $W 2" ;; esac
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf_$W /tmp/pw_$W &&
     timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$W -o p -- $CMD > "$R/gpurun_out/${T}_pf_$W.log" 2>&1 &&

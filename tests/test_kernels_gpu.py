@@ -130,6 +130,7 @@ CONV_CASES = [
     # small linear layers with K % 8 != 0 (small_linear_kernel): conditional-BN projection, label
     # embedding, ragged rows / channels
     ("lin_148", 64, 1, 1, 148, 192, 1, 1, 1),
+    ("lin_148_wide", 200, 1, 1, 148, 1536, 1, 1, 1),   # conditional-BN projection at a ragged batch
     ("lin_1000", 70, 1, 1, 1000, 128, 1, 1, 1),
     ("lin_ragged", 5, 1, 1, 21, 20, 1, 1, 1),
     # few outputs, long K (rowdot_linear_kernel): the final linear of the DCGAN / SNDCGAN discriminators
@@ -1436,6 +1437,8 @@ CONV_VARIANT_ENVS = [
     ("single_buffer", {"CGAMD_CONV_SK": "0", "CGAMD_CONV_NS": "1"}),
     ("tiles128", {"CGAMD_CONV_SK": "0", "CGAMD_CONV_T128_MIN": "1"}),   # 128x128 tiles everywhere
     ("splitk_tiles128", {"CGAMD_CONV_T128_MIN": "1"}),
+    # groups of 3 M tiles walk the N tiles together (the order of weight-heavy layers; ragged last group)
+    ("tile_groups", {"CGAMD_CONV_SK": "0", "CGAMD_CONV_T128_MIN": "1", "CGAMD_CONV_GM": "3"}),
     ("halo_forward", {"CGAMD_HALO": "1"}),             # experimental halo-staged forward kernel
     ("one_tap_wgrad", {"CGAMD_NO_HALO_WGRAD": "1"}),   # one-tap-per-workgroup weight gradient
     # halo-staged forward / weight-gradient kernels wherever they apply
@@ -1449,7 +1452,15 @@ CONV_VARIANT_ENVS = [
     ("no_small", {"CGAMD_SCONV": "0", "CGAMD_SWGRAD": "0"}),
     # 512 weight-gradient workgroups (the policy of the large-batch layers: hwgrad_plan)
     ("hwgrad_512_blocks", {"CGAMD_HWGRAD_BLOCKS": "512", "CGAMD_HWGRAD_MIN": "1"}),
+    # 128-wide tiles where the default takes 192-wide ones (Inception's 160 / 192-channel layers)
+    ("no_wide_tiles", {"CGAMD_CONV_BN_WIDE": "0"},
+     "test_fast_conv_ragged_channel_counts or test_gconv_on_channel_slices"),
 ]
+_VARIANT_DEFAULT_CASES = (
+    "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual or "
+    "test_stem_relu_gate or (test_conv_pool_fused and not full_size) or "
+    "(test_gconv_fused_batch_norm and not full_size) or "
+    "test_gconv_fused_statistics_groups")
 
 
 @pytest.mark.gpu
@@ -1461,12 +1472,10 @@ def test_conv_kernel_variants(dev, variant):
     env = dict(os.environ)
     env.update(variant[1])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = variant[2] if len(variant) > 2 else _VARIANT_DEFAULT_CASES
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q",
-                        "-x", "-k", "test_gconv_forward_adjoint_wgrad or test_gconv_gates_residual or "
-                        "test_stem_relu_gate or (test_conv_pool_fused and not full_size) or "
-                        "(test_gconv_fused_batch_norm and not full_size) or "
-                        "test_gconv_fused_statistics_groups"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                        "-x", "-k", cases],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "variant %s:\n%s\n%s" % (variant[0], r.stdout[-3000:], r.stderr[-1000:])
 
 

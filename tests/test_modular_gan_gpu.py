@@ -579,6 +579,24 @@ def test_biggan_d_substep_at_the_c5_batch(dev):
     torch.cuda.empty_cache()
 
 
+def test_biggan_g_substep_at_half_the_c5_batch(dev):
+    """The generator sub-step of the same configuration at 128 per GPU (the parity
+    of the G sub-step stopped at batch 64).  256 was tried first: the fp64 autograd graph of the
+    device-resident oracle through G and D at 128 x 128 needs more than the 288 GB of the card (269 GB
+    allocated when it gave up), so this is the largest power of two whose oracle fits; the kernels'
+    batch-dependent choices at 256 (tile sizes, pixel splits, grouped launches) are covered by the D
+    sub-step test above on 512 images and the generator forward at 256.  Generator forward with
+    gradients, the discriminator on the generated images, hinge generator loss, every generator
+    gradient and the power-iteration vectors against the bf16-storage oracle; the D sub-step runs
+    first, as in a training step.  gans/modular_gan.py:486-508, resnet_biggan.py:99-151,344-425."""
+    torch.cuda.empty_cache()
+    _biggan_family_forward_and_gradients(
+        dev, "biggan-ch96-bs128-g", [], dict(hierarchical_z=True, embed_y=True, ch=96),
+        dict(project_y=True, ch=96), bsz=128, oracle_device=dev, g_step=True,
+        fwd_tol=(0.03, 2e-3), d_tol=(0.999, 0.06), g_tol=(0.999, 0.06))
+    torch.cuda.empty_cache()
+
+
 def test_biggan_256px(dev):
     """resnet_biggan at 256x256 (resnet_biggan.py:205-221,344-361: seven blocks, attention at 64x64
     in G after B4 and at 128x128 in D after B1 -- 16,384 queries x 4,096 keys), width ch = 32 (the
