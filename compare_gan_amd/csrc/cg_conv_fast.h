@@ -18,6 +18,11 @@ void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, cons
                             const void* gate_out, float slope_out, const void* residual,
                             hipStream_t st);
 
+// ... conv + bias with ReLU on the output channels [0, relu_cols) only (relu_cols % 8 == 0)
+void cg_fast_conv_launch_ld_cols(const cgConvGeom* g, const void* in, int in_ld, const void* bt,
+                                 void* out, int out_ld, int out_is_f32, const float* bias,
+                                 int relu_cols, hipStream_t st);
+
 // halo-staged kernel for unit-stride <= 3x3 filters on >= 16x16 maps (cg_conv_halo.hip)
 bool cg_hconv_supported(const cgConvGeom* g, const void* in, const void* gate_in, float slope_in);
 bool cg_hconv_narrow(const cgConvGeom* g);   // Co < 8: scalar epilogue, no gate tensor / residual

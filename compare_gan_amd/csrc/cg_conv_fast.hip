@@ -88,6 +88,8 @@ struct FastConvArgs {
   FastDiv dGrp;    // gm * ntiles
   int relu_in, out_f32;
   int self_gate;  // gate_out == out: the output activation is applied to the value itself
+  int gate_cols;  // ... to output channels [0, gate_cols) only (a multiple of 8; Co: all of them) -- the
+                  // coalesced epilogue (Co % 8 == 0); cg_gconv_ld's relu_cols
   float slope_out;
   FastDiv dWp, dHp, dNt;
 #ifdef CG_CONV_TIMING
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 3 : 1) void fast_conv_kernel(FastCon
                 const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + col);
                 v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
               }
-              if (a.self_gate) {
+              if (a.self_gate && n0 + col < a.gate_cols) {
                 if (!(v.x > 0.f)) v.x *= a.slope_out;
                 if (!(v.y > 0.f)) v.y *= a.slope_out;
                 if (!(v.z > 0.f)) v.z *= a.slope_out;
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(512) void fast_conv_sk_kernel(FastConvArgs a) {
                 const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + col);
                 v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
               }
-              if (a.self_gate) {
+              if (a.self_gate && n0 + col < a.gate_cols) {
                 if (!(v.x > 0.f)) v.x *= a.slope_out;
                 if (!(v.y > 0.f)) v.y *= a.slope_out;
                 if (!(v.z > 0.f)) v.z *= a.slope_out;
@@ -1396,7 +1398,10 @@ __device__ __forceinline__ bf16_t stem_gather(const StemArgs& a, const StemTap* 
   return v;
 }
 
-// forward: block = 128 pixels x all output channels.  LDS: A [128][KS], W [Co<=128][KS].
+// forward: block = 128 pixels x the 128 output channels from 128 * blockIdx.y (one such tile for the
+// stems proper; the data gradient of a generator's RGB convolution, read as a 3 -> 256 channel
+// convolution, takes two -- it ran the generic gather kernel at 16 TFLOP/s, 52 us per cifar step).
+// LDS: A [128][KS], W [128][KS].
 template <int KS>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   constexpr int LDA = KS + 8;  // +16 B row padding: conflict-free ds_read_b128 fragments
@@ -1405,13 +1410,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   __shared__ StemTap taps[KS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * 128;
+  const int cb = blockIdx.y * 128;   // first output channel of this block
   stem_build_taps(a, taps, KS);
   __syncthreads();
   // weights -> LDS (zero rows / columns beyond Co / K)
   for (int i = tid; i < 128 * (KS / 8); i += 256) {
     const int row = i / (KS / 8), ch = i % (KS / 8);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < a.Co && ch * 8 < a.Kp) v = *reinterpret_cast<const uint4*>(a.bt + (int64_t)row * a.Kp + ch * 8);
+    if (cb + row < a.Co && ch * 8 < a.Kp)
+      v = *reinterpret_cast<const uint4*>(a.bt + (int64_t)(cb + row) * a.Kp + ch * 8);
     *reinterpret_cast<uint4*>(Ws + row * LDA + ch * 8) = v;
   }
   // im2col tile: thread -> pixel (tid & 127), k half (tid >> 7)
@@ -1438,7 +1445,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   const int frow = lane & 31;
   const int m = m0 + wave * 32 + frow;
   const int64_t opix = (int64_t)m * a.Co;
-  const int nct = (a.Co + 31) / 32;
+  const int nct = (min(a.Co - cb, 128) + 31) / 32;
   for (int ct = 0; ct < nct; ++ct) {
     f32x16_t acc;
 #pragma unroll
@@ -1453,7 +1460,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     if (m >= a.M) continue;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int co = ct * 32 + q * 8 + 4 * (lane >> 5);
+      const int co = cb + ct * 32 + q * 8 + 4 * (lane >> 5);
       if (co >= a.Co) continue;
       if ((a.Co & 3) == 0) {
         float v[4] = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
@@ -2204,6 +2211,17 @@ void cg_fast_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
                          residual, st);
 }
 
+static thread_local int g_gate_cols = -1;   // cg_fast_conv_launch_ld_cols -> cg_fast_conv_launch_ld
+
+void cg_fast_conv_launch_ld_cols(const cgConvGeom* g, const void* in, int in_ld, const void* bt,
+                                 void* out, int out_ld, int out_is_f32, const float* bias,
+                                 int relu_cols, hipStream_t st) {
+  g_gate_cols = relu_cols;
+  cg_fast_conv_launch_ld(g, in, in_ld, bt, out, out_ld, out_is_f32, bias, nullptr,
+                         relu_cols > 0 ? out : nullptr, 0.f, nullptr, st);
+  g_gate_cols = -1;
+}
+
 bool cg_fast_conv_ld_supported(const cgConvGeom* g, int in_ld, int out_ld) {
   if (in_ld < g->Ci || out_ld < g->Co || (in_ld % 8) != 0 || (out_ld % 8) != 0 || (g->Co % 8) != 0)
     return false;
@@ -2225,6 +2243,7 @@ void cg_fast_conv_launch_ld(const cgConvGeom* g, const void* in, int in_ld, cons
   a.out = out;
   a.bias = bias;
   a.self_gate = (gate_out != nullptr && gate_out == out);
+  a.gate_cols = g_gate_cols >= 0 ? g_gate_cols : g->Co;
   a.gate_out = a.self_gate ? nullptr : (const bf16_t*)gate_out;
   a.residual = (const bf16_t*)residual;
   a.N = g->N; a.Hin = g->Hin; a.Win = g->Win; a.Ci = g->Ci;
@@ -2446,7 +2465,7 @@ static void stem_fill(const cgConvGeom* g, StemArgs* a) {
 bool cg_stem_conv_supported(const cgConvGeom* g, const void* in, const void* out,
                             const void* gate_in, float slope_in, const void* gate_out,
                             const void* residual) {
-  if (!stem_geom_ok(g) || g->Co > 128 || (gate_out && gate_out != out) || residual) return false;
+  if (!stem_geom_ok(g) || g->Co > 1024 || (gate_out && gate_out != out) || residual) return false;
   if (gate_in && !(gate_in == in && slope_in == 0.f)) return false;
   return true;
 }
@@ -2461,7 +2480,7 @@ void cg_stem_conv_launch(const cgConvGeom* g, const void* in, const void* bt, vo
   a.in = (const bf16_t*)in; a.bt = (const bf16_t*)bt; a.dy = nullptr; a.out = out; a.bias = bias;
   a.relu_in = gate_in != nullptr; a.out_f32 = out_is_f32; a.want_bias = 0; a.rows_per_split = 0;
   a.adjoint_out = 0;
-  const int grid = cdiv(a.M, 128);
+  const dim3 grid(cdiv(a.M, 128), cdiv(g->Co, 128));
   CgProfScope prof(CG_PROF_STEM_FWD, g, st);
   switch (a.KS) {
     case 32: stem_fwd_kernel<32><<<grid, 256, 0, st>>>(a); break;

@@ -380,10 +380,14 @@ __global__ void pool2d_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
 // 8 channels per thread (16-byte loads / stores), C % 8 == 0: the Inception stages pool 64 ... 2048
 // channels and are pure HBM streams; the scalar form above ran at a tenth of the bandwidth
 // (1 ms per call on 512 x 35 x 35 x 288: as much time as all convolutions of the network).
+// x_ld / y_ld: elements between consecutive pixels of x / y (C when dense; wider for channel slices of
+// a concatenation, cg_pool2d_ld); bias (fp32 [C] or NULL) and relu finish the pooled value.
 __global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restrict__ x, int N,
                                                           int H, int W, int C8, int k, int s,
                                                           int p, int kind, int Ho, int Wo,
-                                                          bf16_t* __restrict__ y) {
+                                                          bf16_t* __restrict__ y, int x_ld, int y_ld,
+                                                          const float* __restrict__ bias,
+                                                          int relu) {
   const int64_t total = (int64_t)N * Ho * Wo * C8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restri
           ok[r * 3 + t] = ih >= 0 && ih < H && iw >= 0 && iw < W;
           const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
           raw[r * 3 + t] = *reinterpret_cast<const uint4*>(
-              x + ((((int64_t)n * H + ihc) * W + iwc) * C8 + c8) * 8);
+              x + (((int64_t)n * H + ihc) * W + iwc) * x_ld + c8 * 8);
         }
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restri
         const int iw = ow * s - p + t;
         if (iw < 0 || iw >= W) continue;
         const uint4 raw = *reinterpret_cast<const uint4*>(
-            x + ((((int64_t)n * H + ih) * W + iw) * C8 + c8) * 8);
+            x + (((int64_t)n * H + ih) * W + iw) * x_ld + c8 * 8);
         float v[8];
         unpack8_bf16(raw, v);
 #pragma unroll
@@ -442,7 +446,17 @@ __global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = acc[e] / d;
     }
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8_bf16(acc);
+    if (bias) {   // kernel-uniform
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+      acc[0] += b0.x; acc[1] += b0.y; acc[2] += b0.z; acc[3] += b0.w;
+      acc[4] += b1.x; acc[5] += b1.y; acc[6] += b1.z; acc[7] += b1.w;
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + (i / C8) * y_ld + c8 * 8) = pack8_bf16(acc);
   }
 }
 
@@ -899,13 +913,32 @@ extern "C" int cg_pool2d(const void* x, int N, int H, int W, int C, int k, int s
     int64_t blocks = (units + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     pool2d_vec8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(
-        (const bf16_t*)x, N, H, W, C / 8, k, s, p, kind, Ho, Wo, (bf16_t*)y);
+        (const bf16_t*)x, N, H, W, C / 8, k, s, p, kind, Ho, Wo, (bf16_t*)y, C, C, nullptr, 0);
     CG_CHECK_LAUNCH("cg_pool2d");
     return CG_OK;
   }
   pool2d_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
       (const bf16_t*)x, N, H, W, C, k, s, p, kind, Ho, Wo, (bf16_t*)y);
   CG_CHECK_LAUNCH("cg_pool2d");
+  return CG_OK;
+}
+
+extern "C" int cg_pool2d_ld(const void* x, int x_ld, int N, int H, int W, int C, int k, int s, int p,
+                            int kind, int Ho, int Wo, void* y, int y_ld, const float* bias, int relu,
+                            cgStream stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || p < 0 || Ho <= 0 ||
+      Wo <= 0 || (kind != 0 && kind != 1))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_pool2d_ld: bad argument");
+  if ((C & 7) || (x_ld & 7) || (y_ld & 7) || x_ld < C || y_ld < C || ((uintptr_t)x & 15) ||
+      ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15)))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_pool2d_ld: channels and pitches must be multiples of 8 (>= C), "
+                            "slices 16-byte aligned");
+  const int64_t units = (int64_t)N * Ho * Wo * (C / 8);
+  int64_t blocks = (units + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  pool2d_vec8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)x, N, H, W, C / 8, k, s, p, kind, Ho, Wo, (bf16_t*)y, x_ld, y_ld, bias, relu);
+  CG_CHECK_LAUNCH("cg_pool2d_ld");
   return CG_OK;
 }
 

@@ -975,7 +975,7 @@ extern "C" int cg_gconv_ld_supported(const cgConvGeom* g, int in_ld, int out_ld)
 }
 
 extern "C" int cg_gconv_ld(const cgConvGeom* g, const void* in, int in_ld, const void* bt, void* out,
-                           int out_ld, int out_is_f32, const float* bias, int relu_out,
+                           int out_ld, int out_is_f32, const float* bias, int relu_cols,
                            cgStream stream) {
   int rc = check_geom(g, "cg_gconv_ld");
   if (rc) return rc;
@@ -985,9 +985,10 @@ extern "C" int cg_gconv_ld(const cgConvGeom* g, const void* in, int in_ld, const
                             "(cg_gconv_ld_supported)");
   if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))
     CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_ld: slices must start on 16-byte boundaries");
+  if (relu_cols < 0 || relu_cols > g->Co || (relu_cols & 7))
+    CG_FAIL(CG_ERR_BAD_ARG, "cg_gconv_ld: relu_cols must be a multiple of 8 in [0, Co]");
   hipStream_t st = (hipStream_t)stream;
-  cg_fast_conv_launch_ld(g, in, in_ld, bt, out, out_ld, out_is_f32, bias, nullptr,
-                         relu_out ? out : nullptr, 0.f, nullptr, st);
+  cg_fast_conv_launch_ld_cols(g, in, in_ld, bt, out, out_ld, out_is_f32, bias, relu_cols, st);
   CG_CHECK_LAUNCH("cg_gconv_ld");
   return CG_OK;
 }

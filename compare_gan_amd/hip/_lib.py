@@ -209,6 +209,8 @@ SIGNATURES = {
     "cg_inception_preprocess": (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp]),
     "cg_pool2d": (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, vp, vp]),
+    "cg_pool2d_ld": (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_int, c_int, vp, c_int, vp, c_int, vp]),
 }
 
 _lib = None

@@ -198,7 +198,8 @@ def gconv_ld_supported(geom, in_ld, out_ld):
 
 def gconv_ld(geom, x, bt, out, bias=None, relu=False):
     """cg_gconv_ld: conv (+ bias, + ReLU) reading a channel slice `x` of a wider NHWC tensor and
-    writing into the channel slice `out` of another (bf16, or fp32 out) -- both torch views."""
+    writing into the channel slice `out` of another (bf16, or fp32 out) -- both torch views.  relu:
+    True / False, or the number of leading output channels that get it (a multiple of 8)."""
     for t, dt, nm in ((x, BF16, "x"), (bt, BF16, "bt")):
         if not t.is_cuda or t.dtype != dt:
             raise ValueError("%s must be %s on the GPU" % (nm, dt))
@@ -214,9 +215,28 @@ def gconv_ld(geom, x, bt, out, bias=None, relu=False):
         raise ValueError("bt shape %s != (%d, %d)" % (tuple(bt.shape), geom.Co, Kp))
     if bias is not None and bias.numel() != geom.Co:
         raise ValueError("bias has the wrong number of elements")
+    relu_cols = geom.Co if relu is True else (0 if relu is False else int(relu))
     check(lib().cg_gconv_ld(ctypes.byref(geom), _p(x), _pixel_pitch(x, geom.Ci, "x"), _p(bt), _p(out),
                             _pixel_pitch(out, geom.Co, "out"), int(out.dtype == F32), _p(bias),
-                            int(bool(relu)), _stream()), "cg_gconv_ld")
+                            relu_cols, _stream()), "cg_gconv_ld")
+    return out
+
+
+def pool2d_ld(x, k, s, p, kind, ho, wo, out, bias=None, relu=False):
+    """cg_pool2d_ld: pooling (kind 0 max / 1 avg with TF 'SAME' counts) of a channel slice `x` into the
+    channel slice `out` (both bf16 torch views of NHWC tensors), then + bias (fp32 [C]) and ReLU."""
+    for t, nm in ((x, "x"), (out, "out")):
+        if not t.is_cuda or t.dtype != BF16:
+            raise ValueError("%s must be bf16 on the GPU" % nm)
+    _req(bias, F32, "bias", True)
+    n, h, w, c = x.shape
+    if tuple(out.shape) != (n, ho, wo, c):
+        raise ValueError("out shape %s, expected %s" % (tuple(out.shape), (n, ho, wo, c)))
+    if bias is not None and bias.numel() != c:
+        raise ValueError("bias has the wrong number of elements")
+    check(lib().cg_pool2d_ld(_p(x), _pixel_pitch(x, c, "x"), n, h, w, c, int(k), int(s), int(p),
+                             int(kind), int(ho), int(wo), _p(out), _pixel_pitch(out, c, "out"),
+                             _p(bias), int(bool(relu)), _stream()), "cg_pool2d_ld")
     return out
 
 

@@ -90,6 +90,7 @@ SPEC = [
 _CHUNK = int(os.environ.get("CGAMD_INCEPTION_BATCH", "512"))   # images per call of transform()
 _USE_LD = os.environ.get("CGAMD_INCEPTION_LD", "1") != "0"    # branches write into the block output
 _MERGE_HEADS = os.environ.get("CGAMD_INCEPTION_HEADS", "1") != "0"   # sibling 1x1 convolutions as one
+_SWAP_POOL = os.environ.get("CGAMD_INCEPTION_SWAP_POOL", "1") != "0"  # avg_pool -> 1x1 as 1x1 -> avg_pool
 POOL3_DIM = 2048
 NUM_LOGITS = 1008
 INPUT_SIZE = 299
@@ -194,16 +195,25 @@ class InceptionV3(object):
                  if b[0][0] == "conv" and b[0][3:6] == (1, 1, 1)]
         if len(heads) < 2:
           continue
-        ks = [self.weights[h[1] + "/kernel"] for _, h in heads]
-        bs = [self.weights[h[1] + "/bias"] for _, h in heads]
+        # ... and the `avg_pool 3x3 -> 1x1 conv -> ReLU` branch: the pooling (a per-channel linear map,
+        # TF 'SAME' counts included) commutes with the 1x1 convolution, so the convolution joins the
+        # heads (no bias, no ReLU on its columns: K.gconv_ld's relu_cols) and the pooling runs behind it
+        # on a quarter of the channels, adding bias and ReLU (K.pool2d_ld)
+        pooled = [(i, b[1]) for i, b in enumerate(op[2])
+                  if _SWAP_POOL and len(b) == 2 and b[0] == ("avg3",) and b[1][0] == "conv"
+                  and b[1][3:6] == (1, 1, 1)]
+        ks = [self.weights[h[1] + "/kernel"] for _, h in heads + pooled]
+        bs = [self.weights[h[1] + "/bias"] for _, h in heads] + \
+             [torch.zeros_like(self.weights[h[1] + "/bias"]) for _, h in pooled]
         name = op[1] + "/heads"
         self._bt[name + "/kernel"] = K.weight_prep(torch.cat(ks, dim=3).contiguous(), want_fwd=True)[0]
         self.weights[name + "/bias"] = torch.cat(bs).contiguous()
         cols, off = {}, 0
-        for (i, _), k in zip(heads, ks):
-          cols[i] = (off, int(k.shape[3]))
+        for (i, h), k in zip(heads + pooled, ks):
+          cols[i] = (off, int(k.shape[3]), h[1] if (i, h) in pooled else None)
           off += int(k.shape[3])
-        self._heads[op[1]] = (cols, off)
+        relu_cols = sum(int(self.weights[h[1] + "/kernel"].shape[3]) for _, h in heads)
+        self._heads[op[1]] = (cols, off, relu_cols)
 
   # -- ops -----------------------------------------------------------------------------------------
   # Every block of the graph ends in a concatenation along the channels.  Here the block's output is
@@ -236,7 +246,7 @@ class InceptionV3(object):
     return dst
 
   @staticmethod
-  def _pool(x, kind, k, s, same):
+  def _pool(x, kind, k, s, same, dst=None):
     n, h, w_, c = x.shape
     if same:
       p = (k - 1) // 2
@@ -244,7 +254,13 @@ class InceptionV3(object):
     else:
       p = 0
       ho, wo = (h - k) // s + 1, (w_ - k) // s + 1
-    return K.pool2d(x.contiguous(), k, s, p, kind, ho, wo)
+    if dst is not None and _USE_LD and c % 8 == 0:
+      return K.pool2d_ld(x, k, s, p, kind, ho, wo, dst)   # the pooling branch of a reduction block
+    y = K.pool2d(x.contiguous(), k, s, p, kind, ho, wo)
+    if dst is not None:
+      dst.copy_(y)
+      return dst
+    return y
 
   def _shape_after(self, ops, h, w_, c):
     """(h, w, c) after a list of ops (no launches): the size of a block's output buffer."""
@@ -270,17 +286,23 @@ class InceptionV3(object):
       dst = torch.empty((n, outs[0][0], outs[0][1], sum(o[2] for o in outs)), dtype=BF16,
                         device=x.device)
     cols, heads = {}, None
-    if block in self._heads and x.is_contiguous():
-      cols, width = self._heads[block]
+    if block in self._heads and x.is_contiguous() and _USE_LD:
+      cols, width, relu_cols = self._heads[block]
       geom = K.make_geom(n, h, w_, c, h, w_, width, 1, 1)
-      heads = K.gconv(geom, x, self._bt[block + "/heads/kernel"],
-                      bias=self.weights[block + "/heads/bias"], act_out=0.0)
+      if K.gconv_ld_supported(geom, c, width):
+        heads = torch.empty((n, h, w_, width), dtype=BF16, device=x.device)
+        K.gconv_ld(geom, x, self._bt[block + "/heads/kernel"], heads,
+                   bias=self.weights[block + "/heads/bias"], relu=relu_cols)
+      else:
+        cols = {}
     off = 0
     for i, (b, o) in enumerate(zip(branches, outs)):
       d = dst[..., off:off + o[2]]
       if i in cols:
         xb = heads[..., cols[i][0]:cols[i][0] + cols[i][1]]
-        if len(b) == 1:
+        if cols[i][2] is not None:   # the pooled branch: its 1x1 convolution ran with the heads
+          K.pool2d_ld(xb, 3, 1, 1, 1, h, w_, d, bias=self.weights[cols[i][2] + "/bias"], relu=True)
+        elif len(b) == 1:
           d.copy_(xb)           # the branch IS its 1x1 convolution: its columns move into the block
         else:
           self._emit(b[1:], xb, d)
@@ -302,16 +324,13 @@ class InceptionV3(object):
         x = self._concat(op[1], x, d)
         continue
       if op[0] == "max":
-        y = self._pool(x, 0, op[1], op[2], False)
+        y = self._pool(x, 0, op[1], op[2], False, d)
       elif op[0] == "avg3":
-        y = self._pool(x, 1, 3, 1, True)
+        y = self._pool(x, 1, 3, 1, True, d)
       elif op[0] == "max3s1":
-        y = self._pool(x, 0, 3, 1, True)
+        y = self._pool(x, 0, 3, 1, True, d)
       else:
         raise ValueError("unknown op %r" % (op,))
-      if d is not None:
-        d.copy_(y)
-        y = d
       x = y
     return x
 

@@ -125,12 +125,15 @@ int cg_gconv(const cgConvGeom* geom, const void* in, const void* bt, void* out, 
  * sibling 1x1 convolutions (the frozen graph behind eval_utils.py:41-49,165-175) -- a branch writes its
  * channels straight into the block's output, and the 1x1 convolutions that share an input run as one
  * convolution whose output the next layers read slice by slice.  Same arithmetic as cg_gconv with
- * gate_in = residual = NULL and gate_out = (relu_out ? out : NULL), slope 0.
+ * gate_in = residual = NULL and the ReLU of gate_out = out (slope 0) applied to the output channels
+ * [0, relu_cols) only (relu_cols a multiple of 8: Co = everywhere, 0 = nowhere; in between for a merged
+ * convolution some of whose columns are finished by another kernel -- the 1x1 convolution behind a
+ * block's 3x3 average pooling commutes with it and runs in front, cg_pool2d_ld adds bias and ReLU).
  * cg_gconv_ld_supported: 1 when the geometry has a kernel with this addressing (the MFMA one-tap
  * kernel: Ci % 32 == 0), else 0 -- the caller then uses cg_gconv on dense tensors. */
 int cg_gconv_ld_supported(const cgConvGeom* geom, int in_ld, int out_ld);
 int cg_gconv_ld(const cgConvGeom* geom, const void* in, int in_ld, const void* bt, void* out,
-                int out_ld, int out_is_f32, const float* bias, int relu_out, cgStream stream);
+                int out_ld, int out_is_f32, const float* bias, int relu_cols, cgStream stream);
 
 /* Batch-norm fusion around cg_gconv for forward passes that keep no autograd graph (the generator
  * forward of every discriminator sub-step, modular_gan.py:465-467): the producer convolution emits
@@ -737,6 +740,14 @@ int cg_inception_preprocess(const float* x, int N, int H, int W, int C, int Ho, 
  * pad > 0, TF 'SAME' avg-pool semantics), window k, stride s, symmetric padding p. bf16 NHWC. */
 int cg_pool2d(const void* x, int N, int H, int W, int C, int k, int s, int p, int kind, int Ho,
               int Wo, void* y, cgStream stream);
+/* The same pooling on channel slices (x_ld / y_ld: elements between consecutive pixels, >= C, multiples
+ * of 8, C % 8 == 0), finished by y = relu?(pool + bias): a pooling branch of an Inception block writes
+ * straight into the block output, and the `avg_pool 3x3 -> 1x1 conv -> ReLU` branch (the frozen graph
+ * behind eval_utils.py:165-175) runs as `1x1 conv` (a column group of the block's merged head
+ * convolution, cg_gconv_ld with relu_cols) `-> avg_pool 3x3 + bias + ReLU` -- the two linear maps commute,
+ * the pooling then moves a quarter of the channels. */
+int cg_pool2d_ld(const void* x, int x_ld, int N, int H, int W, int C, int k, int s, int p, int kind,
+                 int Ho, int Wo, void* y, int y_ld, const float* bias, int relu, cgStream stream);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,11 @@ CONV_CASES = [
     ("d_3x3_128", 4, 16, 16, 128, 128, 3, 1, 1),
     ("rgb_in_3x3", 4, 16, 16, 3, 128, 3, 1, 1),
     ("rgb_out_3x3", 2, 16, 16, 64, 3, 3, 1, 1),
+    # more than 128 channels beside an RGB tensor (resnet_cifar.py:108-111: the generator's last
+    # convolution 256 -> 3 and its data gradient, a 3 -> 256 convolution): two channel tiles of the stem kernel
+    ("rgb_in_3x3_co256", 3, 32, 32, 3, 256, 3, 1, 1),
+    ("rgb_in_3x3_co200", 2, 16, 16, 3, 200, 3, 1, 1),
+    ("rgb_out_3x3_ci256", 3, 32, 32, 256, 3, 3, 1, 1),
     ("up_3x3", 2, 4, 4, 256, 256, 3, 1, 2),
     ("s2_4x4", 2, 16, 16, 64, 128, 4, 2, 1),
     ("s2_5x5_asym", 2, 16, 16, 64, 128, 5, 2, 1),
@@ -1324,6 +1329,21 @@ def test_inception_preprocess_and_pool(K, dev):
     assert_close_bf16(K.pool2d(xb.to(dev), 3, 2, 0, 0, 4, 4), ref_max, "maxpool 3x3/2 valid")
     ref_avg = F.avg_pool2d(x64.permute(0, 3, 1, 2), 3, 1, 1, count_include_pad=False).permute(0, 2, 3, 1)
     assert_close_bf16(K.pool2d(xb.to(dev), 3, 1, 1, 1, 9, 9), ref_avg, "avgpool 3x3/1 same")
+    # the same poolings on channel slices, finished by bias + ReLU (cg_pool2d_ld)
+    wide64, wide = rand_bf16((3, 17, 17, 8 + 24 + 16), g)
+    bias = torch.randn((24,), generator=g, dtype=torch.float32)
+    xs64 = wide64[..., 8:32]
+    out = torch.full((3, 17, 17, 16 + 24 + 8), 5.0, dtype=BF16, device=dev)
+    K.pool2d_ld(wide.to(dev)[..., 8:32], 3, 1, 1, 1, 17, 17, out[..., 16:40], bias=bias.to(dev), relu=True)
+    ref = F.avg_pool2d(xs64.permute(0, 3, 1, 2), 3, 1, 1, count_include_pad=False).permute(0, 2, 3, 1)
+    assert_close_bf16(out[..., 16:40], (ref + bias.double()).clamp(min=0.0), "avgpool slices + bias + relu")
+    assert bool((out[..., :16] == 5.0).all()) and bool((out[..., 40:] == 5.0).all())
+    out2 = torch.zeros((3, 8, 8, 32), dtype=BF16, device=dev)
+    K.pool2d_ld(wide.to(dev)[..., 8:32], 3, 2, 0, 0, 8, 8, out2[..., 8:])
+    ref_max = F.max_pool2d(xs64.permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
+    assert_close_bf16(out2[..., 8:], ref_max, "maxpool slices")
+    assert torch.equal(out2[..., 8:].contiguous(),
+                       K.pool2d(wide.to(dev)[..., 8:32].contiguous(), 3, 2, 0, 0, 8, 8))
 
 
 @pytest.mark.parametrize("case", [
@@ -1369,6 +1389,15 @@ def test_gconv_on_channel_slices(K, dev, case):
     out32 = torch.zeros((N, geom.Ho, geom.Wo, Co + 8), dtype=torch.float32, device=dev)
     K.gconv_ld(geom, x_view, bt, out32[..., 8:], bias=None, relu=False)
     assert_close_f32(out32[..., 8:], ref - bias.double(), "gconv_ld fp32 %s" % (case,))
+    # ReLU on the leading output channels only (a merged convolution whose trailing columns another
+    # kernel finishes: cg_pool2d_ld adds bias and ReLU behind the pooling)
+    if Co >= 16:
+        rc = (Co // 2) // 8 * 8
+        part = torch.zeros((N, geom.Ho, geom.Wo, Co), dtype=BF16, device=dev)
+        K.gconv_ld(geom, x_view, bt, part, bias=bias.to(dev), relu=rc)
+        want = torch.cat([ref[..., :rc].clamp(min=0.0), ref[..., rc:]], dim=-1)
+        assert_close_bf16(part, want, "gconv_ld relu_cols %s" % (case,))
+        assert torch.equal(part[..., :rc], got[..., :rc])
     # what is not a slice is refused
     with pytest.raises(ValueError):
         K.gconv_ld(geom, x_view.transpose(1, 2), bt, out_wide[..., ob:ob + Co])   # H == W: shape fits, pitch not
