@@ -462,28 +462,65 @@ __global__ __launch_bounds__(256) void pool2d_vec8_kernel(const bf16_t* __restri
 
 // TF1 legacy bilinear resize (align_corners=False, half_pixel_centers=False):
 //   src = dst * (in / out);  lo = floor(src), hi = min(lo+1, in-1), frac = src - lo.
+// A thread produces 8 consecutive output elements (one 16-byte store; the index decode -- five 64-bit
+// divisions -- once per 8 and incremented in between): the element-per-thread form wrote the 275 MB of a
+// 512-image batch with 2-byte stores at 0.46 TB/s (0.6 ms per batch).  Same arithmetic per element.
+__device__ __forceinline__ float inception_resize_at(const float* __restrict__ x, int H, int W, int C,
+                                                     float sh, float sw, int n, int oh, int ow,
+                                                     int c) {
+  const float fy = oh * sh, fx = ow * sw;
+  const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float wy = fy - y0, wx = fx - x0;
+  const float* xp = x + (int64_t)n * H * W * C + c;
+  const float tl = xp[((int64_t)y0 * W + x0) * C], tr = xp[((int64_t)y0 * W + x1) * C];
+  const float bl = xp[((int64_t)y1 * W + x0) * C], br = xp[((int64_t)y1 * W + x1) * C];
+  const float top = tl + (tr - tl) * wx, bot = bl + (br - bl) * wx;
+  const float v = top + (bot - top) * wy;
+  return (v - 128.f) / 128.f;
+}
 __global__ void inception_preprocess_kernel(const float* __restrict__ x, int N, int H, int W,
                                             int C, int Ho, int Wo, bf16_t* __restrict__ y) {
   const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int64_t total8 = total / 8;
   const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i8 = gid; i8 < total8; i8 += stride) {
+    const int64_t i = i8 * 8;
+    int c = (int)(i % C);
+    int64_t q = i / C;
+    int ow = (int)(q % Wo);
+    q /= Wo;
+    int oh = (int)(q % Ho);
+    int n = (int)(q / Ho);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = inception_resize_at(x, H, W, C, sh, sw, n, oh, ow, c);
+      if (++c == C) {
+        c = 0;
+        if (++ow == Wo) {
+          ow = 0;
+          if (++oh == Ho) {
+            oh = 0;
+            ++n;
+          }
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(y + i) = pack8_bf16(v);
+  }
+  // the last total % 8 elements
+  const int64_t i = total8 * 8 + gid;
+  if (i < total) {
     const int c = (int)(i % C);
     int64_t q = i / C;
     const int ow = (int)(q % Wo);
     q /= Wo;
     const int oh = (int)(q % Ho);
     const int n = (int)(q / Ho);
-    const float fy = oh * sh, fx = ow * sw;
-    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-    const float wy = fy - y0, wx = fx - x0;
-    const float* xp = x + (int64_t)n * H * W * C + c;
-    const float tl = xp[((int64_t)y0 * W + x0) * C], tr = xp[((int64_t)y0 * W + x1) * C];
-    const float bl = xp[((int64_t)y1 * W + x0) * C], br = xp[((int64_t)y1 * W + x1) * C];
-    const float top = tl + (tr - tl) * wx, bot = bl + (br - bl) * wx;
-    const float v = top + (bot - top) * wy;
-    y[i] = f2bf((v - 128.f) / 128.f);
+    y[i] = f2bf(inception_resize_at(x, H, W, C, sh, sw, n, oh, ow, c));
   }
 }
 
@@ -947,7 +984,7 @@ extern "C" int cg_inception_preprocess(const float* x, int N, int H, int W, int 
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0)
     CG_FAIL(CG_ERR_BAD_ARG, "cg_inception_preprocess: bad argument");
   const int64_t total = (int64_t)N * Ho * Wo * C;
-  inception_preprocess_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(
+  inception_preprocess_kernel<<<grid_for(total / 8 + 8), kBlock, 0, (hipStream_t)stream>>>(
       x, N, H, W, C, Ho, Wo, (bf16_t*)y);
   CG_CHECK_LAUNCH("cg_inception_preprocess");
   return CG_OK;

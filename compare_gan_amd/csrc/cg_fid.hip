@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void bj_sweep_kernel(const double* __restrict__ mpart, int gs,
                                                        double tol, double* __restrict__ jg,
                                                        int* __restrict__ rot,
-                                                       int* __restrict__ flags) {
+                                                       int* __restrict__ flags, int inner) {
   if (flags[0]) return;
   __shared__ double M[JR][JR + 1];
   __shared__ double J[JR][JR + 1];
@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256) void bj_sweep_kernel(const double* __restrict_
     J[r][c] = r == c ? 1.0 : 0.0;
   }
   __syncthreads();
-  for (int ir = 0; ir < JR - 1; ++ir) {
+  // `inner` cyclic sweeps over the pair's Gram matrix (CGAMD_JACOBI_INNER): a better diagonalised block
+  // per round costs ~30 us of this kernel and can save outer sweeps of 127 rounds x 60-73 us
+  for (int ir = 0; ir < inner * (JR - 1); ++ir) {
     if (t < JB) {
       const int mm = JR - 1;
       int p, q;
@@ -907,6 +909,11 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
       return e ? atoi(e) : 1;
     }();
     const int split_env = v ? split_env0 : 1;   // (the fused round kernel always carries V)
+    static const int inner_env = []() {
+      const char* e = getenv("CGAMD_JACOBI_INNER");
+      const int n = e ? atoi(e) : 1;
+      return n < 1 ? 1 : (n > 4 ? 4 : n);
+    }();
     const int chunks = d / JCW;
     const int gs = (chunks % 4 == 0) ? 4 : ((chunks % 2 == 0) ? 2 : 1);
     const int ac = (v ? 2 : 1) * chunks;        // chunks the apply pass walks: G (and V)
@@ -918,7 +925,7 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
       for (int r = 0; r < nb - 1; ++r) {
         if (split_env) {
           bj_gram_kernel<<<dim3(nb / 2, gs), 256, 0, q>>>(a, d, nb, r, gs, mpart, flags);
-          bj_sweep_kernel<<<nb / 2, 256, 0, q>>>(mpart, gs, tol, jg, rot, flags);
+          bj_sweep_kernel<<<nb / 2, 256, 0, q>>>(mpart, gs, tol, jg, rot, flags, inner_env);
           bj_apply_kernel<<<dim3(nb / 2, as), 256, 0, q>>>(a, v, d, nb, r, as, jg, rot, flags);
         } else {
           bjacobi_round_kernel<<<nb / 2, 256, 0, q>>>(a, v, d, nb, r, tol, flags);
@@ -1039,6 +1046,17 @@ __global__ __launch_bounds__(256) void spectral_sqrt_kernel(const double* __rest
   __syncthreads();
   if (threadIdx.x == 0 && sum_out) *sum_out = sm[0] + sm[1] + sm[2] + sm[3];
 }
+// d[i] = f(s_i) / s_i^2 for s_i = |w_i| > tiny, else 0 (f as above): the weights that rebuild the
+// symmetric square root from the rows g_i = lambda_i v_i the one-sided Jacobi solver leaves in its
+// matrix argument -- sum_i f(s_i) v_i v_i^T = G^T diag(d) G -- without accumulating V.
+__global__ __launch_bounds__(256) void spectral_root_scale_kernel(const double* __restrict__ w, int n,
+                                                                  double eps,
+                                                                  double* __restrict__ d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double a = fabs(w[i]);
+  d[i] = a > 1e-150 ? (a < eps ? a : sqrt(a)) / (a * a) : 0.0;
+}
 // out = tr(sigma) + tr(sigma_v) - 2 * sqrt_trace + |m - m_v|^2   (fid_score.py:58-75 via tfgan)
 __global__ __launch_bounds__(256) void fid_combine_kernel(const double* __restrict__ sigma,
                                                           const double* __restrict__ sigma_v,
@@ -1072,6 +1090,14 @@ extern "C" int cg_spectral_sqrt_f64(const double* w, int n, double eps, double* 
     CG_FAIL(CG_ERR_BAD_ARG, "cg_spectral_sqrt_f64: bad argument");
   spectral_sqrt_kernel<<<1, 256, 0, (hipStream_t)stream>>>(w, n, eps, f, sum_out);
   CG_CHECK_LAUNCH("cg_spectral_sqrt_f64");
+  return CG_OK;
+}
+
+extern "C" int cg_spectral_root_scale_f64(const double* w, int n, double eps, double* d,
+                                          cgStream stream) {
+  if (!w || !d || n <= 0) CG_FAIL(CG_ERR_BAD_ARG, "cg_spectral_root_scale_f64: bad argument");
+  spectral_root_scale_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(w, n, eps, d);
+  CG_CHECK_LAUNCH("cg_spectral_root_scale_f64");
   return CG_OK;
 }
 

@@ -198,6 +198,7 @@ SIGNATURES = {
     "cg_poly3_kernel_sums_f64": (c_int, [vp, c_int, c_int, c_f64, vp, vp, c_sz, vp]),
     "cg_rowscale_f64": (c_int, [vp, vp, vp, c_int, c_int, vp]),
     "cg_spectral_sqrt_f64": (c_int, [vp, c_int, c_f64, vp, vp, vp]),
+    "cg_spectral_root_scale_f64": (c_int, [vp, c_int, c_f64, vp, vp]),
     "cg_fid_combine_f64": (c_int, [vp, vp, vp, vp, c_int, vp, vp, vp]),
     "cg_sytrd_eigvals_workspace_bytes": (c_sz, [c_int]),
     "cg_sytrd_eigvals_f64": (c_int, [vp, c_int, vp, vp, vp, c_sz, vp]),

@@ -1393,6 +1393,15 @@ def spectral_sqrt_f64(w, eps, want_values=True):
     return f, total
 
 
+def spectral_root_scale_f64(w, eps):
+    """f(|w|) / w^2 (0 where w = 0) on the device: the row weights of G^T diag(.) G (cg_spectral_root_scale_f64)."""
+    _req(w, F64, "w")
+    d = torch.empty_like(w)
+    check(lib().cg_spectral_root_scale_f64(_p(w), w.numel(), float(eps), _p(d), _stream()),
+          "cg_spectral_root_scale_f64")
+    return d
+
+
 def fid_combine_f64(sigma, sigma_v, mean, mean_v, sqrt_trace):
     """tr(sigma) + tr(sigma_v) - 2 sqrt_trace + |mean - mean_v|^2 as a device scalar [1]."""
     for t, nm in ((sigma, "sigma"), (sigma_v, "sigma_v"), (mean, "mean"), (mean_v, "mean_v"),

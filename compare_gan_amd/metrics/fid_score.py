@@ -42,6 +42,8 @@ def _activations_on_device(acts, device):
 _SOLVER = os.environ.get("CGAMD_FID_SOLVER", "auto")
 # the second matrix square root only contributes its TRACE: no eigenvectors (A/B switch, 1 = on)
 _VALUES_ONLY = int(os.environ.get("CGAMD_FID_VALUES_ONLY", "1"))
+# the FIRST root from the rotated rows themselves instead of an accumulated eigenvector matrix (1 = on)
+_ROOT_FROM_G = int(os.environ.get("CGAMD_FID_ROOT_FROM_G", "1"))
 _NS_MAX_ITER = 64
 # The trace of the second square root from eigenvalues computed by tridiagonalisation + bisection
 # (cg_sytrd_eigvals_f64: ~0.05 s at d = 2048 against ~0.33 s of values-only Jacobi sweeps), accepted only
@@ -182,9 +184,19 @@ def frechet_distance(real_activations, generated_activations, device="cuda:0"):
     return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())
   # sqrt(sigma) = V^T diag(f(w)) V  (rows of V are eigenvectors); f and every scalar stay on the
   # device: one host read at the very end
-  w, v = K.syevj_f64(sigma.clone(), max_sweeps=_SWEEPS, tol=_TOL)
-  f, _ = K.spectral_sqrt_f64(w, _EPS)
-  sqrt_sigma = K.gemm_f64(v, K.rowscale_f64(v, f), ta=True)
+  # One-sided Jacobi rotates the rows of G (= sigma at the start) until they are orthogonal: g_i =
+  # lambda_i v_i.  The root sum_i f(lambda_i) v_i v_i^T is then G^T diag(f(|lambda_i|) / lambda_i^2) G:
+  # no eigenvector matrix has to be carried through the sweeps (half the traffic of every apply pass).
+  # (A covariance is positive semi-definite: a negative lambda_i is rounding noise of size ~1e-16
+  # |sigma|, far under the 1e-10 cut-off, where f(|lambda|) = |lambda| -- its sign does not matter.)
+  g = sigma.clone()
+  w, v = K.syevj_f64(g, max_sweeps=_SWEEPS, tol=_TOL, want_vectors=_ROOT_FROM_G == 0)
+  if v is None:
+    LAST_SOLVER["sqrt_sigma"] = "jacobi (rows)"
+    sqrt_sigma = K.gemm_f64(g, K.rowscale_f64(g, K.spectral_root_scale_f64(w, _EPS)), ta=True)
+  else:
+    f, _ = K.spectral_sqrt_f64(w, _EPS)
+    sqrt_sigma = K.gemm_f64(v, K.rowscale_f64(v, f), ta=True)
   inner = K.gemm_f64(K.gemm_f64(sqrt_sigma, sigma_v), sqrt_sigma)
   sqrt_trace = _trace_sqrt_values_only(inner, _trace_scale(sigma, sigma_v))
   return float(K.fid_combine_f64(sigma, sigma_v, m, m_v, sqrt_trace).item())

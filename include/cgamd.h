@@ -718,6 +718,11 @@ int cg_spectral_sqrt_bound_f64(const double* w, int n, double eps, double delta_
  *   cg_fid_combine_f64: *out = tr(sigma) + tr(sigma_v) - 2 * *sqrt_trace + |mean - mean_v|^2. */
 int cg_spectral_sqrt_f64(const double* w, int n, double eps, double* f, double* sum_out,
                          cgStream stream);
+/* d[i] = f(|w_i|) / w_i^2 (0 for w_i = 0), f as in cg_spectral_sqrt_f64: cg_syevj_f64 with v = NULL
+ * leaves the rows g_i = lambda_i v_i in its matrix argument, so the symmetric square root of a
+ * covariance, sum_i f(lambda_i) v_i v_i^T, is G^T diag(d) G -- one GEMM, no eigenvector accumulation
+ * in the sweeps (metrics/fid_score.py:58-75 via tfgan _symmetric_matrix_square_root). */
+int cg_spectral_root_scale_f64(const double* w, int n, double eps, double* d, cgStream stream);
 int cg_fid_combine_f64(const double* sigma, const double* sigma_v, const double* mean,
                        const double* mean_v, int d, const double* sqrt_trace, double* out,
                        cgStream stream);
