@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void bj_gram_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void bj_sweep_kernel(const double* __restrict__ mpart, int gs,
                                                        double tol, double* __restrict__ jg,
                                                        int* __restrict__ rot,
-                                                       int* __restrict__ flags, int inner) {
+                                                       int* __restrict__ flags) {
   if (flags[0]) return;
   __shared__ double M[JR][JR + 1];
   __shared__ double J[JR][JR + 1];
@@ -502,9 +502,9 @@ __global__ __launch_bounds__(256) void bj_sweep_kernel(const double* __restrict_
     J[r][c] = r == c ? 1.0 : 0.0;
   }
   __syncthreads();
-  // `inner` cyclic sweeps over the pair's Gram matrix (CGAMD_JACOBI_INNER): a better diagonalised block
-  // per round costs ~30 us of this kernel and can save outer sweeps of 127 rounds x 60-73 us
-  for (int ir = 0; ir < inner * (JR - 1); ++ir) {
+  // (two or three cyclic sweeps over the pair's Gram matrix per round do NOT save outer sweeps: FID-10k
+  // statistics 0.241 -> 0.306 -> 0.385 s, profiles/r06_fid_stats.txt)
+  for (int ir = 0; ir < JR - 1; ++ir) {
     if (t < JB) {
       const int mm = JR - 1;
       int p, q;
@@ -909,11 +909,6 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
       return e ? atoi(e) : 1;
     }();
     const int split_env = v ? split_env0 : 1;   // (the fused round kernel always carries V)
-    static const int inner_env = []() {
-      const char* e = getenv("CGAMD_JACOBI_INNER");
-      const int n = e ? atoi(e) : 1;
-      return n < 1 ? 1 : (n > 4 ? 4 : n);
-    }();
     const int chunks = d / JCW;
     const int gs = (chunks % 4 == 0) ? 4 : ((chunks % 2 == 0) ? 2 : 1);
     const int ac = (v ? 2 : 1) * chunks;        // chunks the apply pass walks: G (and V)
@@ -925,7 +920,7 @@ extern "C" int cg_syevj_f64(double* a, int d, double* w, double* v, int max_swee
       for (int r = 0; r < nb - 1; ++r) {
         if (split_env) {
           bj_gram_kernel<<<dim3(nb / 2, gs), 256, 0, q>>>(a, d, nb, r, gs, mpart, flags);
-          bj_sweep_kernel<<<nb / 2, 256, 0, q>>>(mpart, gs, tol, jg, rot, flags, inner_env);
+          bj_sweep_kernel<<<nb / 2, 256, 0, q>>>(mpart, gs, tol, jg, rot, flags);
           bj_apply_kernel<<<dim3(nb / 2, as), 256, 0, q>>>(a, v, d, nb, r, as, jg, rot, flags);
         } else {
           bjacobi_round_kernel<<<nb / 2, 256, 0, q>>>(a, v, d, nb, r, tol, flags);
