@@ -57,13 +57,16 @@ def test_pmc_traffic_summary(tmp_path):
 def test_bench_reads_the_committed_traffic_summary():
     bench = _load(os.path.join(ROOT, "bench.py"), "bench_module")
     summary = json.load(open(bench.PMC_TRAFFIC_FILE))["workloads"]
-    assert os.path.basename(bench.PMC_TRAFFIC_FILE) == "r05_pmc_traffic.json"
+    assert os.path.basename(bench.PMC_TRAFFIC_FILE) == "r06_pmc_traffic.json"
     for family in ("hconv_kernel<128, *>", "hwgrad_kernel<*>", "sconv_kernel<*>", "swgrad_kernel<*>"):
         assert bench.pmc_traffic(family) == \
             summary["cifar"]["families"][family]["hbm_bytes_per_launch"] > 0
     for family in ("hconv_kernel<128, *>", "hwgrad_kernel<*>", "hconv_kernel<64, *>"):
         assert bench.pmc_traffic(family, "resnet128_dstep") == \
             summary["resnet128_dstep"]["families"][family]["hbm_bytes_per_launch"] > 0
+    for family in ("hconv_kernel<128, *>", "fast_conv_kernel<128, 128, *>", "fast_wgrad_kernel<64, *>"):
+        assert bench.pmc_traffic(family, "biggan128_bs256") == \
+            summary["biggan128_bs256"]["families"][family]["hbm_bytes_per_launch"] > 0
     assert bench.pmc_traffic("no_such_kernel") is None
 
 
