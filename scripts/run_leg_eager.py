@@ -9,6 +9,7 @@ from tests import gan_util as U
 LEGS = {
     "resnet128_dstep": ("resnet_lsun-bedroom128.gin", ("penalty.fn = @no_penalty",), 64, "dstep"),
     "resnet128_dstep_gp": ("resnet_lsun-bedroom128.gin", (), 64, "dstep"),
+    "resnet_lsun128_step": ("resnet_lsun-bedroom128.gin", (), 32, "step"),
     "biggan128": ("biggan_imagenet128.gin", (), 64, "step"),
     "biggan128_bs256": ("biggan_imagenet128.gin", (), 256, "step"),
     "cifar": ("resnet_cifar10.gin", (), 64, "step"),
